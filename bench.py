@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched Sus-Net environment hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4] [--mode fused|step]
+
+A "step" is one lockstep tick of the hot path over the whole batch (every env samples uniform role-valid
+actions, steps, and auto-resets on done|truncated): the random-action rollout BASELINE.json names
+(`ReplayBuffer.populate`'s loop, reference src/replay_memory.py:96-143, minus the buffer).
+
+  --mode fused (default): `susnet_rollout`, `--ticks` ticks per launch, the trajectory (actions, rewards,
+                          done, truncated, raw observation) written to HBM every tick.
+  --mode step           : the drop-in API, two launches per tick (`sample_actions` + `step`).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the batch is sharded by contiguous global env
+ids, per-GPU batch fixed (weak scaling); the only collective is one all-gather of the episode metrics after
+the timed region (sus-net_amd/dist.py).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(workload="cfg2: ImposterTrainingGround 1v1, 9x9 no walls, 0 jobs (notebook rewards), batch 65536/GPU",
+                 cls="itg", kw=dict(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
+                                    time_step_reward=0, include_walls=False), n=9, A=2, J=0, batch=65536),
+    "cfg3": dict(workload="cfg3: FourRoomEnv 1v2, 14x14 walled, 4 jobs, batch 65536/GPU",
+                 cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536),
+    "cfg4": dict(workload="cfg4: FourRoomEnv 2v6, 14x14 walled, 4 jobs, batch 32768/GPU",
+                 cls="base", kw=dict(n_imposters=2, n_crew=6, n_jobs=4), n=14, A=8, J=4, batch=32768),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_step(A, J, N, obs):
+    """B_step = 12A + 4J + 6 (+ 4*A*2N flat one-hot, + 4*(A+2)*N^2 planes)."""
+    b = 12 * A + 4 * J + 6
+    if obs == "flat":
+        b += 4 * A * 2 * N
+    elif obs == "planes":
+        b += 4 * (A + 2) * N * N
+    return b
+
+
+def stored_bytes_per_step(A, J, N, obs):
+    """What the fused rollout actually writes per env-step: actions u8 + rewards f32 + done + trunc + obs."""
+    b = A + 4 * A + 2
+    if obs == "raw":
+        b += 3 * A + (3 * J if J else 0)
+    elif obs == "flat":
+        b += 4 * A * 2 * N
+    elif obs == "planes":
+        b += 4 * (A + 2) * N * N + 4 * (A + J)
+    return b
+
+
+def make_env(pkg, spec, batch, seed, env_id_base, device, obs_cfg=None):
+    cls = {"itg": pkg.BatchedImposterTrainingGround, "base": pkg.BatchedFourRoomEnv}[spec["cls"]]
+    kw = dict(spec["kw"])
+    walls = kw.pop("include_walls", True)
+    return cls(**kw, grid=pkg.four_room_grid(spec["n"], walls), batch=batch, device=device, rng="philox", seed=seed,
+               env_id_base=env_id_base, auto_reset=True, export_state=False, check_errors=False, obs=obs_cfg)
+
+
+def cpu_baseline(spec, target_seconds=12.0):
+    """The CPU oracle (oracle/susnet_oracle.c, proven step-for-step equal to the reference on the golden
+    traces) timed on this box's host cores with the same loop shape. Reported, never the target."""
+    import numpy as np
+    from oracle import oracle as om
+
+    kw = dict(spec["kw"])
+    walls = kw.pop("include_walls", True)
+    pkg = importlib.import_module("sus-net_amd")
+    grid = pkg.four_room_grid(spec["n"], walls).astype(np.uint8)
+    if spec["cls"] == "itg":
+        kw.setdefault("shuffle_imposter_index", False)
+    cfg = om.make_config(spec["cls"], grid=grid, **kw)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    B = 64 * cores
+    ob = om.OracleBatch(cfg, B)
+    ob.seed_mt(range(B))  # the reference's own stream: numpy-legacy MT19937, one seed per env
+    out = {}
+    for label, threads in (("1", 1), ("all", cores)):
+        steps = 2000
+        t0 = time.perf_counter()
+        n, _, _ = ob.random_rollout(steps, threads)
+        dt = time.perf_counter() - t0
+        rate = n / dt
+        steps = max(2000, int(rate * (target_seconds / 2) / B))
+        t0 = time.perf_counter()
+        n, eps, _ = ob.random_rollout(steps, threads)
+        dt = time.perf_counter() - t0
+        out[label] = dict(rate=n / dt, n=n, seconds=dt, episodes=eps)
+    return dict(
+        value=out["all"]["rate"], unit="env-steps/s", cores=cores, kind="port",
+        sample=(f"C oracle, numpy-legacy MT19937 stream, {B} envs x {out['all']['n'] // B} steps random-action rollout "
+                f"with reset on done|truncated ({out['all']['seconds']:.1f} s on {cores} threads)"),
+        single_thread_value=out["1"]["rate"],
+        reference_python_measured_in_build_container=dict(
+            note="reference Python env, Xeon 2.1 GHz, 1 process / 8 processes (BASELINE.md section 2); not measured on this box",
+            cfg2=[20.7e3, 158e3], cfg3_9x9=[12.8e3, 96e3], cfg4_9x9=[6.8e3, 53e3]),
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8192)
+    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="fused", choices=["fused", "step"])
+    ap.add_argument("--obs", default="raw", choices=["none", "raw", "flat", "planes"])
+    ap.add_argument("--ticks", type=int, default=128, help="ticks per fused launch")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    pkg = importlib.import_module("sus-net_amd")
+    rank, world, local = pkg.dist.init_from_env("nccl")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    spec = CONFIGS[args.config]
+    A, J, N = spec["A"], spec["J"], spec["n"]
+    B = args.batch or spec["batch"]
+    seed = 1234
+
+    def obs_config(mode):
+        if mode == "none":
+            return None
+        if mode == "raw":
+            return pkg.ObsConfig("raw", dtype=torch.uint8)
+        if mode == "flat":
+            return pkg.ObsConfig("flat", ["onehot_pos"], dtype=torch.float32)
+        return pkg.ObsConfig("planes", dtype=torch.float32)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def run_fused(env, n_ticks, T, bufs):
+        done = 0
+        launches = 0
+        while done < n_ticks:
+            t = min(T, n_ticks - done)
+            env.rollout_into(t, bufs)
+            done += t
+            launches += 1
+        return launches
+
+    def run_step(env, n_ticks):
+        for _ in range(n_ticks):
+            a = env.sample_actions()
+            env.step(a)
+        return 2 * n_ticks
+
+    def measure(mode, obs_mode, K, W):
+        oc = obs_config(obs_mode) if mode == "fused" else None
+        env = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=(obs_config(obs_mode) if mode == "step" else None))
+        env.reset()
+        bufs = env.alloc_rollout(args.ticks, obs=oc) if mode == "fused" else None
+        runner = (lambda n: run_fused(env, n, args.ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
+        runner(W)
+        sync_all()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(torch.cuda.current_stream(device))
+        launches = runner(K)
+        ev1.record(torch.cuda.current_stream(device))
+        sync_all()
+        dt = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        env.poll_errors()
+        metrics = pkg.dist.node_metrics(env)  # the ONE collective: all-gather of the episode totals
+        return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, env=env)
+
+    K, W = args.steps, args.warmup
+    res = measure(args.mode, args.obs, K, W)
+    total_steps = B * world * K
+    value = total_steps / res["seconds"]
+    # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration (HIP events)
+    steps_per_launch = B * (args.ticks if args.mode == "fused" else 1)
+    dominant_launches = res["launches"] if args.mode == "fused" else res["launches"] // 2
+    avg_launch_s = (res["device_ms"] / 1e3) / max(1, res["launches"] if args.mode == "fused" else dominant_launches)
+    if args.mode == "fused" and K % args.ticks:
+        avg_launch_s = (res["device_ms"] / 1e3) / (K / args.ticks)
+    b_alg = algorithmic_bytes_per_step(A, J, N, args.obs)
+    b_stored = stored_bytes_per_step(A, J, N, args.obs)
+    achieved = steps_per_launch * b_alg / avg_launch_s / 1e9
+    line = {
+        "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": res["seconds"] * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": spec["workload"], "mode": args.mode, "obs": args.obs, "batch_per_gpu": B,
+                   "global_batch": B * world, "ticks_per_launch": args.ticks if args.mode == "fused" else 1,
+                   "rng": "philox4x32-10 in-kernel", "auto_reset": True, "parallelism": f"dp{world}",
+                   "agent_steps_per_s": value * A},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "k_rollout" if args.mode == "fused" else "k_step<PhiloxRng>",
+            "algorithmic_bytes_per_env_step": b_alg, "stored_bytes_per_env_step": b_stored,
+            "achieved_stored_GBs": steps_per_launch * b_stored / avg_launch_s / 1e9,
+            "env_steps_per_launch": steps_per_launch, "avg_launch_us": avg_launch_s * 1e6,
+            "note": "timed with HIP events on the launch stream over the timed region; see profiles/ for rocprofv3",
+        },
+        "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
+    }
+    del res
+    if rank == 0 and world == 1 and not args.no_secondary:
+        other = "step" if args.mode == "fused" else "fused"
+        r2 = measure(other, args.obs, 512 if other == "step" else 2048, 64)
+        k2 = 512 if other == "step" else 2048
+        line["secondary"] = {"mode": other, "value": B * k2 / r2["seconds"], "unit": "env-steps/s",
+                             "ms_per_step": r2["seconds"] * 1e3 / k2, "launches_per_step": 2 if other == "step" else 1.0 / args.ticks}
+        del r2
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(spec)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,238 @@
+/*
+ * susnet.h -- C ABI of libsusnet_hip.so: batched, MI355X-native (gfx950) implementation of the Sus-Net
+ * grid-world environment hot path (reset / sample_actions / step / fused random rollout / observation
+ * extraction), stepping `batch` independent episodes in lockstep, one wavefront lane per environment.
+ *
+ * The reference is a pure-Python gymnasium.Env (no FFI of its own), so every entry point names the
+ * reference METHOD it replaces (paths relative to the reference repo root):
+ *
+ *   susnet_create          FourRoomEnv.__init__            src/environment/base.py:103-228
+ *                          ImposterTrainingGround.__init__ src/environment/pred_prey.py:26-76
+ *                          FourRoomEnvWithTagging.__init__ src/environment/tagging.py:10-60
+ *   susnet_reset           FourRoomEnv.reset               src/environment/base.py:251-324 (tagging.py:62-101)
+ *   susnet_sample_actions  FourRoomEnv.sample_actions      src/environment/base.py:326-330
+ *   susnet_step            FourRoomEnv.step                src/environment/base.py:332-407 (tagging.py:120-235)
+ *                          + _agent_step 462-533, check_win_condition 409-460 (pred_prey.py:78-99),
+ *                            _merge_rewards 553-563, EnvMetricHandler src/metrics.py:35-64
+ *   susnet_rollout         ReplayBuffer.populate's loop    src/replay_memory.py:96-143 (minus the buffer)
+ *   susnet_observe         flatten_state base.py:234; FlatFeaturizer / GlobalFeaturizer
+ *                          src/features/model_ready.py:219-370, src/features/component.py:83-482
+ *   susnet_export_state    the state tuple step()/reset() return (base.py:317-324, 397-402)
+ *   susnet_import_state    direct assignment to env.agent_positions etc. (what callers/tests do)
+ *
+ * Conventions
+ *   - plain C types only; every device buffer is a caller-owned pointer (the Python host passes
+ *     torch-ROCm tensor data_ptr()s); the library never allocates or frees device memory.
+ *   - every call returns 0 on success or a negative SUSNET_E_* code; susnet_last_error() gives text.
+ *   - all launches are asynchronous on the hipStream_t passed as `stream` (void*; NULL = default).
+ *   - per-environment input errors (reference AssertionError / IndexError) are recorded in a device
+ *     error word and reported by susnet_poll_errors(); an environment with a bad action is not stepped.
+ *   - a handle is owned by one host thread; distinct handles are independent.
+ */
+#ifndef SUSNET_H
+#define SUSNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUSNET_ABI_VERSION 1
+
+#define SUSNET_MAX_AGENTS 16
+#define SUSNET_MAX_JOBS 16
+#define SUSNET_MAX_GRID 16
+#define SUSNET_N_METRICS 13 /* SusMetrics, src/metrics.py:7-20, in declaration order */
+#define SUSNET_N_LIFETIME 12
+
+/* variant = reference class */
+#define SUSNET_VARIANT_BASE 0
+#define SUSNET_VARIANT_ITG 1
+#define SUSNET_VARIANT_TAGGING 2
+
+/* word source of all random decisions */
+#define SUSNET_RNG_TAPE 1   /* caller-supplied raw 32-bit words consumed with numpy-legacy semantics:
+                               given numpy's MT19937 output for seed s, results equal the reference's */
+#define SUSNET_RNG_PHILOX 2 /* Philox4x32-10 keyed (seed, global env id): production stream */
+
+/* error codes */
+#define SUSNET_OK 0
+#define SUSNET_E_INVALID (-1)  /* bad argument / config (reference ctor asserts, base.py:243-249) */
+#define SUSNET_E_HIP (-2)      /* a HIP call failed */
+#define SUSNET_E_STATE (-3)    /* state not bound */
+#define SUSNET_E_ACTION_ASSERT (-4) /* some env got action >= action_space.n (base.py:360-362) */
+#define SUSNET_E_ACTION_INDEX (-5)  /* some env got a role-invalid action index (base.py:379-382) */
+#define SUSNET_E_TAPE (-6)     /* random tape exhausted */
+
+/* bits of the device error word */
+#define SUSNET_ERRBIT_ASSERT 1u
+#define SUSNET_ERRBIT_INDEX 2u
+#define SUSNET_ERRBIT_TAPE 4u
+
+/* dtypes of caller buffers */
+#define SUSNET_U8 0
+#define SUSNET_I32 1
+#define SUSNET_I64 2
+#define SUSNET_F32 3
+#define SUSNET_F64 4
+
+/* action / reward buffer layouts */
+#define SUSNET_LAYOUT_AB 0 /* [A][B]  agent-major (SoA, what the kernels prefer) */
+#define SUSNET_LAYOUT_BA 1 /* [B][A]  env-major (what reference callers index as actions[b]) */
+
+/* observation modes (susnet_obs_spec.mode) */
+#define SUSNET_OBS_NONE 0
+#define SUSNET_OBS_RAW 1    /* flatten_state: [x0,y0,..., alive.., jobxy.., jobdone.. (, used, counts, timer_left)] */
+#define SUSNET_OBS_FLAT 2   /* concatenation of flat components, FlatFeaturizer */
+#define SUSNET_OBS_PLANES 3 /* GlobalFeaturizer: spatial [A+2][N][N] + non_spatial [A(+A)+J] */
+
+/* flat components (src/features/component.py) */
+#define SUSNET_F_ONEHOT_POS 0
+#define SUSNET_F_COORD_POS 1
+#define SUSNET_F_ALIVE_CREW 2
+#define SUSNET_F_L1_CREW 3
+#define SUSNET_F_CLOSEST_CREW 4
+#define SUSNET_F_WALLS3X3 5
+#define SUSNET_F_DIST_TO_IMP 6
+#define SUSNET_F_ROOM_LOC 7
+
+/* lifetime accumulator rows (per env, summed over finished episodes) */
+#define SUSNET_L_EPISODES 0
+#define SUSNET_L_CREW_WON 1
+#define SUSNET_L_IMPOSTER_WON 2
+#define SUSNET_L_TRUNCATED 3
+#define SUSNET_L_KILLS 4
+#define SUSNET_L_COMPLETED_JOBS 5
+#define SUSNET_L_SABOTAGED_JOBS 6
+#define SUSNET_L_IMP_VOTED_OUT 7
+#define SUSNET_L_CREW_VOTED_OUT 8
+#define SUSNET_L_EPISODE_STEPS 9
+#define SUSNET_L_ENV_STEPS 10
+#define SUSNET_L_RESERVED 11
+
+typedef struct susnet_env susnet_env; /* opaque host-side handle */
+
+/* Constructor arguments: the reference's ctor kwargs (base.py:103-120; pred_prey.py:26-38;
+ * tagging.py:10-12) plus what a batched device env needs. */
+typedef struct susnet_config {
+    uint32_t struct_bytes; /* = sizeof(susnet_config) */
+    uint32_t abi_version;  /* = SUSNET_ABI_VERSION */
+    int32_t variant;
+    int32_t batch;         /* environments on THIS device */
+    int32_t n_imposters, n_crew, n_jobs;
+    int32_t grid_n;        /* N; reference hard-codes 9 (base.py:195,206-207) */
+    uint16_t grid_rows[SUSNET_MAX_GRID]; /* bit j of grid_rows[i] = grid[i][j], 1 = free (base.py:195-197) */
+    double kill_reward, complete_job_reward, sabotage_reward, time_step_reward;
+    double game_end_reward, dead_penalty, vote_reward;
+    int32_t max_time_steps;
+    int32_t is_action_order_random;
+    int32_t shuffle_imposter_index;
+    int32_t tag_reset_interval;
+    int32_t auto_reset;    /* 1: an env that ends (done|truncated) is reset inside the same launch */
+    int32_t rng_mode;      /* SUSNET_RNG_* */
+    uint64_t seed;         /* Philox key */
+    uint64_t env_id_base;  /* global id of local env 0 (sharding across GPUs keeps streams identical) */
+    int32_t device;        /* HIP device ordinal the buffers live on */
+    int32_t reserved;
+} susnet_config;
+
+/* Sizes the caller must allocate. All device buffers are raw bytes. */
+typedef struct susnet_layout {
+    uint64_t state_bytes;     /* the compact SoA state blob (see DESIGN.md "Data layout in HBM") */
+    uint64_t state_align;     /* required alignment of the blob (256) */
+    int32_t batch_padded;     /* SoA row stride in elements */
+    int32_t n_agents;
+    int32_t n_actions_imposter; /* len(agent_action_map[i]) for an imposter / a crew member */
+    int32_t n_actions_crew;
+    int32_t action_space_n;   /* Discrete(n) of the reference (8, or 8 + A with tagging) */
+    int32_t obs_raw_size;     /* flattened_state_size (base.py:230-232) */
+} susnet_layout;
+
+typedef struct susnet_obs_spec {
+    int32_t mode;                 /* SUSNET_OBS_* */
+    int32_t dtype;                /* SUSNET_F32 (reference layouts) or SUSNET_U8 (compact) */
+    int32_t n_components;         /* FLAT only */
+    int32_t components[16];       /* SUSNET_F_* in concatenation order */
+    void *out;                    /* [B][obs_size]; PLANES: spatial [B][A+2][N][N] */
+    void *out2;                   /* PLANES: non_spatial [B][A(+A)+J]; else NULL */
+} susnet_obs_spec;
+
+typedef struct susnet_step_io {
+    const void *actions;  /* role-relative action indices (base.py:379-382) */
+    int32_t actions_dtype;  /* SUSNET_U8 / I32 / I64 */
+    int32_t actions_layout; /* SUSNET_LAYOUT_* */
+    void *rewards;        /* out, one per agent */
+    int32_t rewards_dtype;  /* SUSNET_F32 / F64 (reference: float64, base.py:369) */
+    int32_t rewards_layout;
+    uint8_t *done;        /* out [B]  (base.py:384-385) */
+    uint8_t *truncated;   /* out [B]  (base.py:392-395) */
+    const susnet_obs_spec *obs; /* optional fused observation of the post-step (post-auto-reset) state */
+} susnet_step_io;
+
+/* Fused random rollout: T lockstep ticks in one launch; per tick every env samples uniform role-valid
+ * actions (sample_actions), steps, and auto-resets on done|truncated.  Every trajectory pointer is
+ * optional (NULL = not stored).  Philox stream only. */
+typedef struct susnet_rollout_io {
+    int32_t n_ticks;
+    uint8_t *actions;   /* out [T][A][B] u8 */
+    float *rewards;     /* out [T][A][B] f32 */
+    uint8_t *done;      /* out [T][B] */
+    uint8_t *truncated; /* out [T][B] */
+    const susnet_obs_spec *obs; /* out pointer is [T][B][obs_size]; observation AFTER each tick */
+} susnet_rollout_io;
+
+/* Reference-layout views of the state (export / import). NULL pointers are skipped. */
+typedef struct susnet_state_view {
+    int32_t *agent_positions; /* [B][A][2] (x, y)            base.py:291 */
+    uint8_t *alive_agents;    /* [B][A]                      base.py:301 */
+    uint8_t *imposter_mask;   /* [B][A]                      base.py:280-281 */
+    int32_t *job_positions;   /* [B][J][2]                   base.py:299 */
+    uint8_t *completed_jobs;  /* [B][J]                      base.py:302 */
+    uint8_t *used_tag_actions;/* [B][A]                      tagging.py:30 */
+    int32_t *tag_counts;      /* [B][A]                      tagging.py:29 */
+    int32_t *tag_reset_timer; /* [B]                         tagging.py:31 */
+    int32_t *t;               /* [B]                         base.py:315 */
+    int64_t *metrics;         /* [B][13] info counters       metrics.py:35-64 */
+    uint64_t *rng_cursor;     /* [B] words consumed so far */
+    uint32_t *lifetime;       /* [SUSNET_N_LIFETIME][B] per-env sums over finished episodes */
+} susnet_state_view;
+
+int susnet_abi_version(void);
+const char *susnet_last_error(void);
+
+int susnet_create(const susnet_config *cfg, susnet_env **out);
+void susnet_destroy(susnet_env *env);
+int susnet_get_layout(const susnet_env *env, susnet_layout *out);
+
+/* Bind the caller-allocated state blob (zero-filled by the callee, asynchronously, on `stream`). */
+int susnet_bind_state(susnet_env *env, void *state_blob, uint64_t bytes, void *stream);
+/* TAPE mode: per-env raw 32-bit words, tape[b][0..words_per_env); cursors restart at 0. */
+int susnet_bind_tape(susnet_env *env, const uint32_t *tape, int64_t words_per_env);
+/* PHILOX mode: reseed / reposition every env's stream. */
+int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void *stream);
+
+int susnet_reset(susnet_env *env, const uint8_t *mask /* [B] or NULL = all */, const susnet_obs_spec *obs,
+                 void *stream);
+int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t dtype, int32_t layout, void *stream);
+int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream);
+int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
+int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);
+int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *size_out, int32_t *size2_out);
+
+int susnet_export_state(susnet_env *env, const susnet_state_view *view, void *stream);
+int susnet_import_state(susnet_env *env, const susnet_state_view *view, void *stream);
+
+/* Sum the per-env lifetime accumulators into out[SUSNET_N_LIFETIME] (device int64 buffer): the vector
+ * the multi-GPU host all-gathers.  One small launch. */
+int susnet_reduce_lifetime(susnet_env *env, int64_t *out_device, void *stream);
+
+/* Synchronises `stream`, reads and clears the device error word. Returns 0 or the most severe
+ * SUSNET_E_ACTION_* / SUSNET_E_TAPE code; *bits_out receives the raw bits. */
+int susnet_poll_errors(susnet_env *env, uint32_t *bits_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUSNET_H */

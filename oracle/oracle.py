@@ -97,6 +97,8 @@ def lib():
         L.so_batch_step.restype = C.c_int
         L.so_batch_random_rollout.argtypes = [P(SoEnv), C.c_int64, C.c_int64, C.c_int, P(C.c_int64), P(C.c_double)]
         L.so_batch_random_rollout.restype = C.c_int64
+        L.so_batch_export.argtypes = [P(SoEnv), C.c_int64] + [C.c_void_p] * 11
+        L.so_batch_export.restype = None
         L.so_obs_flat_size.argtypes = [P(SoEnv), P(C.c_int32), C.c_int]
         L.so_obs_flat_size.restype = C.c_int
         L.so_obs_flat.argtypes = [P(SoEnv), P(C.c_int32), C.c_int, P(C.c_float)]
@@ -284,6 +286,17 @@ class OracleBatch:
     @property
     def tape_overflow(self):
         return np.array([self.envs[b].rng.overflow for b in range(self.B)], dtype=np.int64)
+
+    def export(self) -> dict:
+        """Dense numpy snapshot of every env (one C call)."""
+        B, A, J = self.B, self.A, self.J
+        out = dict(pos=np.zeros((B, A, 2), np.int32), alive=np.zeros((B, A), np.uint8), imp=np.zeros((B, A), np.uint8),
+                   jobpos=np.zeros((B, J, 2), np.int32), jobdone=np.zeros((B, J), np.uint8), used=np.zeros((B, A), np.uint8),
+                   counts=np.zeros((B, A), np.int32), timer=np.zeros(B, np.int32), t=np.zeros(B, np.int32),
+                   metrics=np.zeros((B, N_METRICS), np.int64), cursor=np.zeros(B, np.uint64))
+        self.L.so_batch_export(self.envs, B, *[out[k].ctypes.data for k in
+                               ("pos", "alive", "imp", "jobpos", "jobdone", "used", "counts", "timer", "t", "metrics", "cursor")])
+        return out
 
     def imp_idxs(self, b=0):
         return np.ctypeslib.as_array(self.envs[b].imp_idxs)[: self.envs[b].cfg.n_imposters].copy()

@@ -157,10 +157,26 @@ static uint32_t rk_interval(so_env *e, uint32_t max) {
 /* np.random.randint(0, n) / np.random.choice(n) one element */
 static int np_randint(so_env *e, int n) { return (int)rk_interval(e, (uint32_t)(n - 1)); }
 
+/* ---- draw protocol ---------------------------------------------------------------------------------
+ * MT19937 / TAPE : numpy-legacy semantics (reference behaviour).
+ * PHILOX         : the PRODUCT's production protocol, restated here only so that the HIP kernels can be
+ *                  checked bit for bit in that mode too (it is not reference behaviour; it draws from the
+ *                  same distributions): the cursor is aligned to a 4-word Philox block at the start of
+ *                  reset / sample_actions / step, every bounded draw consumes exactly one word (also for
+ *                  n == 1) and maps it with a multiply-shift, and "without replacement" is sequential
+ *                  rejection of duplicates instead of a full permutation. */
+static int draw_bounded(so_env *e, int n) {
+    if (e->rng.kind == SO_RNG_PHILOX) return (int)(((uint64_t)so_next_u32(e) * (uint64_t)(uint32_t)n) >> 32);
+    return np_randint(e, n);
+}
+static void draw_align(so_env *e) {
+    if (e->rng.kind == SO_RNG_PHILOX) e->rng.cursor = (e->rng.cursor + 3ull) & ~3ull;
+}
+
 /* np.random.shuffle / permutation: for i = n-1 .. 1: j = interval(i); swap(x[i], x[j]) */
 static void np_shuffle(so_env *e, int32_t *x, int n) {
     for (int i = n - 1; i >= 1; i--) {
-        int j = (int)rk_interval(e, (uint32_t)i);
+        int j = draw_bounded(e, i + 1);
         int32_t t = x[i];
         x[i] = x[j];
         x[j] = t;
@@ -242,8 +258,18 @@ void so_reset(so_env *e) {
     const int A = e->A, J = e->J;
     memset(e->metrics, 0, sizeof(e->metrics)); /* base.py:270 */
 
+    draw_align(e);
+    const int philox = e->rng.kind == SO_RNG_PHILOX;
     /* base.py:273-278 */
-    if (e->cfg.shuffle_imposter_index) {
+    if (e->cfg.shuffle_imposter_index && philox) {
+        for (int i = 0; i < A; i++) e->imp_mask[i] = 0;
+        for (int k = 0; k < e->cfg.n_imposters; k++) {
+            int pick;
+            do { pick = draw_bounded(e, A); } while (e->imp_mask[pick]);
+            e->imp_mask[pick] = 1;
+            e->imp_idxs[k] = pick;
+        }
+    } else if (e->cfg.shuffle_imposter_index) {
         int32_t perm[SO_MAX_AGENTS];
         for (int i = 0; i < A; i++) perm[i] = i;
         np_shuffle(e, perm, A); /* choice(range(A), n_imp, replace=False) == permutation(A)[:n_imp] */
@@ -256,13 +282,25 @@ void so_reset(so_env *e) {
 
     /* base.py:288-291: agent cells, with replacement */
     for (int i = 0; i < A; i++) {
-        int c = np_randint(e, e->n_valid);
+        int c = draw_bounded(e, e->n_valid);
         e->pos[i][0] = e->valid[c][0];
         e->pos[i][1] = e->valid[c][1];
     }
     /* base.py:295-299: job cells, without replacement == permutation(n_valid)[:J]; the full
      * permutation is drawn even when J == 0 */
-    {
+    if (philox) {
+        for (int j = 0; j < J; j++) {
+            int c, dup;
+            do {
+                c = draw_bounded(e, e->n_valid);
+                dup = 0;
+                for (int k = 0; k < j; k++)
+                    dup |= (e->jobpos[k][0] == e->valid[c][0] && e->jobpos[k][1] == e->valid[c][1]);
+            } while (dup);
+            e->jobpos[j][0] = e->valid[c][0];
+            e->jobpos[j][1] = e->valid[c][1];
+        }
+    } else {
         int32_t perm[SO_MAX_GRID * SO_MAX_GRID];
         for (int i = 0; i < e->n_valid; i++) perm[i] = i;
         np_shuffle(e, perm, e->n_valid);
@@ -289,7 +327,8 @@ void so_reset(so_env *e) {
 
 /* base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order */
 void so_sample_actions(so_env *e, int32_t *actions) {
-    for (int i = 0; i < e->A; i++) actions[i] = np_randint(e, so_n_actions(e, i));
+    draw_align(e);
+    for (int i = 0; i < e->A; i++) actions[i] = draw_bounded(e, so_n_actions(e, i));
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -329,7 +368,7 @@ static void agent_step(so_env *e, int idx, int action) {
         for (int i = 0; i < e->A; i++)
             if (e->alive[i] && !e->imp_mask[i] && e->pos[i][0] == x && e->pos[i][1] == y) cands[nc++] = i;
         if (nc > 0) {
-            int victim = cands[np_randint(e, nc)]; /* base.py:497; no word drawn when nc == 1 */
+            int victim = cands[draw_bounded(e, nc)]; /* base.py:497; no word drawn when nc == 1 */
             e->metrics[SO_M_IMP_KILLED_CREW] += 1; /* base.py:508 */
             e->alive[victim] = 0;                  /* base.py:511 */
             e->rewards[victim] = e->cfg.kill_reward; /* base.py:514-515: ASSIGNED, not added */
@@ -415,6 +454,7 @@ int so_step(so_env *e, const int32_t *actions, double *rewards, int32_t *done_ou
         e->rewards[i] = tagging ? 1.0 * e->cfg.time_step_reward : 0.0;
 
     for (int i = 0; i < A; i++) e->order[i] = i;
+    draw_align(e);
     if (e->cfg.is_action_order_random) np_shuffle(e, e->order, A); /* base.py:372-374 */
 
     for (int k = 0; k < A; k++) {
@@ -515,6 +555,31 @@ int so_batch_step(so_env *envs, int64_t B, const int32_t *actions, double *rewar
         if (trunc) trunc[b] = (uint8_t)t;
     }
     return worst;
+}
+
+/* dense export of the batched state (test convenience; avoids per-env Python loops) */
+void so_batch_export(const so_env *envs, int64_t B, int32_t *pos, uint8_t *alive, uint8_t *imp, int32_t *jobpos,
+                     uint8_t *jobdone, uint8_t *used, int32_t *counts, int32_t *timer, int32_t *t, int64_t *metrics,
+                     uint64_t *cursor) {
+    for (int64_t b = 0; b < B; b++) {
+        const so_env *e = &envs[b];
+        const int A = e->A, J = e->J;
+        for (int i = 0; i < A; i++) {
+            if (pos) { pos[(b * A + i) * 2] = e->pos[i][0]; pos[(b * A + i) * 2 + 1] = e->pos[i][1]; }
+            if (alive) alive[b * A + i] = (uint8_t)e->alive[i];
+            if (imp) imp[b * A + i] = (uint8_t)e->imp_mask[i];
+            if (used) used[b * A + i] = (uint8_t)e->used[i];
+            if (counts) counts[b * A + i] = e->counts[i];
+        }
+        for (int j = 0; j < J; j++) {
+            if (jobpos) { jobpos[(b * J + j) * 2] = e->jobpos[j][0]; jobpos[(b * J + j) * 2 + 1] = e->jobpos[j][1]; }
+            if (jobdone) jobdone[b * J + j] = (uint8_t)e->jobdone[j];
+        }
+        if (timer) timer[b] = e->timer;
+        if (t) t[b] = e->t;
+        if (metrics) for (int k = 0; k < SO_N_METRICS; k++) metrics[b * SO_N_METRICS + k] = e->metrics[k];
+        if (cursor) cursor[b] = e->rng.cursor;
+    }
 }
 
 int64_t so_batch_random_rollout(so_env *envs, int64_t B, int64_t steps, int threads, int64_t *episodes_out,

@@ -1,0 +1,689 @@
+// susnet_capi.hip -- kernels + the C ABI declared in include/susnet.h (libsusnet_hip.so, gfx950 only).
+//
+// Build:  hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o libsusnet_hip.so susnet_capi.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "susnet_device.h"
+#include "susnet_obs.h"
+
+using namespace susnet;
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+struct StepArgs {
+    const void *actions;
+    int32_t act_dtype;
+    int64_t act_sa, act_sb; // element strides (agent, env)
+    RewardSink rewards;
+    uint8_t *done, *trunc;
+};
+
+struct RolloutArgs {
+    int32_t n_ticks;
+    uint8_t *actions; // [T][A][B]
+    float *rewards;   // [T][A][B]
+    uint8_t *done, *trunc; // [T][B]
+};
+
+template <class RNG>
+__device__ __forceinline__ RNG make_rng(const Consts &c, const State &s, int64_t b);
+
+template <>
+__device__ __forceinline__ PhiloxRng make_rng<PhiloxRng>(const Consts &c, const State &s, int64_t b) {
+    PhiloxRng r;
+    r.init(c.seed, c.env_id_base + (uint64_t)b, s.rng[b]);
+    return r;
+}
+template <>
+__device__ __forceinline__ TapeRng make_rng<TapeRng>(const Consts &c, const State &s, int64_t b) {
+    TapeRng r;
+    r.init(s.tape ? s.tape + b * s.tape_len : nullptr, s.tape ? s.tape_len : 0, s.rng[b]);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t load_action(const void *p, int dtype, int64_t k) {
+    int64_t v;
+    if (dtype == SUSNET_U8) v = reinterpret_cast<const uint8_t *>(p)[k];
+    else if (dtype == SUSNET_I32) v = reinterpret_cast<const int32_t *>(p)[k];
+    else v = reinterpret_cast<const int64_t *>(p)[k];
+    if (v < 0) v = -1;
+    if (v > 0x7ffffff0ll) v = 0x7ffffff0ll;
+    return (uint32_t)(int32_t)v;
+}
+
+__device__ __forceinline__ void store_action(void *p, int dtype, int64_t k, uint32_t a) {
+    if (dtype == SUSNET_U8) reinterpret_cast<uint8_t *>(p)[k] = (uint8_t)a;
+    else if (dtype == SUSNET_I32) reinterpret_cast<int32_t *>(p)[k] = (int32_t)a;
+    else reinterpret_cast<int64_t *>(p)[k] = (int64_t)a;
+}
+
+__device__ __forceinline__ void load_grid(const Consts &c, const Lds &L, int tid) {
+    if (tid < SUSNET_MAX_GRID) L.grid[tid] = c.grid_rows[tid];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <class RNG>
+__device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG &rng) {
+    s.rng[b] = rng.cur;
+    if (rng.ovf) atomicOr(s.err, SUSNET_ERRBIT_TAPE);
+}
+
+template <class RNG>
+__global__ __launch_bounds__(kBlock) void k_reset(Consts c, State s, const uint8_t *mask, ObsArgs o) {
+    extern __shared__ uint32_t smem[];
+    Lds L = carve_lds(smem, c.A, c.J);
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+    const bool active = b < c.B;
+    load_grid(c, L, tid);
+    Env e = {};
+    if (active) {
+        load_env(c, s, L, tid, (int)b, e);
+        if (!mask || mask[b]) {
+            RNG rng = make_rng<RNG>(c, s, b);
+            reset_env(c, L, tid, e, rng);
+            zero_metrics(e); // metrics.reset(), base.py:270
+            store_env(c, s, L, tid, (int)b, e, true);
+            finish_rng(s, b, rng);
+        }
+    }
+    int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
+    write_obs(c, o, L, tid, e, active, b0, nrows, 0);
+}
+
+template <class RNG>
+__global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out, int32_t dtype, int64_t sa, int64_t sb) {
+    extern __shared__ uint32_t smem[];
+    Lds L = carve_lds(smem, c.A, c.J);
+    const int tid = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * kBlock + tid;
+    if (b >= c.B) return;
+    Env e = {};
+    load_env(c, s, L, tid, (int)b, e);
+    RNG rng = make_rng<RNG>(c, s, b);
+    sample_actions_env(c, L, tid, e, rng);
+    for (int i = 0; i < c.A; i++) store_action(out, dtype, (int64_t)i * sa + b * sb, L.act[i * kBlock + tid]);
+    finish_rng(s, b, rng);
+}
+
+template <class RNG>
+__global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, ObsArgs o) {
+    extern __shared__ uint32_t smem[];
+    Lds L = carve_lds(smem, c.A, c.J);
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+    const bool active = b < c.B;
+    load_grid(c, L, tid);
+    Env e = {};
+    if (active) {
+        load_env(c, s, L, tid, (int)b, e);
+        for (int i = 0; i < c.A; i++) L.act[i * kBlock + tid] = load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb);
+        RNG rng = make_rng<RNG>(c, s, b);
+        bool done, trunc;
+        uint32_t bits = step_env(c, L, tid, e, rng, a.rewards, b, done, trunc);
+        if (bits) atomicOr(s.err, bits);
+        if (a.done) a.done[b] = done ? 1 : 0;
+        if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
+        bool jobs_changed = false;
+        if (c.auto_reset && (done || trunc)) {
+            accumulate_lifetime(c, s, (int)b, e, trunc);
+            reset_env(c, L, tid, e, rng);
+            e.flags |= FLAG_FRESH; // info counters stay readable until the next step
+            jobs_changed = true;
+        }
+        store_env(c, s, L, tid, (int)b, e, jobs_changed);
+        finish_rng(s, b, rng);
+    }
+    int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
+    write_obs(c, o, L, tid, e, active, b0, nrows, 0);
+}
+
+// Fused random rollout: n_ticks x {sample_actions; step; auto-reset} with the state held on chip.
+__global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
+    extern __shared__ uint32_t smem[];
+    Lds L = carve_lds(smem, c.A, c.J);
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+    const bool active = b < c.B;
+    const int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
+    load_grid(c, L, tid);
+    Env e = {};
+    PhiloxRng rng;
+    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
+    if (active) {
+        load_env(c, s, L, tid, (int)b, e);
+        rng.cur = s.rng[b];
+    }
+    const int64_t AB = (int64_t)c.A * c.B;
+    for (int tick = 0; tick < a.n_ticks; tick++) {
+        if (active) {
+            sample_actions_env(c, L, tid, e, rng);
+            if (a.actions)
+                for (int i = 0; i < c.A; i++) a.actions[tick * AB + (int64_t)i * c.B + b] = (uint8_t)L.act[i * kBlock + tid];
+            RewardSink sink{a.rewards ? (void *)(a.rewards + tick * AB) : nullptr, (int64_t)c.B, 1, 0};
+            bool done, trunc;
+            step_env(c, L, tid, e, rng, sink, b, done, trunc);
+            if (a.done) a.done[(int64_t)tick * c.B + b] = done ? 1 : 0;
+            if (a.trunc) a.trunc[(int64_t)tick * c.B + b] = trunc ? 1 : 0;
+            if (done || trunc) {
+                accumulate_lifetime(c, s, (int)b, e, trunc);
+                reset_env(c, L, tid, e, rng);
+                e.flags |= FLAG_FRESH;
+            }
+        }
+        write_obs(c, o, L, tid, e, active, b0, nrows, tick);
+    }
+    if (active) {
+        store_env(c, s, L, tid, (int)b, e, true);
+        s.rng[b] = rng.cur;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o) {
+    extern __shared__ uint32_t smem[];
+    Lds L = carve_lds(smem, c.A, c.J);
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+    const bool active = b < c.B;
+    load_grid(c, L, tid);
+    Env e = {};
+    if (active) load_env(c, s, L, tid, (int)b, e);
+    int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
+    write_obs(c, o, L, tid, e, active, b0, nrows, 0);
+}
+
+__global__ __launch_bounds__(kBlock) void k_export(Consts c, State s, susnet_state_view v) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= c.B) return;
+    const int A = c.A, J = c.J;
+    for (int i = 0; i < A; i++) {
+        uint32_t w = s.agent[(size_t)i * c.Bp + b];
+        if (v.agent_positions) {
+            v.agent_positions[(b * A + i) * 2] = (int32_t)(w & 15u);
+            v.agent_positions[(b * A + i) * 2 + 1] = (int32_t)((w >> 4) & 15u);
+        }
+        if (v.alive_agents) v.alive_agents[b * A + i] = (w >> 8) & 1u;
+        if (v.imposter_mask) v.imposter_mask[b * A + i] = (w >> 9) & 1u;
+        if (v.used_tag_actions) v.used_tag_actions[b * A + i] = (w >> 10) & 1u;
+        if (v.tag_counts) v.tag_counts[b * A + i] = (int32_t)((w >> 11) & 15u);
+    }
+    const uint32_t jd = s.jobdone[b];
+    for (int j = 0; j < J; j++) {
+        uint32_t w = s.job[(size_t)j * c.Bp + b];
+        if (v.job_positions) {
+            v.job_positions[(b * J + j) * 2] = (int32_t)(w & 15u);
+            v.job_positions[(b * J + j) * 2 + 1] = (int32_t)((w >> 4) & 15u);
+        }
+        if (v.completed_jobs) v.completed_jobs[b * J + j] = (jd >> j) & 1u;
+    }
+    if (v.tag_reset_timer) v.tag_reset_timer[b] = s.timer[b];
+    if (v.t) v.t[b] = s.t[b];
+    if (v.rng_cursor) v.rng_cursor[b] = s.rng[b];
+    if (v.metrics) {
+        int64_t *m = v.metrics + b * SUSNET_N_METRICS;
+        const uint32_t kv = s.m_kv[b], fl = s.flags[b];
+        for (int k = 0; k < SUSNET_N_METRICS; k++) m[k] = 0;
+        m[0] = kv & 0xffffu;          // IMP_KILLED_CREW
+        m[1] = (kv >> 16) & 0xffu;    // IMP_VOTED_OUT
+        m[2] = kv >> 24;              // CREW_VOTED_OUT
+        m[3] = s.m_sab[b];            // SABOTAGED_JOBS
+        m[4] = s.m_fix[b];            // COMPLETED_JOBS
+        m[6] = s.m_steps[b];          // TOTAL_TIME_STEPS
+        m[7] = (fl & FLAG_IMP_WON) ? 1 : 0;
+        m[8] = (fl & FLAG_CREW_WON) ? 1 : 0;
+    }
+    if (v.lifetime)
+        for (int k = 0; k < SUSNET_N_LIFETIME; k++) v.lifetime[(size_t)k * c.B + b] = s.life[(size_t)k * c.Bp + b];
+}
+
+__global__ __launch_bounds__(kBlock) void k_import(Consts c, State s, susnet_state_view v) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= c.B) return;
+    const int A = c.A, J = c.J;
+    for (int i = 0; i < A; i++) {
+        uint32_t w = s.agent[(size_t)i * c.Bp + b];
+        uint32_t xy = w & 0xffu, alive = (w >> 8) & 1u, imp = (w >> 9) & 1u, used = (w >> 10) & 1u, cnt = (w >> 11) & 15u;
+        if (v.agent_positions)
+            xy = ((uint32_t)v.agent_positions[(b * A + i) * 2] & 15u) | (((uint32_t)v.agent_positions[(b * A + i) * 2 + 1] & 15u) << 4);
+        if (v.alive_agents) alive = v.alive_agents[b * A + i] ? 1u : 0u;
+        if (v.imposter_mask) imp = v.imposter_mask[b * A + i] ? 1u : 0u;
+        if (v.used_tag_actions) used = v.used_tag_actions[b * A + i] ? 1u : 0u;
+        if (v.tag_counts) cnt = (uint32_t)v.tag_counts[b * A + i] & 15u;
+        s.agent[(size_t)i * c.Bp + b] = (uint16_t)pack_agent(xy, alive, imp, used, cnt);
+    }
+    uint32_t jd = s.jobdone[b];
+    for (int j = 0; j < J; j++) {
+        if (v.job_positions)
+            s.job[(size_t)j * c.Bp + b] = (uint8_t)(((uint32_t)v.job_positions[(b * J + j) * 2] & 15u) |
+                                                     (((uint32_t)v.job_positions[(b * J + j) * 2 + 1] & 15u) << 4));
+        if (v.completed_jobs) jd = (jd & ~(1u << j)) | ((v.completed_jobs[b * J + j] ? 1u : 0u) << j);
+    }
+    s.jobdone[b] = (uint16_t)jd;
+    if (v.tag_reset_timer) s.timer[b] = (uint16_t)v.tag_reset_timer[b];
+    if (v.t) s.t[b] = (uint16_t)v.t[b];
+    if (v.rng_cursor) s.rng[b] = v.rng_cursor[b];
+    if (v.metrics) {
+        const int64_t *m = v.metrics + b * SUSNET_N_METRICS;
+        s.m_kv[b] = ((uint32_t)m[0] & 0xffffu) | (((uint32_t)m[1] & 0xffu) << 16) | (((uint32_t)m[2] & 0xffu) << 24);
+        s.m_sab[b] = (uint32_t)m[3];
+        s.m_fix[b] = (uint32_t)m[4];
+        s.m_steps[b] = (uint32_t)m[6];
+        uint32_t fl = s.flags[b] & ~(FLAG_IMP_WON | FLAG_CREW_WON | FLAG_FRESH);
+        if (m[7]) fl |= FLAG_IMP_WON;
+        if (m[8]) fl |= FLAG_CREW_WON;
+        s.flags[b] = (uint8_t)fl;
+    }
+}
+
+__global__ void k_fill_cursor(Consts c, State s, uint64_t cursor) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < c.B) s.rng[b] = cursor;
+}
+
+// one workgroup per lifetime row: wave shuffles, then one LDS hop across the 4 waves
+__global__ __launch_bounds__(256) void k_reduce_lifetime(Consts c, State s, int64_t *out) {
+    __shared__ unsigned long long part[4];
+    const int row = blockIdx.x;
+    unsigned long long acc = 0;
+    for (int64_t b = threadIdx.x; b < c.B; b += 256) acc += s.life[(size_t)row * c.Bp + b];
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = (int64_t)(part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+struct susnet_env {
+    susnet_config cfg;
+    Consts c;
+    State s;
+    bool bound = false;
+    susnet_layout layout;
+    uint64_t off_err, off_agent, off_job, off_jobdone, off_t, off_timer, off_flags, off_rng, off_msteps, off_mfix, off_msab,
+        off_mkv, off_life;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(SUSNET_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+static inline uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int susnet_abi_version(void) { return SUSNET_ABI_VERSION; }
+extern "C" const char *susnet_last_error(void) { return g_err.c_str(); }
+
+extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
+    if (!cfg || !out) return fail(SUSNET_E_INVALID, "null argument");
+    if (cfg->struct_bytes != sizeof(susnet_config) || cfg->abi_version != SUSNET_ABI_VERSION)
+        return fail(SUSNET_E_INVALID, "susnet_config size/ABI mismatch");
+    int n_imp = cfg->n_imposters;
+    double dead = cfg->dead_penalty;
+    int order_random = cfg->is_action_order_random;
+    if (cfg->variant == SUSNET_VARIANT_ITG) { // pred_prey.py:52-66, 75-76
+        n_imp = 1;
+        dead = 0.0;
+        order_random = 0;
+        if (cfg->n_crew <= 0) return fail(SUSNET_E_INVALID, "Must have at least one crew member.");
+    } else if (cfg->variant == SUSNET_VARIANT_BASE || cfg->variant == SUSNET_VARIANT_TAGGING) { // base.py:243-249
+        if (n_imp <= 0) return fail(SUSNET_E_INVALID, "Must have at least one imposter.");
+        if (cfg->n_crew <= 0) return fail(SUSNET_E_INVALID, "Must have at least one crew member.");
+        if (cfg->n_jobs < 0) return fail(SUSNET_E_INVALID, "Must non-negative jobs.");
+        if (!(n_imp < cfg->n_crew)) return fail(SUSNET_E_INVALID, "Must be more crew members than imposters.");
+    } else {
+        return fail(SUSNET_E_INVALID, "unknown variant");
+    }
+    const int A = n_imp + cfg->n_crew, J = cfg->n_jobs, N = cfg->grid_n;
+    if (A > SUSNET_MAX_AGENTS || J > SUSNET_MAX_JOBS || J < 0) return fail(SUSNET_E_INVALID, "too many agents/jobs (max 16/16)");
+    if (N < 1 || N > SUSNET_MAX_GRID) return fail(SUSNET_E_INVALID, "grid_n must be in [1,16]");
+    if (cfg->batch < 1) return fail(SUSNET_E_INVALID, "batch must be >= 1");
+    if (cfg->max_time_steps < 1 || cfg->max_time_steps > 65535) return fail(SUSNET_E_INVALID, "max_time_steps must be in [1,65535]");
+    if (cfg->rng_mode != SUSNET_RNG_TAPE && cfg->rng_mode != SUSNET_RNG_PHILOX) return fail(SUSNET_E_INVALID, "unknown rng_mode");
+    if (cfg->variant == SUSNET_VARIANT_TAGGING && (cfg->tag_reset_interval < 1 || cfg->tag_reset_interval > 255))
+        return fail(SUSNET_E_INVALID, "tag_reset_interval must be in [1,255]");
+
+    susnet_env *e = new (std::nothrow) susnet_env();
+    if (!e) return fail(SUSNET_E_INVALID, "out of host memory");
+    e->cfg = *cfg;
+    Consts &c = e->c;
+    std::memset(&c, 0, sizeof(c));
+    c.B = cfg->batch;
+    c.Bp = (int32_t)up((uint64_t)cfg->batch, 256);
+    c.A = A; c.J = J; c.N = N; c.n_imp = n_imp; c.n_crew = cfg->n_crew; c.variant = cfg->variant;
+    c.max_t = cfg->max_time_steps;
+    c.order_random = order_random ? 1 : 0;
+    c.shuffle_imp = cfg->shuffle_imposter_index ? 1 : 0;
+    c.tag_interval = cfg->tag_reset_interval;
+    c.auto_reset = cfg->auto_reset ? 1 : 0;
+    c.nr_imp = cfg->variant == SUSNET_VARIANT_ITG ? 6 : 7;  // pred_prey.py:12-19 / base.py:91-99
+    c.nr_crew = cfg->variant == SUSNET_VARIANT_ITG ? 5 : 6; // pred_prey.py:4-10  / base.py:82-89
+    c.n_valid = 0;
+    for (int i = 0; i < N; i++) {
+        c.grid_rows[i] = cfg->grid_rows[i] & ((1u << N) - 1u);
+        for (int j = 0; j < N; j++)
+            if ((cfg->grid_rows[i] >> j) & 1u) c.valid_xy[c.n_valid++] = (uint8_t)(i | (j << 4)); // argwhere order; x = i, y = j
+    }
+    if (c.n_valid < 1 || c.n_valid < J) {
+        delete e;
+        return fail(SUSNET_E_INVALID, "grid has fewer free cells than jobs");
+    }
+    c.r_kill = cfg->kill_reward; c.r_fix = cfg->complete_job_reward; c.r_sab = cfg->sabotage_reward;
+    c.r_tsr = cfg->time_step_reward; c.r_end = cfg->game_end_reward; c.r_dead = dead; c.r_vote = cfg->vote_reward;
+    c.seed = cfg->seed; c.env_id_base = cfg->env_id_base;
+
+    // state blob layout (every array 256-byte aligned; row stride Bp)
+    uint64_t off = 0;
+    const uint64_t Bp = (uint64_t)c.Bp;
+    auto take = [&](uint64_t bytes) { uint64_t o = off; off = up(off + bytes, 256); return o; };
+    e->off_err = take(256);
+    e->off_agent = take(2 * Bp * A);
+    e->off_job = take(Bp * (J > 0 ? J : 1));
+    e->off_jobdone = take(2 * Bp);
+    e->off_t = take(2 * Bp);
+    e->off_timer = take(2 * Bp);
+    e->off_flags = take(Bp);
+    e->off_rng = take(8 * Bp);
+    e->off_msteps = take(4 * Bp);
+    e->off_mfix = take(4 * Bp);
+    e->off_msab = take(4 * Bp);
+    e->off_mkv = take(4 * Bp);
+    e->off_life = take(4 * Bp * SUSNET_N_LIFETIME);
+    susnet_layout &L = e->layout;
+    L.state_bytes = off;
+    L.state_align = 256;
+    L.batch_padded = c.Bp;
+    L.n_agents = A;
+    const int tag_extra = cfg->variant == SUSNET_VARIANT_TAGGING ? A - 1 : 0;
+    L.n_actions_imposter = c.nr_imp + tag_extra;
+    L.n_actions_crew = c.nr_crew + tag_extra;
+    L.action_space_n = 8 + (cfg->variant == SUSNET_VARIANT_TAGGING ? A : 0);
+    L.obs_raw_size = 3 * A + (cfg->variant == SUSNET_VARIANT_TAGGING ? 3 * J + 2 * A + 1 : (J > 0 ? 3 * J : 0));
+    *out = e;
+    return SUSNET_OK;
+}
+
+extern "C" void susnet_destroy(susnet_env *env) { delete env; }
+
+extern "C" int susnet_get_layout(const susnet_env *env, susnet_layout *out) {
+    if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
+    *out = env->layout;
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_bind_state(susnet_env *env, void *blob, uint64_t bytes, void *stream) {
+    if (!env || !blob) return fail(SUSNET_E_INVALID, "null argument");
+    if (bytes < env->layout.state_bytes) return fail(SUSNET_E_INVALID, "state blob too small");
+    if ((uintptr_t)blob % 256) return fail(SUSNET_E_INVALID, "state blob must be 256-byte aligned");
+    char *p = static_cast<char *>(blob);
+    State &s = env->s;
+    const uint32_t *tape = s.tape;
+    int64_t tape_len = s.tape_len;
+    s.err = reinterpret_cast<uint32_t *>(p + env->off_err);
+    s.agent = reinterpret_cast<uint16_t *>(p + env->off_agent);
+    s.job = reinterpret_cast<uint8_t *>(p + env->off_job);
+    s.jobdone = reinterpret_cast<uint16_t *>(p + env->off_jobdone);
+    s.t = reinterpret_cast<uint16_t *>(p + env->off_t);
+    s.timer = reinterpret_cast<uint16_t *>(p + env->off_timer);
+    s.flags = reinterpret_cast<uint8_t *>(p + env->off_flags);
+    s.rng = reinterpret_cast<uint64_t *>(p + env->off_rng);
+    s.m_steps = reinterpret_cast<uint32_t *>(p + env->off_msteps);
+    s.m_fix = reinterpret_cast<uint32_t *>(p + env->off_mfix);
+    s.m_sab = reinterpret_cast<uint32_t *>(p + env->off_msab);
+    s.m_kv = reinterpret_cast<uint32_t *>(p + env->off_mkv);
+    s.life = reinterpret_cast<uint32_t *>(p + env->off_life);
+    s.tape = tape;
+    s.tape_len = tape_len;
+    HIP_TRY(hipMemsetAsync(blob, 0, env->layout.state_bytes, static_cast<hipStream_t>(stream)));
+    env->bound = true;
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_bind_tape(susnet_env *env, const uint32_t *tape, int64_t words_per_env) {
+    if (!env) return fail(SUSNET_E_INVALID, "null argument");
+    if (env->cfg.rng_mode != SUSNET_RNG_TAPE) return fail(SUSNET_E_INVALID, "handle is not in TAPE mode");
+    env->s.tape = tape;
+    env->s.tape_len = tape ? words_per_env : 0;
+    return SUSNET_OK;
+}
+
+static int check_bound(const susnet_env *env) {
+    if (!env) return fail(SUSNET_E_INVALID, "null handle");
+    if (!env->bound) return fail(SUSNET_E_STATE, "state blob not bound (susnet_bind_state)");
+    return SUSNET_OK;
+}
+static inline dim3 grid_for(const susnet_env *env) { return dim3((unsigned)((env->c.B + kBlock - 1) / kBlock)); }
+
+extern "C" int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    env->c.seed = seed;
+    env->cfg.seed = seed;
+    hipLaunchKernelGGL(k_fill_cursor, dim3((unsigned)((env->c.B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), env->c,
+                       env->s, cursor);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+// observation plumbing -----------------------------------------------------------------------------
+static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs &o, int64_t ticks_batch) {
+    std::memset(&o, 0, sizeof(o));
+    if (!spec || spec->mode == SUSNET_OBS_NONE) return SUSNET_OK;
+    const Consts &c = env->c;
+    if (spec->dtype != SUSNET_F32 && spec->dtype != SUSNET_U8) return fail(SUSNET_E_INVALID, "obs dtype must be F32 or U8");
+    o.mode = spec->mode;
+    o.dtype = spec->dtype;
+    o.out = spec->out;
+    o.out2 = spec->out2;
+    if (spec->mode == SUSNET_OBS_RAW) {
+        o.F = env->layout.obs_raw_size;
+        o.words1 = odd_words((o.F + 3) / 4);
+    } else if (spec->mode == SUSNET_OBS_FLAT) {
+        if (spec->n_components < 1 || spec->n_components > 16) return fail(SUSNET_E_INVALID, "1..16 flat components");
+        o.ncomp = spec->n_components;
+        int F = 0;
+        for (int i = 0; i < o.ncomp; i++) {
+            int comp = spec->components[i];
+            int sz = flat_component_size(comp, c.A, c.N, c.n_crew);
+            if (sz < 0) return fail(SUSNET_E_INVALID, "unknown flat component");
+            if ((comp == SUSNET_F_L1_CREW || comp == SUSNET_F_CLOSEST_CREW) && c.A - 1 != c.n_crew)
+                return fail(SUSNET_E_INVALID, "l1_crew/closest_crew need exactly one imposter (component.py:442-446)");
+            if (comp == SUSNET_F_ROOM_LOC && c.N != 9) return fail(SUSNET_E_INVALID, "room_loc is defined on the 9x9 grid only");
+            o.comp[i] = comp;
+            F += sz;
+        }
+        o.F = F;
+        o.words1 = odd_words((F + 3) / 4);
+    } else if (spec->mode == SUSNET_OBS_PLANES) {
+        o.F = (c.A + 2) * c.N * c.N;
+        o.F2 = c.A + c.J + (c.variant == SUSNET_VARIANT_TAGGING ? c.A : 0);
+        o.words1 = odd_words((o.F + 31) / 32);
+        o.words2 = odd_words((o.F2 + 3) / 4);
+    } else {
+        return fail(SUSNET_E_INVALID, "unknown obs mode");
+    }
+    if (!o.out) return fail(SUSNET_E_INVALID, "obs.out is null");
+    if ((uintptr_t)o.out % 16 || (o.out2 && (uintptr_t)o.out2 % 16)) return fail(SUSNET_E_INVALID, "obs buffers must be 16-byte aligned");
+    o.tick_stride = ticks_batch * o.F;
+    o.tick_stride2 = ticks_batch * o.F2;
+    return SUSNET_OK;
+}
+
+static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset) {
+    const Consts &c = env->c;
+    size_t core = (size_t)lds_core_words(c.A, c.J) * 4;
+    size_t perm = (may_reset && env->cfg.rng_mode == SUSNET_RNG_TAPE) ? (size_t)c.n_valid * kBlock : 0;
+    size_t stage = (size_t)kBlock * (o.words1 + o.words2) * 4;
+    return core + (perm > stage ? perm : stage);
+}
+
+extern "C" int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *size_out, int32_t *size2_out) {
+    if (!env || !obs) return fail(SUSNET_E_INVALID, "null argument");
+    susnet_obs_spec tmp = *obs;
+    static char dummy[16] __attribute__((aligned(16)));
+    tmp.out = dummy;
+    tmp.out2 = nullptr;
+    ObsArgs o;
+    if (int rc = build_obs(env, &tmp, o, env->c.B)) return rc;
+    if (size_out) *size_out = o.F;
+    if (size2_out) *size2_out = o.F2;
+    return SUSNET_OK;
+}
+
+#define CHECK_LDS(bytes) \
+    if ((bytes) > 64 * 1024) return fail(SUSNET_E_INVALID, "observation too large for the LDS staging area")
+
+extern "C" int susnet_reset(susnet_env *env, const uint8_t *mask, const susnet_obs_spec *obs, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    ObsArgs o;
+    if (int rc = build_obs(env, obs, o, env->c.B)) return rc;
+    size_t sh = lds_bytes(env, o, true);
+    CHECK_LDS(sh);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (env->cfg.rng_mode == SUSNET_RNG_TAPE)
+        hipLaunchKernelGGL(k_reset<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, mask, o);
+    else
+        hipLaunchKernelGGL(k_reset<PhiloxRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, mask, o);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+static int strides_for(const susnet_env *env, int layout, int64_t &sa, int64_t &sb) {
+    if (layout == SUSNET_LAYOUT_AB) { sa = env->c.B; sb = 1; }
+    else if (layout == SUSNET_LAYOUT_BA) { sa = 1; sb = env->c.A; }
+    else return fail(SUSNET_E_INVALID, "unknown layout");
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t dtype, int32_t layout, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!actions_out) return fail(SUSNET_E_INVALID, "null actions_out");
+    if (dtype != SUSNET_U8 && dtype != SUSNET_I32 && dtype != SUSNET_I64) return fail(SUSNET_E_INVALID, "actions dtype must be U8/I32/I64");
+    int64_t sa, sb;
+    if (int rc = strides_for(env, layout, sa, sb)) return rc;
+    ObsArgs o;
+    std::memset(&o, 0, sizeof(o));
+    size_t sh = lds_bytes(env, o, false);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (env->cfg.rng_mode == SUSNET_RNG_TAPE)
+        hipLaunchKernelGGL(k_sample<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb);
+    else
+        hipLaunchKernelGGL(k_sample<PhiloxRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!io || !io->actions) return fail(SUSNET_E_INVALID, "null actions");
+    StepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.actions = io->actions;
+    a.act_dtype = io->actions_dtype;
+    if (a.act_dtype != SUSNET_U8 && a.act_dtype != SUSNET_I32 && a.act_dtype != SUSNET_I64)
+        return fail(SUSNET_E_INVALID, "actions dtype must be U8/I32/I64");
+    if (int rc = strides_for(env, io->actions_layout, a.act_sa, a.act_sb)) return rc;
+    a.rewards.ptr = io->rewards;
+    if (io->rewards) {
+        if (io->rewards_dtype != SUSNET_F32 && io->rewards_dtype != SUSNET_F64) return fail(SUSNET_E_INVALID, "rewards dtype must be F32/F64");
+        a.rewards.f64 = io->rewards_dtype == SUSNET_F64;
+        if (int rc = strides_for(env, io->rewards_layout, a.rewards.sa, a.rewards.sb)) return rc;
+    }
+    a.done = io->done;
+    a.trunc = io->truncated;
+    ObsArgs o;
+    if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
+    size_t sh = lds_bytes(env, o, env->c.auto_reset != 0);
+    CHECK_LDS(sh);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (env->cfg.rng_mode == SUSNET_RNG_TAPE)
+        hipLaunchKernelGGL(k_step<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, a, o);
+    else
+        hipLaunchKernelGGL(k_step<PhiloxRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, a, o);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!io || io->n_ticks < 1) return fail(SUSNET_E_INVALID, "n_ticks must be >= 1");
+    if (env->cfg.rng_mode != SUSNET_RNG_PHILOX) return fail(SUSNET_E_INVALID, "susnet_rollout needs the PHILOX stream");
+    RolloutArgs a;
+    a.n_ticks = io->n_ticks;
+    a.actions = io->actions;
+    a.rewards = io->rewards;
+    a.done = io->done;
+    a.trunc = io->truncated;
+    ObsArgs o;
+    if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
+    size_t sh = lds_bytes(env, o, true);
+    CHECK_LDS(sh);
+    hipLaunchKernelGGL(k_rollout, grid_for(env), dim3(kBlock), sh, static_cast<hipStream_t>(stream), env->c, env->s, a, o);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!obs || obs->mode == SUSNET_OBS_NONE) return fail(SUSNET_E_INVALID, "nothing to observe");
+    ObsArgs o;
+    if (int rc = build_obs(env, obs, o, env->c.B)) return rc;
+    size_t sh = lds_bytes(env, o, false);
+    CHECK_LDS(sh);
+    hipLaunchKernelGGL(k_observe, grid_for(env), dim3(kBlock), sh, static_cast<hipStream_t>(stream), env->c, env->s, o);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_export_state(susnet_env *env, const susnet_state_view *view, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!view) return fail(SUSNET_E_INVALID, "null view");
+    hipLaunchKernelGGL(k_export, grid_for(env), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->c, env->s, *view);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_import_state(susnet_env *env, const susnet_state_view *view, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!view) return fail(SUSNET_E_INVALID, "null view");
+    hipLaunchKernelGGL(k_import, grid_for(env), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->c, env->s, *view);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_reduce_lifetime(susnet_env *env, int64_t *out_device, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!out_device) return fail(SUSNET_E_INVALID, "null output");
+    hipLaunchKernelGGL(k_reduce_lifetime, dim3(SUSNET_N_LIFETIME), dim3(256), 0, static_cast<hipStream_t>(stream), env->c, env->s,
+                       out_device);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_poll_errors(susnet_env *env, uint32_t *bits_out, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, env->s.err, sizeof(bits), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bits) HIP_TRY(hipMemsetAsync(env->s.err, 0, sizeof(uint32_t), st));
+    if (bits_out) *bits_out = bits;
+    if (bits & SUSNET_ERRBIT_ASSERT) return fail(SUSNET_E_ACTION_ASSERT, "Invalid action(s): action >= action_space.n");
+    if (bits & SUSNET_ERRBIT_INDEX) return fail(SUSNET_E_ACTION_INDEX, "role-invalid action index");
+    if (bits & SUSNET_ERRBIT_TAPE) return fail(SUSNET_E_TAPE, "random tape exhausted");
+    return SUSNET_OK;
+}

@@ -1,0 +1,508 @@
+// susnet_device.h -- device-side environment logic for gfx950 (CDNA4), one wavefront lane per environment.
+//
+// Reference behaviour implemented here (paths relative to the reference repo root):
+//   reset            src/environment/base.py:251-324, src/environment/tagging.py:62-101
+//   sample_actions   src/environment/base.py:326-330
+//   step             src/environment/base.py:332-407, src/environment/tagging.py:120-235
+//   _agent_step      src/environment/base.py:462-533
+//   win conditions   src/environment/base.py:409-460, src/environment/pred_prey.py:78-99
+//   _merge_rewards   src/environment/base.py:553-563
+//   info counters    src/metrics.py:35-64
+//
+// Execution model: a workgroup is ONE 64-lane wavefront (64 environments).  Per-lane scalars (alive /
+// imposter / tag-used / job-done bitmasks, t, counters) live in VGPRs; everything that is indexed by a
+// data-dependent agent or job number (positions, tag counts, actions, the wall map, the spawn
+// permutation) lives in LDS, laid out [index][lane] so that a lane-varying index is a conflict-free
+// ds_read_b32.  No barriers: a lane only touches its own column, except the cooperative observation
+// writer, and LDS operations of one wave complete in order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/susnet.h"
+
+namespace susnet {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 64; // one wave per workgroup (see header comment)
+
+// Action enum values (src/environment/base.py:46-58)
+enum : int { ACT_STAY = 0, ACT_UP = 1, ACT_DOWN = 2, ACT_LEFT = 3, ACT_RIGHT = 4, ACT_KILL = 5, ACT_FIX = 6, ACT_SABOTAGE = 7 };
+// reward codes: which ASSIGNMENT (base.py:514-515,523,532) an agent's reward slot last received
+enum : uint32_t { RC_NONE = 0, RC_KILL = 1, RC_FIX = 2, RC_SAB = 3 };
+
+// per-env flag byte
+constexpr uint32_t FLAG_FRESH = 1;    // episode was auto-reset: zero the info counters at the next step
+constexpr uint32_t FLAG_CREW_WON = 2; // SusMetrics.CREW_WON latched (metrics.update, base.py:433)
+constexpr uint32_t FLAG_IMP_WON = 4;  // SusMetrics.IMPOSTER_WON latched (base.py:444)
+
+// packed agent halfword in HBM: x[0:4) y[4:8) alive[8] imposter[9] tag_used[10] tag_count[11:15)
+__device__ __forceinline__ uint32_t pack_agent(uint32_t xy, uint32_t alive, uint32_t imp, uint32_t used, uint32_t cnt) {
+    return (xy & 0xffu) | (alive << 8) | (imp << 9) | (used << 10) | ((cnt & 15u) << 11);
+}
+
+// Immutable per-handle constants, passed BY VALUE as a kernel argument (lands in SGPRs / kernarg memory).
+struct Consts {
+    int32_t B, Bp;
+    int32_t A, J, N, n_imp, n_crew, variant;
+    int32_t max_t, order_random, shuffle_imp, tag_interval;
+    int32_t n_valid, auto_reset, nr_imp, nr_crew; // nr_* = length of the role part of agent_action_map
+    uint32_t grid_rows[SUSNET_MAX_GRID];          // bit j of row i = grid[i][j]
+    uint8_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID]; // np.argwhere(grid) order; x | y << 4
+    double r_kill, r_fix, r_sab, r_tsr, r_end, r_dead, r_vote;
+    uint64_t seed, env_id_base;
+};
+
+// Device pointers into the caller's state blob (SoA, row stride Bp).
+struct State {
+    uint32_t *err;      // [1] device error word
+    uint16_t *agent;    // [A][Bp]
+    uint8_t *job;       // [J][Bp]  x | y << 4 (constant within an episode)
+    uint16_t *jobdone;  // [Bp] bitmask
+    uint16_t *t;        // [Bp]
+    uint16_t *timer;    // [Bp] tag_reset_timer
+    uint8_t *flags;     // [Bp]
+    uint64_t *rng;      // [Bp] words consumed
+    uint32_t *m_steps;  // [Bp] TOTAL_TIME_STEPS
+    uint32_t *m_fix;    // [Bp] COMPLETED_JOBS
+    uint32_t *m_sab;    // [Bp] SABOTAGED_JOBS
+    uint32_t *m_kv;     // [Bp] kills[0:16) imp_voted[16:24) crew_voted[24:32)
+    uint32_t *life;     // [SUSNET_N_LIFETIME][Bp]
+    const uint32_t *tape; // TAPE mode: [B][tape_len]
+    int64_t tape_len;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// word sources
+// ---------------------------------------------------------------------------------------------------
+// Philox4x32-10; key = (seed lo, hi), counter = (block lo, block hi, env lo, env hi), block = cursor >> 2,
+// word = out[cursor & 3].  Identical mapping in oracle/susnet_oracle.c (philox_word).
+struct PhiloxRng {
+    static constexpr bool kNumpy = false;
+    uint32_t k0, k1, e0, e1;
+    uint64_t cur, blk;
+    uint32_t w0, w1, w2, w3;
+    bool ovf;
+
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t env, uint64_t cursor) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        e0 = (uint32_t)env; e1 = (uint32_t)(env >> 32);
+        cur = cursor; blk = ~0ull; ovf = false;
+        w0 = w1 = w2 = w3 = 0;
+    }
+    __device__ __forceinline__ void gen(uint64_t b) {
+        uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32), c2 = e0, c3 = e1;
+        uint32_t a = k0, d = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+            uint32_t n0 = h1 ^ c1 ^ a, n2 = h0 ^ c3 ^ d;
+            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+            a += 0x9E3779B9u; d += 0xBB67AE85u;
+        }
+        w0 = c0; w1 = c1; w2 = c2; w3 = c3;
+        blk = b;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        uint64_t b = cur >> 2;
+        if (b != blk) gen(b);
+        uint32_t s = (uint32_t)cur & 3u;
+        cur++;
+        uint32_t lo = (s & 1u) ? w1 : w0, hi = (s & 1u) ? w3 : w2;
+        return (s & 2u) ? hi : lo;
+    }
+    // production protocol: block-aligned at the start of reset / sample_actions / step, one word per
+    // bounded draw (also for n == 1), multiply-shift mapping onto [0, n)
+    __device__ __forceinline__ void align() { cur = (cur + 3ull) & ~3ull; }
+    __device__ __forceinline__ uint32_t bounded(uint32_t n) { return __umulhi(next(), n); }
+};
+
+// Caller-supplied raw words consumed with numpy-legacy semantics (masked rejection, nothing drawn for a
+// one-element range): fed numpy's MT19937 output the decisions equal the reference's.
+struct TapeRng {
+    static constexpr bool kNumpy = true;
+    const uint32_t *p;
+    int64_t len;
+    uint64_t cur;
+    bool ovf;
+
+    __device__ __forceinline__ void init(const uint32_t *tape, int64_t n, uint64_t cursor) {
+        p = tape; len = n; cur = cursor; ovf = false;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        uint32_t w = 0;
+        if ((int64_t)cur < len) w = p[cur];
+        else ovf = true;
+        cur++;
+        return w;
+    }
+    __device__ __forceinline__ void align() {}
+    __device__ __forceinline__ uint32_t bounded(uint32_t n) { // np.random.randint(0, n)
+        if (n <= 1u) return 0u;
+        uint32_t mx = n - 1u, mask = mx;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do { v = next() & mask; } while (v > mx);
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// per-wave LDS view (dynamic shared memory, carved by the kernel)
+// ---------------------------------------------------------------------------------------------------
+struct Lds {
+    uint32_t *grid; // [16] wall map rows
+    uint32_t *xy;   // [A][64]  x | y << 4 | tag_count << 8
+    uint32_t *job;  // [J][64]  x | y << 4
+    uint32_t *act;  // [A][64]  role-relative action index
+    uint8_t *perm;  // [n_valid][64] spawn permutation (TAPE resets only)
+    uint32_t *stage; // observation staging
+};
+
+__host__ __device__ inline uint32_t lds_core_words(int A, int J) { return 16u + (uint32_t)(2 * A + J) * kBlock; }
+
+__device__ __forceinline__ Lds carve_lds(uint32_t *base, int A, int J) {
+    Lds L;
+    L.grid = base;
+    L.xy = base + 16;
+    L.job = L.xy + A * kBlock;
+    L.act = L.job + J * kBlock;
+    uint32_t *end = L.act + A * kBlock;
+    L.perm = reinterpret_cast<uint8_t *>(end);
+    L.stage = end;
+    return L;
+}
+
+// per-lane register state of one environment
+struct Env {
+    uint32_t alive, imp, used, jd; // bitmasks over agents / jobs
+    uint32_t t, timer, flags;
+    uint32_t m_steps, m_fix, m_sab, m_kv;
+};
+
+__device__ __forceinline__ void load_env(const Consts &c, const State &s, const Lds &L, int tid, int b, Env &e) {
+    e.alive = e.imp = e.used = 0;
+    for (int i = 0; i < c.A; i++) {
+        uint32_t w = s.agent[(size_t)i * c.Bp + b];
+        L.xy[i * kBlock + tid] = (w & 0xffu) | (((w >> 11) & 15u) << 8);
+        e.alive |= ((w >> 8) & 1u) << i;
+        e.imp |= ((w >> 9) & 1u) << i;
+        e.used |= ((w >> 10) & 1u) << i;
+    }
+    for (int j = 0; j < c.J; j++) L.job[j * kBlock + tid] = s.job[(size_t)j * c.Bp + b];
+    e.jd = s.jobdone[b];
+    e.t = s.t[b];
+    e.timer = s.timer[b];
+    e.flags = s.flags[b];
+    e.m_steps = s.m_steps[b];
+    e.m_fix = s.m_fix[b];
+    e.m_sab = s.m_sab[b];
+    e.m_kv = s.m_kv[b];
+}
+
+__device__ __forceinline__ void store_env(const Consts &c, const State &s, const Lds &L, int tid, int b, const Env &e,
+                                          bool store_jobs) {
+    for (int i = 0; i < c.A; i++) {
+        uint32_t w = L.xy[i * kBlock + tid];
+        s.agent[(size_t)i * c.Bp + b] =
+            (uint16_t)pack_agent(w, (e.alive >> i) & 1u, (e.imp >> i) & 1u, (e.used >> i) & 1u, (w >> 8) & 15u);
+    }
+    if (store_jobs)
+        for (int j = 0; j < c.J; j++) s.job[(size_t)j * c.Bp + b] = (uint8_t)L.job[j * kBlock + tid];
+    s.jobdone[b] = (uint16_t)e.jd;
+    s.t[b] = (uint16_t)e.t;
+    s.timer[b] = (uint16_t)e.timer;
+    s.flags[b] = (uint8_t)e.flags;
+    s.m_steps[b] = e.m_steps;
+    s.m_fix[b] = e.m_fix;
+    s.m_sab[b] = e.m_sab;
+    s.m_kv[b] = e.m_kv;
+}
+
+__device__ __forceinline__ uint32_t nibble(uint64_t v, int i) { return (uint32_t)(v >> (4 * i)) & 15u; }
+__device__ __forceinline__ void nibble_swap(uint64_t &v, int i, int j) {
+    uint64_t d = (uint64_t)(nibble(v, i) ^ nibble(v, j));
+    v ^= (d << (4 * i)) ^ (d << (4 * j)); // cancels when i == j
+}
+__device__ __forceinline__ int nth_set_bit(uint32_t m, uint32_t r) {
+    for (uint32_t k = 0; k < r; k++) m &= m - 1u;
+    return __ffs((int)m) - 1;
+}
+
+// np.random.shuffle / permutation on a nibble-packed list (base.py:374): i = n-1 .. 1, j in [0, i]
+template <class RNG>
+__device__ __forceinline__ void shuffle_nibbles(RNG &rng, uint64_t &v, int n) {
+    for (int i = n - 1; i >= 1; i--) {
+        int j = (int)rng.bounded((uint32_t)i + 1u);
+        nibble_swap(v, i, j);
+    }
+}
+
+__device__ __forceinline__ uint32_t n_role_actions(const Consts &c, uint32_t is_imp) { return is_imp ? c.nr_imp : c.nr_crew; }
+__device__ __forceinline__ uint32_t n_actions(const Consts &c, uint32_t is_imp) {
+    return n_role_actions(c, is_imp) + (c.variant == SUSNET_VARIANT_TAGGING ? (uint32_t)(c.A - 1) : 0u);
+}
+
+// role-relative index -> Action (base.py:82-99; pred_prey.py:4-19); caller guarantees idx < role count
+__device__ __forceinline__ int role_action(const Consts &c, uint32_t is_imp, uint32_t idx) {
+    if (idx <= 4u) return (int)idx;
+    if (c.variant == SUSNET_VARIANT_ITG) return ACT_KILL;      // imposter idx 5
+    if (is_imp) return idx == 5u ? ACT_SABOTAGE : ACT_KILL;    // imposter idx 5, 6
+    return ACT_FIX;                                            // crew idx 5
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reset (base.py:251-324).  Draw order: [imposter indices] -> agent cells -> job cells.
+//   TAPE   : numpy semantics incl. the FULL permutation of the valid cells (drawn even when J == 0)
+//   PHILOX : same distributions by sequential rejection of duplicates (n_imp + A + J draws, +rare retries)
+// ---------------------------------------------------------------------------------------------------
+template <class RNG>
+__device__ __forceinline__ void reset_env(const Consts &c, const Lds &L, int tid, Env &e, RNG &rng) {
+    const int A = c.A, J = c.J;
+    rng.align();
+    if (c.shuffle_imp) {
+        if (RNG::kNumpy) {
+            uint64_t perm = 0xFEDCBA9876543210ull;
+            shuffle_nibbles(rng, perm, A); // choice(range(A), n_imp, replace=False) == permutation(A)[:n_imp]
+            e.imp = 0;
+            for (int k = 0; k < c.n_imp; k++) e.imp |= 1u << nibble(perm, k);
+        } else {
+            e.imp = 0;
+            for (int k = 0; k < c.n_imp; k++) {
+                uint32_t pick;
+                do { pick = rng.bounded((uint32_t)A); } while ((e.imp >> pick) & 1u);
+                e.imp |= 1u << pick;
+            }
+        }
+    } else {
+        e.imp = (1u << c.n_imp) - 1u; // np.arange(n_imposters), base.py:278
+    }
+    for (int i = 0; i < A; i++) { // base.py:288-291, with replacement
+        uint32_t cell = rng.bounded((uint32_t)c.n_valid);
+        L.xy[i * kBlock + tid] = c.valid_xy[cell]; // tag count bits cleared
+    }
+    if (RNG::kNumpy) {
+        // base.py:295-299: permutation(n_valid)[:J]
+        const int n = c.n_valid;
+        for (int k = 0; k < n; k++) L.perm[k * kBlock + tid] = (uint8_t)k;
+        for (int i = n - 1; i >= 1; i--) {
+            int j = (int)rng.bounded((uint32_t)i + 1u);
+            uint8_t a = L.perm[i * kBlock + tid], b2 = L.perm[j * kBlock + tid];
+            L.perm[i * kBlock + tid] = b2;
+            L.perm[j * kBlock + tid] = a;
+        }
+        for (int j = 0; j < J; j++) L.job[j * kBlock + tid] = c.valid_xy[L.perm[j * kBlock + tid]];
+    } else {
+        for (int j = 0; j < J; j++) {
+            uint32_t xy;
+            bool dup;
+            do {
+                xy = c.valid_xy[rng.bounded((uint32_t)c.n_valid)];
+                dup = false;
+                for (int k = 0; k < j; k++) dup |= (L.job[k * kBlock + tid] == xy);
+            } while (dup);
+            L.job[j * kBlock + tid] = xy;
+        }
+    }
+    e.alive = (1u << A) - 1u; // base.py:301
+    e.jd = 0;                 // base.py:302
+    e.used = 0;               // tagging.py:64-66 (counts cleared with xy above)
+    e.timer = 0;
+    e.t = 0;                  // base.py:315
+}
+
+__device__ __forceinline__ void zero_metrics(Env &e) {
+    e.m_steps = e.m_fix = e.m_sab = e.m_kv = 0;
+    e.flags &= ~(FLAG_FRESH | FLAG_CREW_WON | FLAG_IMP_WON);
+}
+
+// base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order
+template <class RNG>
+__device__ __forceinline__ void sample_actions_env(const Consts &c, const Lds &L, int tid, const Env &e, RNG &rng) {
+    rng.align();
+    for (int i = 0; i < c.A; i++) L.act[i * kBlock + tid] = rng.bounded(n_actions(c, (e.imp >> i) & 1u));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// step
+// ---------------------------------------------------------------------------------------------------
+struct RewardSink {
+    void *ptr;       // NULL = drop
+    int64_t sa, sb;  // element strides for (agent, env)
+    int32_t f64;     // store double instead of float
+    __device__ __forceinline__ void put(int i, int64_t b, double r) const {
+        if (!ptr) return;
+        int64_t k = (int64_t)i * sa + b * sb;
+        if (f64) reinterpret_cast<double *>(ptr)[k] = r;
+        else reinterpret_cast<float *>(ptr)[k] = (float)r;
+    }
+};
+
+// returns error bits (0 = stepped).  Actions are read from L.act; rewards go to `sink` at env index b.
+template <class RNG>
+__device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int tid, Env &e, RNG &rng, const RewardSink &sink,
+                                             int64_t b, bool &done, bool &trunc) {
+    const int A = c.A, J = c.J;
+    const bool tagging = c.variant == SUSNET_VARIANT_TAGGING;
+    done = false;
+    trunc = false;
+    // base.py:357-362 / 379-382: validate before touching anything
+    {
+        uint32_t space_n = 8u + (tagging ? (uint32_t)A : 0u);
+        uint32_t bits = 0;
+        for (int i = 0; i < A; i++) {
+            int32_t a = (int32_t)L.act[i * kBlock + tid];
+            if (a >= (int32_t)space_n) bits |= SUSNET_ERRBIT_ASSERT;
+            else if (a < 0 || (uint32_t)a >= n_actions(c, (e.imp >> i) & 1u)) bits |= SUSNET_ERRBIT_INDEX;
+        }
+        if (bits) {
+            for (int i = 0; i < A; i++) sink.put(i, b, 0.0);
+            return bits;
+        }
+    }
+    if (e.flags & FLAG_FRESH) zero_metrics(e);
+    e.m_steps += 1; // base.py:366
+    uint32_t rc = 0; // 2-bit reward code per agent
+    double team = 0.0;
+
+    uint64_t order = 0xFEDCBA9876543210ull;
+    rng.align();
+    if (c.order_random) shuffle_nibbles(rng, order, A); // base.py:372-374
+
+    const uint32_t crew_alive_mask = ~e.imp;
+    for (int k = 0; k < A; k++) {
+        const int idx = (int)nibble(order, k);
+        const uint32_t a = L.act[idx * kBlock + tid];
+        const uint32_t is_imp = (e.imp >> idx) & 1u;
+        const uint32_t nr = n_role_actions(c, is_imp);
+        if (tagging && a >= nr) {
+            // tagging.py:68-75,103-110: k-th OTHER agent ascending; the actor's own aliveness is not checked
+            uint32_t target = a - nr;
+            if (target >= (uint32_t)idx) target += 1u;
+            if (!((e.used >> idx) & 1u) && ((e.alive >> target) & 1u)) {
+                L.xy[target * kBlock + tid] += 0x100u; // tag_counts[target] += 1
+                e.used |= 1u << idx;
+            }
+            continue;
+        }
+        if (!((e.alive >> idx) & 1u)) continue; // base.py:477
+        const int action = role_action(c, is_imp, a);
+        const uint32_t w = L.xy[idx * kBlock + tid];
+        const uint32_t xy = w & 0xffu;
+        if (action <= ACT_RIGHT) { // base.py:484-487, move() 69-79
+            int x = (int)(xy & 15u), y = (int)(xy >> 4);
+            int nx = x + (action == ACT_RIGHT) - (action == ACT_LEFT);
+            int ny = y + (action == ACT_UP) - (action == ACT_DOWN);
+            // base.py:548-551: in range and grid[pos[1], pos[0]] (TRANSPOSED w.r.t. the spawn lookup)
+            bool ok = (unsigned)nx < (unsigned)c.N && (unsigned)ny < (unsigned)c.N;
+            uint32_t row = L.grid[ok ? ny : 0];
+            ok = ok && ((row >> nx) & 1u);
+            if (ok) L.xy[idx * kBlock + tid] = (w & ~0xffu) | (uint32_t)nx | ((uint32_t)ny << 4);
+        } else if (action == ACT_KILL) { // base.py:490-515
+            uint32_t cm = 0;
+            const uint32_t crew = e.alive & crew_alive_mask;
+            for (int i = 0; i < A; i++)
+                if (((crew >> i) & 1u) && (L.xy[i * kBlock + tid] & 0xffu) == xy) cm |= 1u << i;
+            if (cm) {
+                uint32_t r = rng.bounded((uint32_t)__popc(cm)); // base.py:497
+                int victim = nth_set_bit(cm, r);
+                e.m_kv += 1u;                  // IMP_KILLED_CREW, base.py:508
+                e.alive &= ~(1u << victim);    // base.py:511
+                rc = (rc & ~(3u << (2 * victim))) | (RC_KILL << (2 * victim)); // base.py:514
+                rc = (rc & ~(3u << (2 * idx))) | (RC_KILL << (2 * idx));       // base.py:515
+            }
+        } else { // FIX (base.py:518-524) / SABOTAGE (527-533): first job on the cell (544-546)
+            int job = -1;
+            for (int j = J - 1; j >= 0; j--)
+                if (L.job[j * kBlock + tid] == xy) job = j;
+            if (job >= 0) {
+                const uint32_t isdone = (e.jd >> job) & 1u;
+                if (action == ACT_FIX && !isdone) {
+                    e.jd |= 1u << job;
+                    e.m_fix += 1u;
+                    rc = (rc & ~(3u << (2 * idx))) | (RC_FIX << (2 * idx));
+                } else if (action == ACT_SABOTAGE && isdone) {
+                    e.jd &= ~(1u << job);
+                    e.m_sab += 1u;
+                    rc = (rc & ~(3u << (2 * idx))) | (RC_SAB << (2 * idx));
+                }
+            }
+        }
+    }
+
+    if (tagging) {
+        // tagging.py:180: tag_counts *= alive_agents
+        for (int i = 0; i < A; i++)
+            if (!((e.alive >> i) & 1u)) L.xy[i * kBlock + tid] &= 0xffu;
+        e.timer += 1u; // tagging.py:182
+        if (e.timer >= (uint32_t)c.tag_interval) { // tagging.py:184-207
+            uint32_t best = 0, highest = (L.xy[tid] >> 8) & 0xffu;
+            for (int i = 1; i < A; i++) { // np.argmax: first maximum
+                uint32_t v = (L.xy[i * kBlock + tid] >> 8) & 0xffu;
+                if (v > highest) { highest = v; best = (uint32_t)i; }
+            }
+            uint32_t quorum = ((uint32_t)__popc(e.alive) + 1u) / 2u;
+            if (highest >= quorum) {
+                e.alive &= ~(1u << best);
+                bool vimp = (e.imp >> best) & 1u;
+                team += c.r_vote * (vimp ? -1.0 : 1.0); // tagging.py:196, sign as coded
+                e.m_kv += vimp ? (1u << 16) : (1u << 24);
+            }
+            for (int i = 0; i < A; i++) L.xy[i * kBlock + tid] &= 0xffu; // tagging.py:237-241
+            e.used = 0;
+            e.timer = 0;
+        }
+    }
+
+    // check_win_condition: base.py:409-460 / pred_prey.py:78-99
+    {
+        const int alive_imp = __popc(e.alive & e.imp), alive_all = __popc(e.alive), done_jobs = __popc(e.jd);
+        double win = 0.0;
+        if (c.variant == SUSNET_VARIANT_ITG) {
+            if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = c.r_end; }
+            else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; win = -1.0 * c.r_end; }
+        } else {
+            if (alive_imp == 0 || done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = c.r_end; }
+            else if (alive_all - alive_imp <= alive_imp) { done = true; e.flags |= FLAG_IMP_WON; win = -1.0 * c.r_end; }
+        }
+        team += win;
+    }
+
+    // per-agent rewards: assignments (codes) -> _merge_rewards (base.py:553-563) -> zero fill (389-390)
+    for (int i = 0; i < A; i++) {
+        uint32_t code = (rc >> (2 * i)) & 3u;
+        double r = tagging ? 1.0 * c.r_tsr : 0.0; // tagging.py:162 / base.py:369
+        if (code == RC_KILL) r = c.r_kill;
+        else if (code == RC_FIX) r = c.r_fix;
+        else if (code == RC_SAB) r = -1.0 * c.r_sab;
+        r += team;
+        if (i < c.n_imp) r *= -1.0; // indices [:n_imposters], NOT the imposter mask (base.py:559)
+        if (!((e.alive >> i) & 1u)) r = c.r_dead; // base.py:562
+        if (!tagging && r == 0.0) r = c.r_tsr;    // base.py:389-390 (tagging.py has no fill)
+        sink.put(i, b, r);
+    }
+    // base.py:392-395: t saturates at max_time_steps - 1
+    if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;
+    else e.t += 1u;
+    return 0;
+}
+
+// episode bookkeeping at an auto-reset: per-env lifetime sums (the multi-GPU metrics reduction input)
+__device__ __forceinline__ void accumulate_lifetime(const Consts &c, const State &s, int b, const Env &e, bool trunc) {
+    uint32_t *L = s.life + b;
+    const size_t st = (size_t)c.Bp;
+    L[SUSNET_L_EPISODES * st] += 1u;
+    if (e.flags & FLAG_CREW_WON) L[SUSNET_L_CREW_WON * st] += 1u;
+    if (e.flags & FLAG_IMP_WON) L[SUSNET_L_IMPOSTER_WON * st] += 1u;
+    if (trunc) L[SUSNET_L_TRUNCATED * st] += 1u;
+    if (e.m_kv & 0xffffu) L[SUSNET_L_KILLS * st] += e.m_kv & 0xffffu;
+    if (e.m_fix) L[SUSNET_L_COMPLETED_JOBS * st] += e.m_fix;
+    if (e.m_sab) L[SUSNET_L_SABOTAGED_JOBS * st] += e.m_sab;
+    if ((e.m_kv >> 16) & 0xffu) L[SUSNET_L_IMP_VOTED_OUT * st] += (e.m_kv >> 16) & 0xffu;
+    if (e.m_kv >> 24) L[SUSNET_L_CREW_VOTED_OUT * st] += e.m_kv >> 24;
+    L[SUSNET_L_EPISODE_STEPS * st] += e.m_steps;
+}
+
+} // namespace susnet

@@ -1,0 +1,657 @@
+"""Batched drop-in for the reference environments, running on one MI355X through libsusnet_hip.so.
+
+Mirrors (same ctor kwargs, method names, argument meaning and error types):
+
+* ``BatchedFourRoomEnv``            <- ``FourRoomEnv``            (reference src/environment/base.py:102-582)
+* ``BatchedImposterTrainingGround`` <- ``ImposterTrainingGround`` (reference src/environment/pred_prey.py:20-99)
+* ``BatchedFourRoomEnvWithTagging`` <- ``FourRoomEnvWithTagging`` (reference src/environment/tagging.py:9-249)
+
+Every per-environment quantity of the reference gains a leading batch dimension ``B``:
+``agent_positions [B, A, 2]``, ``alive_agents [B, A]``, rewards ``[B, A]``, ``done [B]``, ``info[name] [B]``.
+PyTorch is used only as the owner of device memory and streams; all dynamics run in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from enum import Enum
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .metrics import SusMetrics
+
+# reference src/environment/base.py:171-193
+REFERENCE_WALLS = ((0, 4), (2, 4), (3, 4), (4, 4), (5, 4), (6, 4), (8, 4), (4, 0), (4, 2), (4, 3), (4, 5), (4, 6), (4, 8))
+
+
+class StateFields(Enum):  # reference src/environment/base.py:36-43
+    AGENT_POSITIONS = 0
+    ALIVE_AGENTS = 1
+    JOB_POSITIONS = 2
+    JOB_STATUS = 3
+    USED_TAGS = 4
+    TAG_COUNTS = 5
+    TAG_RESET_COUNT = 6
+
+
+class Action(Enum):  # reference src/environment/base.py:46-66
+    STAY = 0
+    UP = 1
+    DOWN = 2
+    LEFT = 3
+    RIGHT = 4
+    KILL = 5
+    FIX = 6
+    SABOTAGE = 7
+
+    @property
+    def is_move_action(self):
+        return self in (Action.UP, Action.DOWN, Action.LEFT, Action.RIGHT, Action.STAY)
+
+    @property
+    def is_job_action(self):
+        return self in (Action.KILL, Action.FIX, Action.SABOTAGE)
+
+
+CREW_ACTIONS = [Action.STAY, Action.UP, Action.DOWN, Action.LEFT, Action.RIGHT, Action.FIX]  # base.py:82-89
+IMPOSTER_ACTIONS = [Action.STAY, Action.UP, Action.DOWN, Action.LEFT, Action.RIGHT, Action.SABOTAGE, Action.KILL]  # 91-99
+CREW_ACTIONS_SIMPLE = CREW_ACTIONS[:5]  # pred_prey.py:4-10
+IMPOSTER_ACTIONS_SIMPLE = CREW_ACTIONS[:5] + [Action.KILL]  # pred_prey.py:12-19
+
+
+def four_room_grid(n: int = 9, include_walls: bool = True) -> np.ndarray:
+    """``grid[i, j]`` True = free.  n == 9 is the reference layout (base.py:171-197).  Other sizes (the
+    reference hard-codes 9) use the same transpose-symmetric shape: one wall row and column at index
+    ``(n - 1) // 2`` with a door gap two cells in from each end of every arm."""
+    g = np.ones((n, n), dtype=bool)
+    if not include_walls:
+        return g
+    if n == 9:
+        for i, j in REFERENCE_WALLS:
+            g[i, j] = False
+        return g
+    wall = (n - 1) // 2                                    # 9 -> 4, 14 -> 6
+    doors = ((wall - 1) // 2, wall + 1 + (n - 1 - wall) // 2)  # 9 -> (1, 7) as the reference, 14 -> (2, 10)
+    for i in range(n):
+        if i not in doors:
+            g[i, wall] = False
+            g[wall, i] = False
+    return g
+
+
+_TORCH_TO_SUS = {torch.uint8: L.U8, torch.int32: L.I32, torch.int64: L.I64}
+
+
+class ObsConfig:
+    """Which fused observation the kernels write next to every step / reset / rollout tick.
+
+    mode: ``None`` | ``"raw"`` (``flatten_state``) | ``"flat"`` (FlatFeaturizer over ``components``) |
+    ``"planes"`` (GlobalFeaturizer).  dtype ``torch.float32`` reproduces the reference tensors,
+    ``torch.uint8`` stores the same integers in a quarter of the bytes.
+    """
+
+    def __init__(self, mode: Optional[str] = None, components: Sequence[str] = (), dtype=torch.float32):
+        assert mode in (None, "raw", "flat", "planes"), mode
+        assert dtype in (torch.float32, torch.uint8, torch.int8)
+        self.mode, self.components, self.dtype = mode, list(components), dtype
+        if mode == "flat":
+            unknown = [c for c in self.components if c not in L.FLAT_COMPONENTS]
+            assert self.components and not unknown, f"unknown flat components {unknown}"
+
+    @property
+    def code(self):
+        return {None: L.OBS_NONE, "raw": L.OBS_RAW, "flat": L.OBS_FLAT, "planes": L.OBS_PLANES}[self.mode]
+
+
+class BatchedFourRoomEnv:
+    VARIANT = L.VARIANT_BASE
+    crew_actions = CREW_ACTIONS
+    imposter_actions = IMPOSTER_ACTIONS
+
+    def __init__(
+        self,
+        n_imposters: int,
+        n_crew: int,
+        n_jobs: int,
+        is_action_order_random=True,
+        random_state: Optional[int] = None,
+        kill_reward: int = -5,
+        complete_job_reward=3,
+        sabotage_reward=3,
+        time_step_reward: int = 0,
+        game_end_reward: int = 10,
+        dead_penalty: int = -2,
+        shuffle_imposter_index: bool = True,
+        debug: bool = False,
+        max_time_steps=1000,
+        include_walls: bool = True,
+        *,
+        batch: int = 1,
+        device="cuda",
+        grid: Optional[np.ndarray] = None,
+        grid_size: int = 9,
+        auto_reset: bool = False,
+        rng: str = "philox",
+        seed: int = 0,
+        env_id_base: int = 0,
+        tape_words: int = 1 << 15,
+        obs: Optional[ObsConfig] = None,
+        reward_dtype=torch.float32,
+        export_state: bool = True,
+        check_errors: bool = True,
+        _tag_reset_interval: int = 50,
+        _vote_reward=3,
+    ):
+        self._validate_init_args(n_imposters, n_crew, n_jobs)
+        assert rng in ("philox", "numpy", "tape")
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("sus-net_amd runs on a ROCm device only (device='cuda[:i]')")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.batch = int(batch)
+        self.is_action_order_random = is_action_order_random
+        self.n_imposters, self.n_crew, self.n_jobs = n_imposters, n_crew, n_jobs
+        self.n_agents = n_imposters + n_crew
+        self.kill_reward, self.complete_job_reward, self.sabotage_reward = kill_reward, complete_job_reward, sabotage_reward
+        self.time_step_reward, self.game_end_reward, self.dead_penalty = time_step_reward, game_end_reward, dead_penalty
+        self.shuffle_imposter_index = shuffle_imposter_index
+        self.max_time_steps = max_time_steps
+        self.auto_reset, self.rng_kind, self.seed, self.env_id_base = auto_reset, rng, int(seed), int(env_id_base)
+        self.export_state, self.check_errors = export_state, check_errors
+        self.reward_dtype = reward_dtype
+        self.tape_words = tape_words
+        self.debug = debug
+
+        self.grid = np.asarray(grid, dtype=bool) if grid is not None else four_room_grid(grid_size, include_walls)
+        n = self.grid.shape[0]
+        assert self.grid.shape == (n, n) and n <= L.MAX_GRID, "square grid up to 16x16"
+        self.n_rows = self.n_cols = n
+        self.valid_positions = np.argwhere(self.grid)
+        self.walls = np.argwhere(~self.grid)
+        self.n_imposter_actions = len(self.imposter_actions)
+        self.n_crew_actions = len(self.crew_actions)
+        self.state_fields = {f: i for i, f in enumerate(
+            [StateFields.AGENT_POSITIONS, StateFields.ALIVE_AGENTS, StateFields.JOB_POSITIONS, StateFields.JOB_STATUS])}
+
+        cfg = L.Config()
+        cfg.struct_bytes, cfg.abi_version = C.sizeof(L.Config), L.ABI_VERSION
+        cfg.variant, cfg.batch = self.VARIANT, self.batch
+        cfg.n_imposters, cfg.n_crew, cfg.n_jobs, cfg.grid_n = n_imposters, n_crew, n_jobs, n
+        for i in range(n):
+            cfg.grid_rows[i] = int(sum(1 << j for j in range(n) if self.grid[i, j]))
+        cfg.kill_reward, cfg.complete_job_reward, cfg.sabotage_reward = kill_reward, complete_job_reward, sabotage_reward
+        cfg.time_step_reward, cfg.game_end_reward, cfg.dead_penalty = time_step_reward, game_end_reward, dead_penalty
+        cfg.vote_reward = _vote_reward
+        cfg.max_time_steps = max_time_steps
+        cfg.is_action_order_random = int(bool(is_action_order_random))
+        cfg.shuffle_imposter_index = int(bool(shuffle_imposter_index))
+        cfg.tag_reset_interval = _tag_reset_interval
+        cfg.auto_reset = int(bool(auto_reset))
+        cfg.rng_mode = L.RNG_PHILOX if rng == "philox" else L.RNG_TAPE
+        cfg.seed, cfg.env_id_base, cfg.device = self.seed & (2**64 - 1), self.env_id_base, self.device.index
+        self._cfg = cfg
+        self._h = C.c_void_p()
+        rc = self.lib.susnet_create(C.byref(cfg), C.byref(self._h))
+        if rc == L.E_INVALID:
+            raise AssertionError(self.lib.susnet_last_error().decode())  # reference ctor asserts (base.py:243-249)
+        L.check(rc)
+        self._layout = L.Layout()
+        L.check(self.lib.susnet_get_layout(self._h, C.byref(self._layout)))
+        self.action_space_n = self._layout.action_space_n
+        B, A, J = self.batch, self.n_agents, self.n_jobs
+        dev = self.device
+        with torch.cuda.device(dev):
+            self._state = torch.empty(self._layout.state_bytes, dtype=torch.uint8, device=dev)
+            L.check(self.lib.susnet_bind_state(self._h, self._state.data_ptr(), self._state.numel(), self._stream()))
+        # reference-layout views refreshed by the export kernel
+        self.agent_positions = torch.zeros(B, A, 2, dtype=torch.int32, device=dev)
+        self.alive_agents = torch.zeros(B, A, dtype=torch.bool, device=dev)
+        self.imposter_mask = torch.zeros(B, A, dtype=torch.bool, device=dev)
+        self.job_positions = torch.zeros(B, J, 2, dtype=torch.int32, device=dev)
+        self.completed_jobs = torch.zeros(B, J, dtype=torch.bool, device=dev)
+        self.used_tag_actions = torch.zeros(B, A, dtype=torch.bool, device=dev)
+        self.tag_counts = torch.zeros(B, A, dtype=torch.int32, device=dev)
+        self._timer = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._t = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._metrics = torch.zeros(B, L.N_METRICS, dtype=torch.int64, device=dev)
+        self._rewards = torch.zeros(A, B, dtype=reward_dtype, device=dev)  # [A][B] in memory; exposed as [B, A]
+        self._done = torch.zeros(B, dtype=torch.bool, device=dev)
+        self._trunc = torch.zeros(B, dtype=torch.bool, device=dev)
+        self._actions = torch.zeros(A, B, dtype=torch.uint8, device=dev)
+        self._life_sum = torch.zeros(L.N_LIFETIME, dtype=torch.int64, device=dev)
+        self._tape = None
+        self.metrics = _MetricsView(self)
+        self.obs_config = obs or ObsConfig(None)
+        self._obs_spec, self.obs, self.obs_non_spatial = self._make_obs(self.obs_config, 1)
+        self.agent_action_map = _ActionMapView(self)
+        if random_state is not None:  # base.py:125-126
+            self._reseed(random_state)
+
+    # ------------------------------------------------------------------------------------------
+    def _validate_init_args(self, n_imposters, n_crew, n_jobs):  # base.py:243-249
+        assert n_imposters > 0, f"Must have at least one imposter. Got {n_imposters}."
+        assert n_crew > 0, f"Must have at least one crew member. Got {n_crew}."
+        assert n_jobs >= 0, f"Must non-negative jobs. Got {n_jobs}."
+        assert n_imposters < n_crew, (
+            f"Must be more crew members than imposters. Got {n_imposters} imposters and {n_crew} crew members.")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self.lib.susnet_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _make_obs(self, oc: ObsConfig, ticks: int):
+        if oc.mode is None:
+            return None, None, None
+        spec = L.ObsSpec()
+        spec.mode = oc.code
+        spec.dtype = L.F32 if oc.dtype == torch.float32 else L.U8
+        spec.n_components = len(oc.components)
+        for i, c in enumerate(oc.components):
+            spec.components[i] = L.FLAT_COMPONENTS[c]
+        f1, f2 = C.c_int32(0), C.c_int32(0)
+        rc = self.lib.susnet_obs_size(self._h, C.byref(spec), C.byref(f1), C.byref(f2))
+        if rc == L.E_INVALID:
+            raise ValueError(self.lib.susnet_last_error().decode())
+        L.check(rc)
+        lead = (ticks, self.batch) if ticks > 1 else (self.batch,)
+        A, N = self.n_agents, self.n_rows
+        shape1 = (*lead, A + 2, N, N) if oc.mode == "planes" else (*lead, f1.value)
+        out = torch.zeros(shape1, dtype=oc.dtype, device=self.device)
+        out2 = torch.zeros((*lead, f2.value), dtype=oc.dtype, device=self.device) if f2.value else None
+        spec.out = out.data_ptr()
+        spec.out2 = out2.data_ptr() if out2 is not None else None
+        return spec, out, out2
+
+    def _obs_ptr(self):
+        return C.byref(self._obs_spec) if self._obs_spec is not None else None
+
+    # ---- randomness --------------------------------------------------------------------------
+    def _reseed(self, seed):
+        """np.random.seed(seed) of the reference (base.py:126,267).
+
+        philox: Philox key = seed, every env's stream restarts at word 0 (env b uses counter env_id_base+b).
+        numpy : env b consumes numpy's legacy MT19937 stream for seed ``seed + b`` -- at batch 1 the
+                decisions equal the reference's for the same seed.
+        """
+        if self.rng_kind == "philox":
+            self.seed = int(seed)
+            L.check(self.lib.susnet_seed(self._h, self.seed & (2**64 - 1), 0, self._stream()))
+        elif self.rng_kind == "numpy":
+            seeds = [int(seed) + b for b in range(self.batch)] if np.isscalar(seed) else [int(s) for s in seed]
+            tape = np.stack([np.random.RandomState(s).randint(0, 2**32, size=self.tape_words, dtype=np.uint32) for s in seeds])
+            self.set_tape(tape)
+        else:
+            raise ValueError("rng='tape': call set_tape(words[B, L]) instead of seeding")
+
+    def set_tape(self, words):
+        """Bind raw 32-bit words [B, L] (any integer tensor/array holding values < 2**32); cursors restart at 0."""
+        w = torch.as_tensor(np.asarray(words.cpu() if isinstance(words, torch.Tensor) else words).astype(np.uint32).view(np.int32))
+        assert w.dim() == 2 and w.shape[0] == self.batch
+        self._tape = w.contiguous().to(self.device)
+        L.check(self.lib.susnet_bind_tape(self._h, self._tape.data_ptr(), self._tape.shape[1]))
+        cur = torch.zeros(self.batch, dtype=torch.int64, device=self.device)
+        view = L.StateView()
+        view.rng_cursor = cur.data_ptr()
+        L.check(self.lib.susnet_import_state(self._h, C.byref(view), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()  # `cur` must outlive the async import
+
+    # ---- reference API -----------------------------------------------------------------------
+    @property
+    def flattened_state_size(self):  # base.py:230-232
+        return self._layout.obs_raw_size
+
+    def flatten_state(self, state):  # base.py:234-235 (batched: [B, S])
+        parts = [p.reshape(self.batch, -1).to(torch.int64) for p in state]
+        return torch.cat(parts, dim=1)
+
+    def unflatten_state(self, flat):  # base.py:237-241
+        flat = torch.as_tensor(flat)
+        A, J = self.n_agents, self.n_jobs
+        lead = flat.shape[:-1]
+        out, k = [], 0
+        out.append(flat[..., k:k + 2 * A].reshape(*lead, A, 2)); k += 2 * A
+        out.append(flat[..., k:k + A]); k += A
+        if J > 0 or self.VARIANT == L.VARIANT_TAGGING:
+            out.append(flat[..., k:k + 2 * J].reshape(*lead, J, 2)); k += 2 * J
+            out.append(flat[..., k:k + J]); k += J
+        if self.VARIANT == L.VARIANT_TAGGING:
+            out.append(flat[..., k:k + A]); k += A
+            out.append(flat[..., k:k + A]); k += A
+            out.append(flat[..., k:k + 1])
+        return tuple(out)
+
+    @property
+    def imposter_idxs(self):
+        """[B, n_imposters] ascending agent indices (the reference keeps numpy's draw order, base.py:274-278;
+        only the set matters to the dynamics)."""
+        return torch.nonzero(self.imposter_mask)[:, 1].reshape(self.batch, self.n_imposters)
+
+    @property
+    def crew_mask(self):
+        return ~self.imposter_mask
+
+    @property
+    def t(self):
+        return self._t
+
+    def _export(self, full: bool):
+        view = L.StateView()
+        view.agent_positions = self.agent_positions.data_ptr()
+        view.alive_agents = self.alive_agents.data_ptr()
+        view.metrics = self._metrics.data_ptr()
+        view.t = self._t.data_ptr()
+        if self.n_jobs:
+            view.completed_jobs = self.completed_jobs.data_ptr()
+        if full or self.auto_reset:
+            view.imposter_mask = self.imposter_mask.data_ptr()
+            if self.n_jobs:
+                view.job_positions = self.job_positions.data_ptr()
+        if self.VARIANT == L.VARIANT_TAGGING:
+            view.used_tag_actions = self.used_tag_actions.data_ptr()
+            view.tag_counts = self.tag_counts.data_ptr()
+            view.tag_reset_timer = self._timer.data_ptr()
+        L.check(self.lib.susnet_export_state(self._h, C.byref(view), self._stream()))
+
+    def _state_tuple(self):  # base.py:317-323 / 397-402
+        return (self.agent_positions, self.alive_agents,
+                *([self.job_positions, self.completed_jobs] if self.n_jobs > 0 else []))
+
+    def reset(self, seed: Optional[int] = None, mask=None, **kwargs) -> Tuple[Tuple, Dict]:
+        """base.py:251-324.  ``mask`` [B] bool restricts the reset to some environments."""
+        with torch.cuda.device(self.device):
+            if seed is not None:
+                self._reseed(seed)
+            m = None
+            if mask is not None:
+                m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            L.check(self.lib.susnet_reset(self._h, m.data_ptr() if m is not None else None, self._obs_ptr(), self._stream()))
+            if self.export_state:
+                self._export(full=True)
+            if self.check_errors:
+                self.poll_errors()
+        return self._state_tuple(), self.metrics.get_metrics()
+
+    def sample_actions(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """base.py:326-330: uniform role-valid action index per agent; returns [B, A]."""
+        with torch.cuda.device(self.device):
+            if out is None:
+                buf, dtype, layout = self._actions, L.U8, L.LAYOUT_AB  # [A][B] in memory, returned as a [B, A] view
+            else:
+                dtype, layout, buf = self._describe_actions(out)
+            L.check(self.lib.susnet_sample_actions(self._h, buf.data_ptr(), dtype, layout, self._stream()))
+        return buf.t() if out is None else buf
+
+    def _describe_actions(self, a: torch.Tensor):
+        A, B = self.n_agents, self.batch
+        if a.dtype not in _TORCH_TO_SUS:
+            a = a.to(torch.int64)
+        if tuple(a.shape) == (B, A) and a.is_contiguous():
+            return _TORCH_TO_SUS[a.dtype], L.LAYOUT_BA, a
+        if tuple(a.shape) == (B, A) and a.t().is_contiguous():
+            return _TORCH_TO_SUS[a.dtype], L.LAYOUT_AB, a
+        if tuple(a.shape) == (A, B) and a.is_contiguous() and A != B:
+            return _TORCH_TO_SUS[a.dtype], L.LAYOUT_AB, a
+        if tuple(a.shape) == (B, A):
+            a = a.contiguous()
+            return _TORCH_TO_SUS[a.dtype], L.LAYOUT_BA, a
+        raise AssertionError(f"Expected {A} actions per environment, got shape {tuple(a.shape)}")  # base.py:357-359
+
+    def step(self, agent_actions):
+        """base.py:332-407.  Returns ``(state, rewards[B, A], done[B], truncated[B], info)``."""
+        a = agent_actions
+        if not isinstance(a, torch.Tensor):
+            a = torch.as_tensor(np.asarray(a))
+        if a.dim() == 1 and self.batch == 1:
+            a = a.reshape(1, -1)
+        assert a.shape[-1] == self.n_agents or tuple(a.shape) == (self.n_agents, self.batch), (
+            f"Expected {self.n_agents} actions, got {a.shape[-1]}")  # base.py:357-359
+        with torch.cuda.device(self.device):
+            if a.device != self.device:
+                a = a.to(self.device)
+            dtype, layout, a = self._describe_actions(a)
+            io = L.StepIO()
+            io.actions, io.actions_dtype, io.actions_layout = a.data_ptr(), dtype, layout
+            io.rewards = self._rewards.data_ptr()
+            io.rewards_dtype = L.F32 if self._rewards.dtype == torch.float32 else L.F64
+            io.rewards_layout = L.LAYOUT_AB
+            io.done, io.truncated = self._done.data_ptr(), self._trunc.data_ptr()
+            if self._obs_spec is not None:
+                io.obs = C.pointer(self._obs_spec)
+            L.check(self.lib.susnet_step(self._h, C.byref(io), self._stream()))
+            if self.export_state:
+                self._export(full=False)
+            if self.check_errors:
+                self.poll_errors()
+        return self._state_tuple(), self._rewards.t(), self._done, self._trunc, self.metrics.get_metrics()
+
+    def step4(self, agent_actions):
+        """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""
+        state, rew, done, trunc, info = self.step(agent_actions)
+        obs = self.obs if self._obs_spec is not None else state
+        return obs, rew, done | trunc, info
+
+    def alloc_rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None):
+        """Allocate (once) the trajectory buffers a fused rollout of up to ``n_ticks`` ticks writes:
+        actions u8 [T, A, B], rewards f32 [T, A, B], done / truncated bool [T, B], obs [T, B, ...]."""
+        T, A, B = int(n_ticks), self.n_agents, self.batch
+        out = {"n_ticks": T}
+        if "actions" in store:
+            out["actions"] = torch.empty(T, A, B, dtype=torch.uint8, device=self.device)
+        if "rewards" in store:
+            out["rewards"] = torch.empty(T, A, B, dtype=torch.float32, device=self.device)
+        if "done" in store:
+            out["done"] = torch.empty(T, B, dtype=torch.bool, device=self.device)
+        if "truncated" in store:
+            out["truncated"] = torch.empty(T, B, dtype=torch.bool, device=self.device)
+        if obs is not None and obs.mode is not None:
+            spec, o1, o2 = self._make_obs(obs, T)
+            out["_obs_spec"] = spec
+            out["obs"] = o1 if T > 1 else o1.unsqueeze(0)
+            if o2 is not None:
+                out["obs_non_spatial"] = o2 if T > 1 else o2.unsqueeze(0)
+        return out
+
+    def rollout_into(self, n_ticks: int, bufs) -> None:
+        """One fused launch of ``n_ticks`` (<= the buffers' capacity) ticks; asynchronous on the current stream."""
+        assert self.rng_kind == "philox", "rollout() uses the Philox stream"
+        assert 1 <= n_ticks <= bufs["n_ticks"]
+        io = L.RolloutIO()
+        io.n_ticks = int(n_ticks)
+        for name in ("actions", "rewards", "done", "truncated"):
+            if name in bufs:
+                setattr(io, name, bufs[name].data_ptr())
+        if "_obs_spec" in bufs:
+            io.obs = C.pointer(bufs["_obs_spec"])
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_rollout(self._h, C.byref(io), self._stream()))
+
+    def rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None):
+        """Fused random rollout (ReplayBuffer.populate's loop, reference src/replay_memory.py:96-143, without
+        the buffer): ``n_ticks`` x {sample_actions; step; reset on done|truncated} in ONE launch.
+        Returns a dict of trajectory tensors with a leading tick dimension."""
+        bufs = self.alloc_rollout(n_ticks, store, obs)
+        self.rollout_into(n_ticks, bufs)
+        return bufs
+
+    def observe(self, obs: Optional[ObsConfig] = None):
+        """Observation of the CURRENT state (same writers the step kernel fuses)."""
+        oc = obs or self.obs_config
+        spec, o1, o2 = self._make_obs(oc, 1)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_observe(self._h, C.byref(spec), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+        return (o1, o2) if o2 is not None else o1
+
+    def poll_errors(self):
+        bits = C.c_uint32(0)
+        rc = self.lib.susnet_poll_errors(self._h, C.byref(bits), self._stream())
+        if rc == L.E_ACTION_ASSERT:
+            raise AssertionError("Invalid action(s): some action >= action_space.n")  # base.py:360-362
+        if rc == L.E_ACTION_INDEX:
+            raise IndexError("list index out of range")  # base.py:379-382
+        L.check(rc)
+
+    def set_state(self, *, agent_positions=None, alive_agents=None, imposter_mask=None, job_positions=None,
+                  completed_jobs=None, used_tag_actions=None, tag_counts=None, tag_reset_timer=None, t=None,
+                  metrics=None, rng_cursor=None):
+        """Direct state assignment (what reference callers do with ``env.agent_positions[...] = ...``)."""
+        keep = []
+
+        def dev(x, dtype):
+            tns = torch.as_tensor(np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x)).to(dtype).contiguous().to(self.device)
+            keep.append(tns)
+            return tns.data_ptr()
+
+        view = L.StateView()
+        if agent_positions is not None:
+            view.agent_positions = dev(agent_positions, torch.int32)
+        if alive_agents is not None:
+            view.alive_agents = dev(alive_agents, torch.uint8)
+        if imposter_mask is not None:
+            view.imposter_mask = dev(imposter_mask, torch.uint8)
+        if job_positions is not None:
+            view.job_positions = dev(job_positions, torch.int32)
+        if completed_jobs is not None:
+            view.completed_jobs = dev(completed_jobs, torch.uint8)
+        if used_tag_actions is not None:
+            view.used_tag_actions = dev(used_tag_actions, torch.uint8)
+        if tag_counts is not None:
+            view.tag_counts = dev(tag_counts, torch.int32)
+        if tag_reset_timer is not None:
+            view.tag_reset_timer = dev(tag_reset_timer, torch.int32)
+        if t is not None:
+            view.t = dev(t, torch.int32)
+        if metrics is not None:
+            view.metrics = dev(metrics, torch.int64)
+        if rng_cursor is not None:
+            view.rng_cursor = dev(rng_cursor, torch.int64)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_import_state(self._h, C.byref(view), self._stream()))
+            if self.export_state:
+                self._export(full=True)
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def rng_cursor(self) -> torch.Tensor:
+        cur = torch.zeros(self.batch, dtype=torch.int64, device=self.device)
+        view = L.StateView()
+        view.rng_cursor = cur.data_ptr()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_export_state(self._h, C.byref(view), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+        return cur
+
+    def lifetime_totals(self) -> torch.Tensor:
+        """int64[12] sums over this device's envs of the per-env episode accumulators (device tensor):
+        the vector the multi-GPU host all-gathers (see dist.py)."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_reduce_lifetime(self._h, self._life_sum.data_ptr(), self._stream()))
+        return self._life_sum
+
+    def compute_action(self, agent_idx, action_idx, env_idx: int = 0):  # base.py:581-582
+        return str(self.agent_action_map[agent_idx, env_idx][action_idx])
+
+
+class BatchedImposterTrainingGround(BatchedFourRoomEnv):
+    """reference src/environment/pred_prey.py:20-99: one imposter, no FIX/SABOTAGE, fixed action order,
+    dead_penalty 0, own win rule; allows 1v1 (75-76)."""
+
+    VARIANT = L.VARIANT_ITG
+    crew_actions = CREW_ACTIONS_SIMPLE
+    imposter_actions = IMPOSTER_ACTIONS_SIMPLE
+
+    def __init__(self, n_crew, n_jobs, time_step_reward, kill_reward, sabotage_reward, end_of_game_reward,
+                 random_state=None, debug=False, shuffle_imposter_index=False, include_walls: bool = True, **batched):
+        super().__init__(
+            n_imposters=1, n_crew=n_crew, n_jobs=n_jobs, time_step_reward=time_step_reward, kill_reward=kill_reward,
+            sabotage_reward=sabotage_reward, debug=debug, dead_penalty=0, game_end_reward=end_of_game_reward,
+            random_state=random_state, is_action_order_random=False, shuffle_imposter_index=shuffle_imposter_index,
+            include_walls=include_walls, **batched)
+
+    def _validate_init_args(self, n_imposters, n_crew, n_jobs):  # pred_prey.py:75-76
+        assert n_crew > 0, f"Must have at least one crew member. Got {n_crew}."
+
+
+class BatchedFourRoomEnvWithTagging(BatchedFourRoomEnv):
+    """reference src/environment/tagging.py:9-249 (per-agent one-shot votes, tally every tag_reset_interval)."""
+
+    VARIANT = L.VARIANT_TAGGING
+
+    def __init__(self, *args, tag_reset_interval: int = 50, vote_reward: int = 3, **kwargs):
+        self.tag_reset_interval, self.vote_reward = tag_reset_interval, vote_reward
+        super().__init__(*args, _tag_reset_interval=tag_reset_interval, _vote_reward=vote_reward, **kwargs)
+        self.n_imposter_actions += self.n_agents - 1  # tagging.py:35-36
+        self.n_crew_actions += self.n_agents - 1
+        # tagging.py:15-28 (this order does not match the returned tuple -- reproduced as is)
+        self.state_fields = {f: i for i, f in enumerate(
+            [StateFields.AGENT_POSITIONS, StateFields.JOB_POSITIONS, StateFields.JOB_STATUS, StateFields.ALIVE_AGENTS,
+             StateFields.USED_TAGS, StateFields.TAG_COUNTS, StateFields.TAG_RESET_COUNT])}
+
+    @property
+    def tag_reset_timer(self):
+        return self._timer
+
+    def _state_tuple(self):  # tagging.py:94-99, 220-230
+        return (self.agent_positions, self.alive_agents, self.job_positions, self.completed_jobs,
+                self.used_tag_actions, self.tag_counts, self.tag_reset_interval - self._timer)
+
+    def reset(self, seed=None, mask=None, **kwargs):
+        state, _ = super().reset(seed=seed, mask=mask, **kwargs)
+        return state, {}  # tagging.py:101
+
+    def compute_action(self, agent_idx, action_idx, env_idx: int = 0):  # tagging.py:243-249
+        if action_idx < len(Action):
+            return str(Action(action_idx))
+        players = [p for p in range(self.n_agents) if p != agent_idx]
+        return f"Vote Player {players[action_idx - len(Action)]}"
+
+
+class _MetricsView:
+    """``env.metrics`` of the reference (EnvMetricHandler, src/metrics.py:35-64), batched: values are [B] tensors."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def get_metrics(self) -> Dict[SusMetrics, torch.Tensor]:
+        m = self._env._metrics
+        return {metric: m[:, i] for i, metric in enumerate(SusMetrics)}
+
+    @property
+    def metrics(self):
+        return self.get_metrics()
+
+    def __repr__(self):
+        return repr({k.value: v.tolist() for k, v in self.get_metrics().items()})
+
+
+class _ActionMapView:
+    """``env.agent_action_map[agent]`` (base.py:306-312; tagging.py:68-75) for environment ``env_idx``."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __getitem__(self, key):
+        agent, env_idx = key if isinstance(key, tuple) else (key, 0)
+        e = self._env
+        is_imp = bool(e.imposter_mask[env_idx, agent])
+        acts = list(e.imposter_actions if is_imp else e.crew_actions)
+        if e.VARIANT == L.VARIANT_TAGGING:
+            acts += [p for p in range(e.n_agents) if p != agent]
+        return acts
+
+    def __iter__(self):
+        return iter(range(self._env.n_agents))
+
+    def __len__(self):
+        return self._env.n_agents

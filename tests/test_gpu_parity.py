@@ -1,0 +1,372 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP kernels, called through the C ABI, must
+be bit-exact against (a) the golden traces of the reference and (b) the CPU oracle."""
+import importlib
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_golden, trace_names
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return importlib.import_module("sus-net_amd")
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def env_from_meta(pkg, meta, batch, **kw):
+    cls = meta["class"]
+    k = dict(meta["kwargs"])
+    k.pop("include_walls", None)
+    grid = np.array(meta["grid_used"], dtype=bool)
+    if cls == "itg":
+        return pkg.BatchedImposterTrainingGround(**k, grid=grid, batch=batch, **kw)
+    if cls == "tagging":
+        return pkg.BatchedFourRoomEnvWithTagging(**k, grid=grid, batch=batch, **kw)
+    return pkg.BatchedFourRoomEnv(**k, grid=grid, batch=batch, **kw)
+
+
+def families():
+    fam = {}
+    for n in trace_names():
+        m = re.match(r"(.*)_s(\d+)$", n)
+        key = m.group(1) if m else n
+        fam.setdefault(key, []).append(n)
+    return fam
+
+
+FAMILIES = families()
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def check_step_against_golden(env, gs, s, rew, done, trunc, tagging):
+    B = len(gs)
+    pos, alive = np_(env.agent_positions), np_(env.alive_agents)
+    met = np_(env._metrics)
+    for b, g in enumerate(gs):
+        tag = f"{g['name']} step {s}"
+        np.testing.assert_array_equal(pos[b], g["pos"][s], err_msg=tag + " pos")
+        np.testing.assert_array_equal(alive[b], g["alive"][s].astype(bool), err_msg=tag + " alive")
+        if env.n_jobs:
+            np.testing.assert_array_equal(np_(env.completed_jobs)[b], g["jobdone"][s].astype(bool), err_msg=tag + " jobdone")
+        want = g["rewards"][s]
+        got = np_(rew)[b].astype(np.float64)
+        assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist(), f"{tag} rewards {got} vs {want}"
+        assert bool(np_(done)[b]) == bool(g["done"][s]) and bool(np_(trunc)[b]) == bool(g["trunc"][s]), tag + " done/trunc"
+        np.testing.assert_array_equal(met[b], g["metrics"][s], err_msg=tag + " metrics")
+        if tagging:
+            np.testing.assert_array_equal(np_(env.used_tag_actions)[b], g["used"][s].astype(bool), err_msg=tag + " used")
+            np.testing.assert_array_equal(np_(env.tag_counts)[b], g["counts"][s], err_msg=tag + " counts")
+            assert env.tag_reset_interval - int(np_(env._timer)[b]) == int(g["timer_left"][s]), tag + " timer"
+
+
+# ------------------------------------------------------------------------------------------------
+# (a) HIP kernels vs the reference's golden traces, fed numpy's MT19937 words as the tape
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family", sorted(FAMILIES))
+def test_hip_replays_reference_traces(pkg, family):
+    gs = [load_golden(f"{GOLDEN_DIR}/{n}.npz") for n in FAMILIES[family]]
+    meta = gs[0]["meta"]
+    B = len(gs)
+    tagging = meta["class"] == "tagging"
+    env = env_from_meta(pkg, meta, B, rng="numpy", reward_dtype=torch.float64, tape_words=1 << 15)
+    env._reseed([g["meta"]["seed"] for g in gs])  # env b consumes numpy's legacy stream of its fixture's seed
+    env.reset()
+    np.testing.assert_array_equal(np_(env.rng_cursor()), [g["words"][0] for g in gs])
+    sampled = meta["mode"] == "sampled"
+    S = len(gs[0]["done"])
+    for s in range(S):
+        if s > 0:
+            mask = np.array([bool(g["ep_start"][s]) for g in gs])
+            if mask.any():
+                env.reset(mask=mask)
+        if not sampled:
+            for b, g in enumerate(gs):
+                assert B == 1
+                if g["inject"][s]:
+                    kw = dict(agent_positions=g["pre_pos"][s][None], alive_agents=g["pre_alive"][s][None], t=g["pre_t"][s:s + 1])
+                    if env.n_jobs:
+                        kw.update(job_positions=g["pre_jobpos"][s][None], completed_jobs=g["pre_jobdone"][s][None])
+                    if tagging:
+                        kw.update(used_tag_actions=g["pre_used"][s][None], tag_counts=g["pre_counts"][s][None],
+                                  tag_reset_timer=g["pre_timer"][s:s + 1])
+                    env.set_state(**kw)
+        # state before the step (after reset / injection) -- includes the reset's random spawns
+        np.testing.assert_array_equal(np_(env.agent_positions), np.stack([g["pre_pos"][s] for g in gs]), err_msg=f"pre_pos {s}")
+        np.testing.assert_array_equal(np_(env.imposter_mask), np.stack([g["pre_imp"][s] for g in gs]).astype(bool))
+        if env.n_jobs:
+            np.testing.assert_array_equal(np_(env.job_positions), np.stack([g["pre_jobpos"][s] for g in gs]))
+        want_a = np.stack([g["actions"][s] for g in gs])
+        if sampled:
+            a = env.sample_actions().clone()
+            np.testing.assert_array_equal(np_(a), want_a, err_msg=f"sampled actions step {s}")
+        else:
+            a = torch.as_tensor(want_a.astype(np.int64))
+        _, rew, done, trunc, _ = env.step(a)
+        check_step_against_golden(env, gs, s, rew, done, trunc, tagging)
+    # raw words consumed == what numpy consumed (only comparable where no reset follows)
+    cur = np_(env.rng_cursor())
+    for b, g in enumerate(gs):
+        if not (g["done"][-1] or g["trunc"][-1]):
+            assert cur[b] == g["words"][-1], g["name"]
+
+
+# ------------------------------------------------------------------------------------------------
+# (b) HIP kernels vs the CPU oracle on the production (Philox) stream, with auto-reset
+# ------------------------------------------------------------------------------------------------
+CONFIGS = {
+    "itg_1v1_nowalls": dict(cls="itg", kw=dict(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
+                                              time_step_reward=0, include_walls=False), n=9),
+    "base_1v2_j4_14": dict(cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14),
+    "base_2v6_j4_14": dict(cls="base", kw=dict(n_imposters=2, n_crew=6, n_jobs=4), n=14),
+    "base_3v9_j8_16": dict(cls="base", kw=dict(n_imposters=3, n_crew=9, n_jobs=8, max_time_steps=60), n=16),
+    "tagging_1v4_j5": dict(cls="tagging", kw=dict(n_imposters=1, n_crew=4, n_jobs=5, tag_reset_interval=6), n=9),
+    "tagging_2v6_j4_14": dict(cls="tagging", kw=dict(n_imposters=2, n_crew=6, n_jobs=4, tag_reset_interval=11, time_step_reward=-1), n=14),
+    "itg_1v5_j3": dict(cls="itg", kw=dict(n_crew=5, n_jobs=3, kill_reward=-3, sabotage_reward=1, end_of_game_reward=7,
+                                         time_step_reward=-1, shuffle_imposter_index=True), n=9),
+}
+
+
+def make_pair(pkg, oracle_mod, name, B, seed, env_id_base=0, **envkw):
+    spec = CONFIGS[name]
+    kw = dict(spec["kw"])
+    walls = kw.pop("include_walls", True)
+    grid = pkg.four_room_grid(spec["n"], walls)
+    cls = {"itg": pkg.BatchedImposterTrainingGround, "base": pkg.BatchedFourRoomEnv, "tagging": pkg.BatchedFourRoomEnvWithTagging}[spec["cls"]]
+    env = cls(**kw, grid=grid, batch=B, rng="philox", seed=seed, env_id_base=env_id_base, **envkw)
+    okw = dict(kw)
+    if spec["cls"] == "itg":
+        okw.setdefault("shuffle_imposter_index", False)
+    ob = oracle_mod.OracleBatch(oracle_mod.make_config(spec["cls"], grid=grid.astype(np.uint8), **okw), B)
+    ob.set_philox(seed, env_id_base, 0)
+    return env, ob
+
+
+def compare_full_state(env, ob, tag):
+    e = ob.export()
+    np.testing.assert_array_equal(np_(env.agent_positions), e["pos"], err_msg=tag + " pos")
+    np.testing.assert_array_equal(np_(env.alive_agents), e["alive"].astype(bool), err_msg=tag + " alive")
+    np.testing.assert_array_equal(np_(env.imposter_mask), e["imp"].astype(bool), err_msg=tag + " imp")
+    if env.n_jobs:
+        np.testing.assert_array_equal(np_(env.job_positions), e["jobpos"], err_msg=tag + " jobpos")
+        np.testing.assert_array_equal(np_(env.completed_jobs), e["jobdone"].astype(bool), err_msg=tag + " jobdone")
+    np.testing.assert_array_equal(np_(env.t), e["t"], err_msg=tag + " t")
+    np.testing.assert_array_equal(np_(env.rng_cursor()).astype(np.uint64), e["cursor"], err_msg=tag + " cursor")
+    if env.VARIANT == 2:
+        np.testing.assert_array_equal(np_(env.used_tag_actions), e["used"].astype(bool), err_msg=tag + " used")
+        np.testing.assert_array_equal(np_(env.tag_counts), e["counts"], err_msg=tag + " counts")
+        np.testing.assert_array_equal(np_(env._timer), e["timer"], err_msg=tag + " timer")
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_hip_matches_oracle_philox_autoreset(pkg, oracle_mod, name):
+    B, steps, seed = 2048 + 37, 150, 77
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, env_id_base=10_000_000_000, auto_reset=True, check_errors=False)
+    env.reset()
+    ob.reset()
+    compare_full_state(env, ob, f"{name} reset")
+    episodes = 0
+    for s in range(steps):
+        a = env.sample_actions().clone()
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(np_(a), oa, err_msg=f"{name} sample_actions step {s}")
+        _, rew, done, trunc, _ = env.step(a)
+        orew, odone, otrunc, rc = ob.step(oa)
+        assert rc == 0
+        got = np_(rew).astype(np.float64)
+        assert np.array_equal(got.view(np.uint64), orew.view(np.uint64)), f"{name} rewards step {s}"
+        np.testing.assert_array_equal(np_(done), odone.astype(bool), err_msg=f"{name} done step {s}")
+        np.testing.assert_array_equal(np_(trunc), otrunc.astype(bool), err_msg=f"{name} trunc step {s}")
+        # info of the terminal step stays readable until the next step (lazy metric reset)
+        np.testing.assert_array_equal(np_(env._metrics), ob.export()["metrics"], err_msg=f"{name} metrics step {s}")
+        ended = (odone | otrunc).astype(bool)
+        episodes += int(ended.sum())
+        ob.reset(mask=ended)
+        if s % 10 == 0 or s == steps - 1:
+            compare_full_state(env, ob, f"{name} step {s}")
+    env.poll_errors()
+    life = np_(env.lifetime_totals())
+    assert life[0] == episodes, "lifetime episode count"
+
+
+def test_sharding_is_invisible(pkg, oracle_mod):
+    """Env b of a shard with env_id_base = k behaves exactly as env k + b of one big batch."""
+    name, B, seed = "base_2v6_j4_14", 1024, 5
+    big, _ = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+    lo, _ = make_pair(pkg, oracle_mod, name, B // 2, seed, env_id_base=0, auto_reset=True, check_errors=False)
+    hi, _ = make_pair(pkg, oracle_mod, name, B // 2, seed, env_id_base=B // 2, auto_reset=True, check_errors=False)
+    for e in (big, lo, hi):
+        e.reset()
+    for s in range(60):
+        outs = []
+        for e in (big, lo, hi):
+            a = e.sample_actions().clone()
+            _, rew, done, trunc, _ = e.step(a)
+            outs.append((np_(a), np_(rew), np_(done), np_(trunc), np_(e.agent_positions)))
+        for k in range(5):
+            np.testing.assert_array_equal(outs[0][k], np.concatenate([outs[1][k], outs[2][k]]), err_msg=f"step {s} field {k}")
+    tot = np_(big.lifetime_totals())
+    np.testing.assert_array_equal(tot, np_(lo.lifetime_totals()) + np_(hi.lifetime_totals()))
+
+
+@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5"])
+def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
+    B, T, seed = 1000, 120, 9
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+    env.reset()
+    ob.reset()
+    traj = env.rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    torch.cuda.synchronize()
+    acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
+    for s in range(T):
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(acts[s].T, oa, err_msg=f"{name} actions tick {s}")
+        orew, odone, otrunc, rc = ob.step(oa)
+        assert np.array_equal(rews[s].T.astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
+        np.testing.assert_array_equal(dones[s], odone.astype(bool))
+        np.testing.assert_array_equal(truncs[s], otrunc.astype(bool))
+        ob.reset(mask=(odone | otrunc).astype(bool))
+        np.testing.assert_array_equal(obs[s], ob.obs_raw().astype(np.uint8), err_msg=f"{name} raw obs tick {s}")
+    env._export(full=True)
+    compare_full_state(env, ob, f"{name} after rollout")
+    # a second launch continues the same streams
+    traj2 = env.rollout(7)
+    for s in range(7):
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(np_(traj2["actions"])[s].T, oa)
+        orew, odone, otrunc, _ = ob.step(oa)
+        ob.reset(mask=(odone | otrunc).astype(bool))
+
+
+# ------------------------------------------------------------------------------------------------
+# observations
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v5_j3"])
+def test_observations_match_oracle(pkg, oracle_mod, name):
+    B, seed = 777, 3
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+    env.reset()
+    ob.reset()
+    one_imp = env.n_imposters == 1
+    comps = ["onehot_pos", "coord_pos", "alive_crew", "walls3x3", "dist_to_imp"]
+    if one_imp:
+        comps += ["l1_crew", "closest_crew"]
+    if env.n_rows == 9:
+        comps += ["room_loc"]
+    for s in range(40):
+        a = env.sample_actions().clone()
+        env.step(a)
+        orew, odone, otrunc, _ = ob.step(ob.sample_actions())
+        ob.reset(mask=(odone | otrunc).astype(bool))
+        if s % 8 == 0:
+            np.testing.assert_array_equal(np_(env.observe(pkg.ObsConfig("raw"))), ob.obs_raw().astype(np.float32))
+            if env.VARIANT != 2:  # the reference featurizers do not run on the tagging env
+                got = np_(env.observe(pkg.ObsConfig("flat", comps)))
+                want = ob.obs_flat(comps)
+                assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist(), f"{name} flat step {s}"
+                i8 = np_(env.observe(pkg.ObsConfig("flat", comps, dtype=torch.int8)))
+                np.testing.assert_array_equal(i8.astype(np.float32), want)
+            sp, non = env.observe(pkg.ObsConfig("planes"))
+            wsp, wnon = ob.obs_planes()
+            np.testing.assert_array_equal(np_(sp), wsp)
+            np.testing.assert_array_equal(np_(non), wnon)
+
+
+def test_observations_match_reference_feature_fixtures(pkg):
+    """Directly against golden vectors produced by the reference featurizers (states injected)."""
+    import glob
+    import os
+
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "feat_*.npz"))):
+        g = load_golden(path)
+        meta = g["meta"]
+        S = len(g["pos"])
+        env = env_from_meta(pkg, meta, S, rng="philox")
+        env.reset()
+        kw = dict(agent_positions=g["pos"], alive_agents=g["alive"], imposter_mask=g["imp"])
+        if env.n_jobs:
+            kw.update(job_positions=g["jobpos"], completed_jobs=g["jobdone"])
+        env.set_state(**kw)
+        np.testing.assert_array_equal(np_(env.observe(pkg.ObsConfig("raw"))), g["raw"].astype(np.float32))
+        comps = [c for c in meta["flat"] if c != "scent"]
+        got = np_(env.observe(pkg.ObsConfig("flat", comps)))
+        want = np.concatenate([g["flat_" + c] for c in comps], axis=1)
+        assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist(), g["name"]
+        if "planes_spatial" in g:
+            sp, non = env.observe(pkg.ObsConfig("planes"))
+            np.testing.assert_array_equal(np_(sp), g["planes_spatial"])
+            np.testing.assert_array_equal(np_(non), g["planes_non_spatial"])
+
+
+# ------------------------------------------------------------------------------------------------
+# error behaviour (reference: AssertionError base.py:357-362, IndexError base.py:379-382)
+# ------------------------------------------------------------------------------------------------
+def test_error_types_match_reference(pkg):
+    env = pkg.BatchedFourRoomEnv(1, 2, 2, batch=4, shuffle_imposter_index=False)
+    env.reset()
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros(4, 2, dtype=torch.int64))  # wrong number of actions
+    bad = torch.zeros(4, 3, dtype=torch.int64)
+    bad[2, 1] = 8  # >= action_space.n
+    with pytest.raises(AssertionError):
+        env.step(bad)
+    bad[2, 1] = 6  # crew member has only 6 actions (0..5): IndexError in the reference
+    with pytest.raises(IndexError):
+        env.step(bad)
+    bad[2, 1] = 5
+    env.step(bad)  # fine again
+    with pytest.raises(AssertionError):
+        pkg.BatchedFourRoomEnv(2, 2, 1, batch=1)  # base.py:247-249
+    pkg.BatchedImposterTrainingGround(1, 0, 0, -3, 0, 0, batch=1)  # 1v1 allowed (pred_prey.py:75-76)
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties at BASELINE.json's batch (size-independent invariants)
+# ------------------------------------------------------------------------------------------------
+def test_full_batch_invariants(pkg):
+    B, T = 65536, 64
+    env = pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, grid_size=14, auto_reset=True, seed=123, check_errors=False)
+    env.reset()
+    grid = torch.as_tensor(env.grid, device=env.device)
+    jobs0 = env.job_positions.clone()
+    traj = env.rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    env._export(full=True)
+    torch.cuda.synchronize()
+    obs = traj["obs"].long()  # [T, B, 3A+3J]
+    A, J = 3, 4
+    xy = obs[..., : 2 * A].reshape(T, B, A, 2)
+    assert int(xy.min()) >= 0 and int(xy.max()) < 14
+    # agents that MOVED this tick stand on a cell that is free under the transposed lookup (base.py:551)
+    moved = (xy[1:] != xy[:-1]).any(-1) & ~(traj["done"][1:] | traj["truncated"][1:])[..., None]  # obs[s] is post-auto-reset
+    assert bool(grid[xy[1:][..., 1], xy[1:][..., 0]][moved].all())
+    # a move changes exactly one coordinate by one
+    d = (xy[1:] - xy[:-1]).abs().sum(-1)
+    assert int(d[moved].max()) == 1
+    # rewards of a 1v2 default game are integers from the finite reward table
+    vals = set(torch.unique(traj["rewards"]).tolist())
+    assert vals <= {0.0, -5.0, 5.0, 3.0, -3.0, 10.0, -10.0, -2.0, 13.0, -13.0, 7.0, -7.0, 15.0, -15.0, 5.0, 8.0, -8.0}, vals
+    # job cells are pairwise distinct after every reset
+    jp = env.job_positions.long()
+    code = jp[..., 0] * 16 + jp[..., 1]
+    assert bool((code.sort(-1).values.diff(dim=-1) != 0).all())
+    life = env.lifetime_totals().tolist()
+    ended = int((traj["done"] | traj["truncated"]).sum())
+    assert life[0] == ended and life[1] + life[2] + life[3] >= ended
+    # determinism: same seed, same trajectory
+    env2 = pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, grid_size=14, auto_reset=True, seed=123, check_errors=False)
+    env2.reset()
+    traj2 = env2.rollout(T)
+    assert torch.equal(traj2["actions"], traj["actions"]) and torch.equal(traj2["rewards"], traj["rewards"])
+    assert not torch.equal(jobs0, env.job_positions)  # episodes did end and respawn
