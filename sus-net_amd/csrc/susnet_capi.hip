@@ -63,13 +63,6 @@ __device__ __forceinline__ void store_action(void *p, int dtype, int64_t k, uint
     else reinterpret_cast<int64_t *>(p)[k] = (int64_t)a;
 }
 
-__device__ __forceinline__ void load_grid(const Consts &c, const Lds &L, int tid) {
-    if (tid < SUSNET_MAX_GRID) L.grid[tid] = c.grid_rows[tid];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 template <class RNG>
 __device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG &rng) {
     s.rng[b] = rng.cur;
@@ -78,126 +71,148 @@ __device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG 
 
 template <class RNG>
 __global__ __launch_bounds__(kBlock) void k_reset(Consts c, State s, const uint8_t *mask, ObsArgs o) {
+    using S = GenericSpec;
     extern __shared__ uint32_t smem[];
-    Lds L = carve_lds(smem, c.A, c.J);
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
     const bool active = b < c.B;
-    load_grid(c, L, tid);
+    LdsStore st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
     Env e = {};
     if (active) {
-        load_env(c, s, L, tid, (int)b, e);
+        load_env<S>(c, s, st, b, e);
         if (!mask || mask[b]) {
             RNG rng = make_rng<RNG>(c, s, b);
-            reset_env(c, L, tid, e, rng);
+            reset_env<S>(c, T, st, tid, e, rng);
             zero_metrics(e); // metrics.reset(), base.py:270
-            store_env(c, s, L, tid, (int)b, e, true);
+            store_env<S>(c, s, st, b, e, true);
             finish_rng(s, b, rng);
         }
     }
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
-    write_obs(c, o, L, tid, e, active, b0, nrows, 0);
+    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
 
 template <class RNG>
 __global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out, int32_t dtype, int64_t sa, int64_t sb) {
+    using S = GenericSpec;
     extern __shared__ uint32_t smem[];
-    Lds L = carve_lds(smem, c.A, c.J);
     const int tid = threadIdx.x;
     const int64_t b = (int64_t)blockIdx.x * kBlock + tid;
+    LdsStore st;
+    setup_lds<S>(c, smem, tid, st);
     if (b >= c.B) return;
     Env e = {};
-    load_env(c, s, L, tid, (int)b, e);
+    load_env<S>(c, s, st, b, e);
     RNG rng = make_rng<RNG>(c, s, b);
-    sample_actions_env(c, L, tid, e, rng);
-    for (int i = 0; i < c.A; i++) store_action(out, dtype, (int64_t)i * sa + b * sb, L.act[i * kBlock + tid]);
+    sample_actions_env<S>(c, st, e, rng);
+    for (int i = 0; i < c.A; i++) store_action(out, dtype, (int64_t)i * sa + b * sb, st.act(i));
     finish_rng(s, b, rng);
 }
 
-template <class RNG>
+template <class RNG, class S>
 __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
-    Lds L = carve_lds(smem, c.A, c.J);
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
     const bool active = b < c.B;
-    load_grid(c, L, tid);
+    typename StoreFor<S>::type st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
     Env e = {};
     if (active) {
-        load_env(c, s, L, tid, (int)b, e);
-        for (int i = 0; i < c.A; i++) L.act[i * kBlock + tid] = load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb);
+        const int A = S::A(c);
+        load_env<S>(c, s, st, b, e);
+#pragma unroll
+        for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
         RNG rng = make_rng<RNG>(c, s, b);
         bool done, trunc;
-        uint32_t bits = step_env(c, L, tid, e, rng, a.rewards, b, done, trunc);
+        uint32_t bits = step_env<S, true>(c, T, st, e, rng, a.rewards, b, done, trunc);
         if (bits) atomicOr(s.err, bits);
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
         bool jobs_changed = false;
         if (c.auto_reset && (done || trunc)) {
-            accumulate_lifetime(c, s, (int)b, e, trunc);
-            reset_env(c, L, tid, e, rng);
+            accumulate_lifetime(c, s, b, e, trunc);
+            reset_env<S>(c, T, st, tid, e, rng);
             e.flags |= FLAG_FRESH; // info counters stay readable until the next step
             jobs_changed = true;
         }
-        store_env(c, s, L, tid, (int)b, e, jobs_changed);
+        store_env<S>(c, s, st, b, e, jobs_changed);
         finish_rng(s, b, rng);
     }
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
-    write_obs(c, o, L, tid, e, active, b0, nrows, 0);
+    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
 
 // Fused random rollout: n_ticks x {sample_actions; step; auto-reset} with the state held on chip.
+template <class S>
 __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
-    Lds L = carve_lds(smem, c.A, c.J);
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
     const bool active = b < c.B;
     const int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
-    load_grid(c, L, tid);
+    const int A = S::A(c);
+    typename StoreFor<S>::type st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
     Env e = {};
     PhiloxRng rng;
     rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
     if (active) {
-        load_env(c, s, L, tid, (int)b, e);
+        load_env<S>(c, s, st, b, e);
         rng.cur = s.rng[b];
     }
-    const int64_t AB = (int64_t)c.A * c.B;
+    const int64_t AB = (int64_t)A * c.B;
     for (int tick = 0; tick < a.n_ticks; tick++) {
         if (active) {
-            sample_actions_env(c, L, tid, e, rng);
-            if (a.actions)
-                for (int i = 0; i < c.A; i++) a.actions[tick * AB + (int64_t)i * c.B + b] = (uint8_t)L.act[i * kBlock + tid];
+            sample_actions_env<S>(c, st, e, rng);
+            if (a.actions) {
+#pragma unroll
+                for (int i = 0; i < A; i++) a.actions[tick * AB + (int64_t)i * c.B + b] = (uint8_t)st.act(i);
+            }
             RewardSink sink{a.rewards ? (void *)(a.rewards + tick * AB) : nullptr, (int64_t)c.B, 1, 0};
             bool done, trunc;
-            step_env(c, L, tid, e, rng, sink, b, done, trunc);
+            step_env<S, false>(c, T, st, e, rng, sink, b, done, trunc);
             if (a.done) a.done[(int64_t)tick * c.B + b] = done ? 1 : 0;
             if (a.trunc) a.trunc[(int64_t)tick * c.B + b] = trunc ? 1 : 0;
             if (done || trunc) {
-                accumulate_lifetime(c, s, (int)b, e, trunc);
-                reset_env(c, L, tid, e, rng);
+                accumulate_lifetime(c, s, b, e, trunc);
+                reset_env<S>(c, T, st, tid, e, rng);
                 e.flags |= FLAG_FRESH;
             }
         }
-        write_obs(c, o, L, tid, e, active, b0, nrows, tick);
+        write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
     }
     if (active) {
-        store_env(c, s, L, tid, (int)b, e, true);
+        store_env<S>(c, s, st, b, e, true);
         s.rng[b] = rng.cur;
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o) {
+    using S = GenericSpec;
     extern __shared__ uint32_t smem[];
-    Lds L = carve_lds(smem, c.A, c.J);
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
     const bool active = b < c.B;
-    load_grid(c, L, tid);
+    LdsStore st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
     Env e = {};
-    if (active) load_env(c, s, L, tid, (int)b, e);
+    if (active) load_env<S>(c, s, st, b, e);
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
-    write_obs(c, o, L, tid, e, active, b0, nrows, 0);
+    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
+}
+
+// configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
+using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0>;  // ImposterTrainingGround 1v1, no jobs
+using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
+using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
+
+static int pick_spec(const Consts &c) {
+    if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return 2;
+    if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
+    if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
+    return 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_export(Consts c, State s, susnet_state_view v) {
@@ -377,7 +392,7 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     for (int i = 0; i < N; i++) {
         c.grid_rows[i] = cfg->grid_rows[i] & ((1u << N) - 1u);
         for (int j = 0; j < N; j++)
-            if ((cfg->grid_rows[i] >> j) & 1u) c.valid_xy[c.n_valid++] = (uint8_t)(i | (j << 4)); // argwhere order; x = i, y = j
+            if ((cfg->grid_rows[i] >> j) & 1u) reinterpret_cast<uint8_t *>(c.valid_xy)[c.n_valid++] = (uint8_t)(i | (j << 4)); // argwhere order; x = i, y = j
     }
     if (c.n_valid < 1 || c.n_valid < J) {
         delete e;
@@ -480,6 +495,9 @@ extern "C" int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void
 }
 
 // observation plumbing -----------------------------------------------------------------------------
+// packed LDS image of `elements` elements of `bits` bits each, in words, rounded to 16 bytes
+static inline int img_words(int elements, int bits) { return (int)(((size_t)elements * bits + 127) / 128 * 4); }
+
 static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs &o, int64_t ticks_batch) {
     std::memset(&o, 0, sizeof(o));
     if (!spec || spec->mode == SUSNET_OBS_NONE) return SUSNET_OK;
@@ -491,7 +509,7 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
     o.out2 = spec->out2;
     if (spec->mode == SUSNET_OBS_RAW) {
         o.F = env->layout.obs_raw_size;
-        o.words1 = odd_words((o.F + 3) / 4);
+        o.words1 = img_words(kBlock * o.F, 8);
     } else if (spec->mode == SUSNET_OBS_FLAT) {
         if (spec->n_components < 1 || spec->n_components > 16) return fail(SUSNET_E_INVALID, "1..16 flat components");
         o.ncomp = spec->n_components;
@@ -507,12 +525,12 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
             F += sz;
         }
         o.F = F;
-        o.words1 = odd_words((F + 3) / 4);
+        o.words1 = img_words(kBlock * F, 8);
     } else if (spec->mode == SUSNET_OBS_PLANES) {
         o.F = (c.A + 2) * c.N * c.N;
         o.F2 = c.A + c.J + (c.variant == SUSNET_VARIANT_TAGGING ? c.A : 0);
-        o.words1 = odd_words((o.F + 31) / 32);
-        o.words2 = odd_words((o.F2 + 3) / 4);
+        o.words1 = img_words(kBlock * o.F, 1);
+        o.words2 = img_words(kBlock * o.F2, 8);
     } else {
         return fail(SUSNET_E_INVALID, "unknown obs mode");
     }
@@ -523,11 +541,11 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
     return SUSNET_OK;
 }
 
-static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset) {
+static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset, bool generic = true) {
     const Consts &c = env->c;
-    size_t core = (size_t)lds_core_words(c.A, c.J) * 4;
+    size_t core = (size_t)lds_core_words(c.A, c.J, generic) * 4;
     size_t perm = (may_reset && env->cfg.rng_mode == SUSNET_RNG_TAPE) ? (size_t)c.n_valid * kBlock : 0;
-    size_t stage = (size_t)kBlock * (o.words1 + o.words2) * 4;
+    size_t stage = (size_t)(o.words1 + o.words2) * 4;
     return core + (perm > stage ? perm : stage);
 }
 
@@ -607,13 +625,16 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     a.trunc = io->truncated;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
-    size_t sh = lds_bytes(env, o, env->c.auto_reset != 0);
-    CHECK_LDS(sh);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (env->cfg.rng_mode == SUSNET_RNG_TAPE)
-        hipLaunchKernelGGL(k_step<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, a, o);
-    else
-        hipLaunchKernelGGL(k_step<PhiloxRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, a, o);
+    const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c) : 0;
+    size_t sh = lds_bytes(env, o, env->c.auto_reset != 0, spec == 0);
+    CHECK_LDS(sh);
+    const dim3 g = grid_for(env), blk(kBlock);
+    if (env->cfg.rng_mode == SUSNET_RNG_TAPE) hipLaunchKernelGGL((k_step<TapeRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
+    else if (spec == 2) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg2>), g, blk, sh, st, env->c, env->s, a, o);
+    else if (spec == 3) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
+    else if (spec == 4) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
+    else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }
@@ -630,9 +651,15 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     a.trunc = io->truncated;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
-    size_t sh = lds_bytes(env, o, true);
+    const int spec = pick_spec(env->c);
+    size_t sh = lds_bytes(env, o, true, spec == 0);
     CHECK_LDS(sh);
-    hipLaunchKernelGGL(k_rollout, grid_for(env), dim3(kBlock), sh, static_cast<hipStream_t>(stream), env->c, env->s, a, o);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 g = grid_for(env), blk(kBlock);
+    if (spec == 2) hipLaunchKernelGGL((k_rollout<SpecCfg2>), g, blk, sh, st, env->c, env->s, a, o);
+    else if (spec == 3) hipLaunchKernelGGL((k_rollout<SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
+    else if (spec == 4) hipLaunchKernelGGL((k_rollout<SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
+    else hipLaunchKernelGGL((k_rollout<GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }

@@ -10,15 +10,20 @@
 //   info counters    src/metrics.py:35-64
 //
 // Execution model: a workgroup is ONE 64-lane wavefront (64 environments).  Per-lane scalars (alive /
-// imposter / tag-used / job-done bitmasks, t, counters) live in VGPRs; everything that is indexed by a
-// data-dependent agent or job number (positions, tag counts, actions, the wall map, the spawn
-// permutation) lives in LDS, laid out [index][lane] so that a lane-varying index is a conflict-free
-// ds_read_b32.  No barriers: a lane only touches its own column, except the cooperative observation
-// writer, and LDS operations of one wave complete in order.
+// imposter / tag-used / job-done bitmasks, t, counters) live in VGPRs.  The per-agent table (cell, tag
+// count, action) and the job cells come in two storage flavours behind one interface:
+//   LdsStore        [index][lane] columns in LDS: any agent/job count, a lane-varying index is one
+//                   conflict-free ds_read_b32 (generic kernels);
+//   RegStore<A, J>  VGPR arrays for configurations compiled in (Spec<...>): loops unroll, indices become
+//                   register names, a data-dependent index is a short select chain.
+// The wall map and the spawn-cell table are wave-shared LDS tables.  No barriers: a lane only touches its
+// own column, except the cooperative observation writer, and LDS operations of one wave complete in order.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/susnet.h"
 
@@ -49,7 +54,7 @@ struct Consts {
     int32_t max_t, order_random, shuffle_imp, tag_interval;
     int32_t n_valid, auto_reset, nr_imp, nr_crew; // nr_* = length of the role part of agent_action_map
     uint32_t grid_rows[SUSNET_MAX_GRID];          // bit j of row i = grid[i][j]
-    uint8_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID]; // np.argwhere(grid) order; x | y << 4
+    uint32_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID / 4]; // np.argwhere(grid) order; bytes x | y << 4
     double r_kill, r_fix, r_sab, r_tsr, r_end, r_dead, r_vote;
     uint64_t seed, env_id_base;
 };
@@ -72,6 +77,21 @@ struct State {
     const uint32_t *tape; // TAPE mode: [B][tape_len]
     int64_t tape_len;
 };
+
+// Compile-time specialisation of a configuration; -1 = read the value from Consts at run time.
+template <int A_, int J_, int VAR_, int ORD_>
+struct Spec {
+    static constexpr bool kGeneric = A_ < 0;
+    static constexpr int kA = A_, kJ = J_;
+    __device__ static __forceinline__ int A(const Consts &c) { return A_ >= 0 ? A_ : c.A; }
+    __device__ static __forceinline__ int J(const Consts &c) { return J_ >= 0 ? J_ : c.J; }
+    __device__ static __forceinline__ int variant(const Consts &c) { return VAR_ >= 0 ? VAR_ : c.variant; }
+    __device__ static __forceinline__ bool order_random(const Consts &c) { return ORD_ >= 0 ? (ORD_ != 0) : (c.order_random != 0); }
+    __device__ static __forceinline__ bool tagging(const Consts &c) { return variant(c) == SUSNET_VARIANT_TAGGING; }
+    __device__ static __forceinline__ uint32_t nr_imp(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 6u : 7u) : (uint32_t)c.nr_imp; }
+    __device__ static __forceinline__ uint32_t nr_crew(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 5u : 6u) : (uint32_t)c.nr_crew; }
+};
+using GenericSpec = Spec<-1, -1, -1, -1>;
 
 // ---------------------------------------------------------------------------------------------------
 // word sources
@@ -96,10 +116,9 @@ struct PhiloxRng {
         uint32_t a = k0, d = k1;
 #pragma unroll
         for (int r = 0; r < 10; r++) {
-            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-            uint32_t n0 = h1 ^ c1 ^ a, n2 = h0 ^ c3 ^ d;
-            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+            uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ d;
+            c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
             a += 0x9E3779B9u; d += 0xBB67AE85u;
         }
         w0 = c0; w1 = c1; w2 = c2; w3 = c3;
@@ -150,29 +169,89 @@ struct TapeRng {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// per-wave LDS view (dynamic shared memory, carved by the kernel)
+// wave-shared LDS tables + per-lane storage
 // ---------------------------------------------------------------------------------------------------
-struct Lds {
-    uint32_t *grid; // [16] wall map rows
-    uint32_t *xy;   // [A][64]  x | y << 4 | tag_count << 8
-    uint32_t *job;  // [J][64]  x | y << 4
-    uint32_t *act;  // [A][64]  role-relative action index
-    uint8_t *perm;  // [n_valid][64] spawn permutation (TAPE resets only)
-    uint32_t *stage; // observation staging
+struct Tables {
+    const uint32_t *grid;  // [16] wall map rows
+    const uint8_t *valid;  // [256] spawn cells, x | y << 4
+    uint8_t *perm;         // [n_valid][64] spawn permutation (TAPE resets only)
+    uint32_t *stage;       // observation staging
 };
 
-__host__ __device__ inline uint32_t lds_core_words(int A, int J) { return 16u + (uint32_t)(2 * A + J) * kBlock; }
+constexpr uint32_t kTableWords = 16 + 64; // grid + valid
 
-__device__ __forceinline__ Lds carve_lds(uint32_t *base, int A, int J) {
-    Lds L;
-    L.grid = base;
-    L.xy = base + 16;
-    L.job = L.xy + A * kBlock;
-    L.act = L.job + J * kBlock;
-    uint32_t *end = L.act + A * kBlock;
-    L.perm = reinterpret_cast<uint8_t *>(end);
-    L.stage = end;
-    return L;
+__host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic) {
+    return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u);
+}
+
+// generic flavour: [index][lane] columns in LDS (cell in bits 0-7, tag count in bits 8-15 of one word)
+struct LdsStore {
+    uint32_t *xyp, *jobp, *actp;
+    int tid;
+    __device__ __forceinline__ void init(uint32_t *base, int A, int J, int tid_) {
+        xyp = base; jobp = xyp + A * kBlock; actp = jobp + J * kBlock; tid = tid_;
+    }
+    __device__ __forceinline__ uint32_t xy(int i) const { return xyp[i * kBlock + tid] & 0xffu; }
+    __device__ __forceinline__ void set_xy(int i, uint32_t cell) { xyp[i * kBlock + tid] = (xyp[i * kBlock + tid] & ~0xffu) | cell; }
+    __device__ __forceinline__ uint32_t cnt(int i) const { return xyp[i * kBlock + tid] >> 8; }
+    __device__ __forceinline__ void set_cnt(int i, uint32_t v) { xyp[i * kBlock + tid] = (xyp[i * kBlock + tid] & 0xffu) | (v << 8); }
+    __device__ __forceinline__ void set_agent(int i, uint32_t cell, uint32_t cnt) { xyp[i * kBlock + tid] = cell | (cnt << 8); }
+    __device__ __forceinline__ uint32_t job(int j) const { return jobp[j * kBlock + tid]; }
+    __device__ __forceinline__ void set_job(int j, uint32_t w) { jobp[j * kBlock + tid] = w; }
+    __device__ __forceinline__ uint32_t act(int i) const { return actp[i * kBlock + tid]; }
+    __device__ __forceinline__ void set_act(int i, uint32_t a) { actp[i * kBlock + tid] = a; }
+};
+
+// compiled-in flavour (A, J <= 8): byte lanes of packed VGPR words -- a data-dependent index is a shift,
+// never a memory access (per-lane arrays indexed at run time would be demoted to scratch memory)
+template <int N_>
+struct PackedBytes {
+    using W = typename std::conditional<(N_ <= 4), uint32_t, uint64_t>::type;
+    W w = 0;
+    __device__ __forceinline__ uint32_t get(int i) const { return (uint32_t)(w >> (8 * i)) & 0xffu; }
+    __device__ __forceinline__ void set(int i, uint32_t v) { w = (w & ~((W)0xffu << (8 * i))) | ((W)(v & 0xffu) << (8 * i)); }
+};
+
+template <int A, int J>
+struct RegStore {
+    static_assert(A <= 8 && J <= 8, "RegStore packs at most 8 agents / jobs");
+    PackedBytes<A> xyw, actw;
+    PackedBytes<(J > 0 ? J : 1)> jobw;
+    uint32_t cntw = 0; // 4 bits per agent
+    __device__ __forceinline__ void init(uint32_t *, int, int, int) {}
+    __device__ __forceinline__ uint32_t xy(int i) const { return xyw.get(i); }
+    __device__ __forceinline__ void set_xy(int i, uint32_t cell) { xyw.set(i, cell); }
+    __device__ __forceinline__ uint32_t cnt(int i) const { return (cntw >> (4 * i)) & 15u; }
+    __device__ __forceinline__ void set_cnt(int i, uint32_t v) { cntw = (cntw & ~(15u << (4 * i))) | ((v & 15u) << (4 * i)); }
+    __device__ __forceinline__ void set_agent(int i, uint32_t cell, uint32_t c) { set_xy(i, cell); set_cnt(i, c); }
+    __device__ __forceinline__ uint32_t job(int j) const { return jobw.get(j); }
+    __device__ __forceinline__ void set_job(int j, uint32_t v) { jobw.set(j, v); }
+    __device__ __forceinline__ uint32_t act(int i) const { return actw.get(i); }
+    __device__ __forceinline__ void set_act(int i, uint32_t a) { actw.set(i, a); }
+};
+
+template <class S>
+struct StoreFor { using type = RegStore<S::kA, S::kJ>; };
+template <>
+struct StoreFor<GenericSpec> { using type = LdsStore; };
+
+// Fill the wave-shared tables (all 64 lanes take part) and carve the rest of the dynamic LDS.
+template <class S>
+__device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
+    Tables T;
+    if (tid < SUSNET_MAX_GRID) smem[tid] = c.grid_rows[tid];
+    smem[16 + tid] = c.valid_xy[tid];
+    T.grid = smem;
+    T.valid = reinterpret_cast<const uint8_t *>(smem + 16);
+    uint32_t *rest = smem + kTableWords;
+    st.init(rest, c.A, c.J, tid);
+    if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
+    T.perm = reinterpret_cast<uint8_t *>(rest);
+    T.stage = rest;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return T;
 }
 
 // per-lane register state of one environment
@@ -182,16 +261,20 @@ struct Env {
     uint32_t m_steps, m_fix, m_sab, m_kv;
 };
 
-__device__ __forceinline__ void load_env(const Consts &c, const State &s, const Lds &L, int tid, int b, Env &e) {
+template <class S, class Store>
+__device__ __forceinline__ void load_env(const Consts &c, const State &s, Store &st, int64_t b, Env &e) {
+    const int A = S::A(c), J = S::J(c);
     e.alive = e.imp = e.used = 0;
-    for (int i = 0; i < c.A; i++) {
+#pragma unroll
+    for (int i = 0; i < A; i++) {
         uint32_t w = s.agent[(size_t)i * c.Bp + b];
-        L.xy[i * kBlock + tid] = (w & 0xffu) | (((w >> 11) & 15u) << 8);
+        st.set_agent(i, w & 0xffu, (w >> 11) & 15u);
         e.alive |= ((w >> 8) & 1u) << i;
         e.imp |= ((w >> 9) & 1u) << i;
         e.used |= ((w >> 10) & 1u) << i;
     }
-    for (int j = 0; j < c.J; j++) L.job[j * kBlock + tid] = s.job[(size_t)j * c.Bp + b];
+#pragma unroll
+    for (int j = 0; j < J; j++) st.set_job(j, s.job[(size_t)j * c.Bp + b]);
     e.jd = s.jobdone[b];
     e.t = s.t[b];
     e.timer = s.timer[b];
@@ -202,15 +285,18 @@ __device__ __forceinline__ void load_env(const Consts &c, const State &s, const 
     e.m_kv = s.m_kv[b];
 }
 
-__device__ __forceinline__ void store_env(const Consts &c, const State &s, const Lds &L, int tid, int b, const Env &e,
-                                          bool store_jobs) {
-    for (int i = 0; i < c.A; i++) {
-        uint32_t w = L.xy[i * kBlock + tid];
+template <class S, class Store>
+__device__ __forceinline__ void store_env(const Consts &c, const State &s, const Store &st, int64_t b, const Env &e, bool store_jobs) {
+    const int A = S::A(c), J = S::J(c);
+#pragma unroll
+    for (int i = 0; i < A; i++) {
         s.agent[(size_t)i * c.Bp + b] =
-            (uint16_t)pack_agent(w, (e.alive >> i) & 1u, (e.imp >> i) & 1u, (e.used >> i) & 1u, (w >> 8) & 15u);
+            (uint16_t)pack_agent(st.xy(i), (e.alive >> i) & 1u, (e.imp >> i) & 1u, (e.used >> i) & 1u, st.cnt(i));
     }
-    if (store_jobs)
-        for (int j = 0; j < c.J; j++) s.job[(size_t)j * c.Bp + b] = (uint8_t)L.job[j * kBlock + tid];
+    if (store_jobs) {
+#pragma unroll
+        for (int j = 0; j < J; j++) s.job[(size_t)j * c.Bp + b] = (uint8_t)st.job(j);
+    }
     s.jobdone[b] = (uint16_t)e.jd;
     s.t[b] = (uint16_t)e.t;
     s.timer[b] = (uint16_t)e.timer;
@@ -234,21 +320,25 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, uint32_t r) {
 // np.random.shuffle / permutation on a nibble-packed list (base.py:374): i = n-1 .. 1, j in [0, i]
 template <class RNG>
 __device__ __forceinline__ void shuffle_nibbles(RNG &rng, uint64_t &v, int n) {
+#pragma unroll
     for (int i = n - 1; i >= 1; i--) {
         int j = (int)rng.bounded((uint32_t)i + 1u);
         nibble_swap(v, i, j);
     }
 }
 
-__device__ __forceinline__ uint32_t n_role_actions(const Consts &c, uint32_t is_imp) { return is_imp ? c.nr_imp : c.nr_crew; }
+template <class S>
+__device__ __forceinline__ uint32_t n_role_actions(const Consts &c, uint32_t is_imp) { return is_imp ? S::nr_imp(c) : S::nr_crew(c); }
+template <class S>
 __device__ __forceinline__ uint32_t n_actions(const Consts &c, uint32_t is_imp) {
-    return n_role_actions(c, is_imp) + (c.variant == SUSNET_VARIANT_TAGGING ? (uint32_t)(c.A - 1) : 0u);
+    return n_role_actions<S>(c, is_imp) + (S::tagging(c) ? (uint32_t)(S::A(c) - 1) : 0u);
 }
 
 // role-relative index -> Action (base.py:82-99; pred_prey.py:4-19); caller guarantees idx < role count
+template <class S>
 __device__ __forceinline__ int role_action(const Consts &c, uint32_t is_imp, uint32_t idx) {
     if (idx <= 4u) return (int)idx;
-    if (c.variant == SUSNET_VARIANT_ITG) return ACT_KILL;      // imposter idx 5
+    if (S::variant(c) == SUSNET_VARIANT_ITG) return ACT_KILL;  // imposter idx 5
     if (is_imp) return idx == 5u ? ACT_SABOTAGE : ACT_KILL;    // imposter idx 5, 6
     return ACT_FIX;                                            // crew idx 5
 }
@@ -258,9 +348,9 @@ __device__ __forceinline__ int role_action(const Consts &c, uint32_t is_imp, uin
 //   TAPE   : numpy semantics incl. the FULL permutation of the valid cells (drawn even when J == 0)
 //   PHILOX : same distributions by sequential rejection of duplicates (n_imp + A + J draws, +rare retries)
 // ---------------------------------------------------------------------------------------------------
-template <class RNG>
-__device__ __forceinline__ void reset_env(const Consts &c, const Lds &L, int tid, Env &e, RNG &rng) {
-    const int A = c.A, J = c.J;
+template <class S, class RNG, class Store>
+__device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Store &st, int tid, Env &e, RNG &rng) {
+    const int A = S::A(c), J = S::J(c);
     rng.align();
     if (c.shuffle_imp) {
         if (RNG::kNumpy) {
@@ -279,31 +369,34 @@ __device__ __forceinline__ void reset_env(const Consts &c, const Lds &L, int tid
     } else {
         e.imp = (1u << c.n_imp) - 1u; // np.arange(n_imposters), base.py:278
     }
+#pragma unroll
     for (int i = 0; i < A; i++) { // base.py:288-291, with replacement
         uint32_t cell = rng.bounded((uint32_t)c.n_valid);
-        L.xy[i * kBlock + tid] = c.valid_xy[cell]; // tag count bits cleared
+        st.set_agent(i, T.valid[cell], 0u); // tagging.py:64: counts cleared
     }
     if (RNG::kNumpy) {
         // base.py:295-299: permutation(n_valid)[:J]
         const int n = c.n_valid;
-        for (int k = 0; k < n; k++) L.perm[k * kBlock + tid] = (uint8_t)k;
+        for (int k = 0; k < n; k++) T.perm[k * kBlock + tid] = (uint8_t)k;
         for (int i = n - 1; i >= 1; i--) {
             int j = (int)rng.bounded((uint32_t)i + 1u);
-            uint8_t a = L.perm[i * kBlock + tid], b2 = L.perm[j * kBlock + tid];
-            L.perm[i * kBlock + tid] = b2;
-            L.perm[j * kBlock + tid] = a;
+            uint8_t a = T.perm[i * kBlock + tid], b2 = T.perm[j * kBlock + tid];
+            T.perm[i * kBlock + tid] = b2;
+            T.perm[j * kBlock + tid] = a;
         }
-        for (int j = 0; j < J; j++) L.job[j * kBlock + tid] = c.valid_xy[L.perm[j * kBlock + tid]];
+        for (int j = 0; j < J; j++) st.set_job(j, T.valid[T.perm[j * kBlock + tid]]);
     } else {
+#pragma unroll
         for (int j = 0; j < J; j++) {
             uint32_t xy;
             bool dup;
             do {
-                xy = c.valid_xy[rng.bounded((uint32_t)c.n_valid)];
+                xy = T.valid[rng.bounded((uint32_t)c.n_valid)];
                 dup = false;
-                for (int k = 0; k < j; k++) dup |= (L.job[k * kBlock + tid] == xy);
+#pragma unroll
+                for (int k = 0; k < J; k++) dup |= (k < j) && (st.job(k) == xy);
             } while (dup);
-            L.job[j * kBlock + tid] = xy;
+            st.set_job(j, xy);
         }
     }
     e.alive = (1u << A) - 1u; // base.py:301
@@ -319,10 +412,12 @@ __device__ __forceinline__ void zero_metrics(Env &e) {
 }
 
 // base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order
-template <class RNG>
-__device__ __forceinline__ void sample_actions_env(const Consts &c, const Lds &L, int tid, const Env &e, RNG &rng) {
+template <class S, class RNG, class Store>
+__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, RNG &rng) {
+    const int A = S::A(c);
     rng.align();
-    for (int i = 0; i < c.A; i++) L.act[i * kBlock + tid] = rng.bounded(n_actions(c, (e.imp >> i) & 1u));
+#pragma unroll
+    for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (e.imp >> i) & 1u)));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -340,22 +435,24 @@ struct RewardSink {
     }
 };
 
-// returns error bits (0 = stepped).  Actions are read from L.act; rewards go to `sink` at env index b.
-template <class RNG>
-__device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int tid, Env &e, RNG &rng, const RewardSink &sink,
+__device__ __forceinline__ void set_code(uint32_t &rc, int idx, uint32_t code) { rc = (rc & ~(3u << (2 * idx))) | (code << (2 * idx)); }
+
+// returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
+template <class S, bool VALIDATE, class RNG, class Store>
+__device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const RewardSink &sink,
                                              int64_t b, bool &done, bool &trunc) {
-    const int A = c.A, J = c.J;
-    const bool tagging = c.variant == SUSNET_VARIANT_TAGGING;
+    const int A = S::A(c), J = S::J(c);
+    const bool tagging = S::tagging(c);
     done = false;
     trunc = false;
-    // base.py:357-362 / 379-382: validate before touching anything
-    {
+    if (VALIDATE) { // base.py:357-362 / 379-382: validate before touching anything
         uint32_t space_n = 8u + (tagging ? (uint32_t)A : 0u);
         uint32_t bits = 0;
+#pragma unroll
         for (int i = 0; i < A; i++) {
-            int32_t a = (int32_t)L.act[i * kBlock + tid];
+            int32_t a = (int32_t)st.act(i);
             if (a >= (int32_t)space_n) bits |= SUSNET_ERRBIT_ASSERT;
-            else if (a < 0 || (uint32_t)a >= n_actions(c, (e.imp >> i) & 1u)) bits |= SUSNET_ERRBIT_INDEX;
+            else if (a < 0 || (uint32_t)a >= n_actions<S>(c, (e.imp >> i) & 1u)) bits |= SUSNET_ERRBIT_INDEX;
         }
         if (bits) {
             for (int i = 0; i < A; i++) sink.put(i, b, 0.0);
@@ -369,64 +466,66 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int 
 
     uint64_t order = 0xFEDCBA9876543210ull;
     rng.align();
-    if (c.order_random) shuffle_nibbles(rng, order, A); // base.py:372-374
+    const bool shuffled = S::order_random(c);
+    if (shuffled) shuffle_nibbles(rng, order, A); // base.py:372-374
 
-    const uint32_t crew_alive_mask = ~e.imp;
+#pragma unroll
     for (int k = 0; k < A; k++) {
-        const int idx = (int)nibble(order, k);
-        const uint32_t a = L.act[idx * kBlock + tid];
+        const int idx = shuffled ? (int)nibble(order, k) : k;
+        const uint32_t a = st.act(idx);
         const uint32_t is_imp = (e.imp >> idx) & 1u;
-        const uint32_t nr = n_role_actions(c, is_imp);
+        const uint32_t nr = n_role_actions<S>(c, is_imp);
         if (tagging && a >= nr) {
             // tagging.py:68-75,103-110: k-th OTHER agent ascending; the actor's own aliveness is not checked
             uint32_t target = a - nr;
             if (target >= (uint32_t)idx) target += 1u;
             if (!((e.used >> idx) & 1u) && ((e.alive >> target) & 1u)) {
-                L.xy[target * kBlock + tid] += 0x100u; // tag_counts[target] += 1
+                st.set_cnt((int)target, st.cnt((int)target) + 1u); // tag_counts[target] += 1
                 e.used |= 1u << idx;
             }
             continue;
         }
         if (!((e.alive >> idx) & 1u)) continue; // base.py:477
-        const int action = role_action(c, is_imp, a);
-        const uint32_t w = L.xy[idx * kBlock + tid];
-        const uint32_t xy = w & 0xffu;
+        const int action = role_action<S>(c, is_imp, a);
+        const uint32_t xy = st.xy(idx);
         if (action <= ACT_RIGHT) { // base.py:484-487, move() 69-79
             int x = (int)(xy & 15u), y = (int)(xy >> 4);
             int nx = x + (action == ACT_RIGHT) - (action == ACT_LEFT);
             int ny = y + (action == ACT_UP) - (action == ACT_DOWN);
             // base.py:548-551: in range and grid[pos[1], pos[0]] (TRANSPOSED w.r.t. the spawn lookup)
             bool ok = (unsigned)nx < (unsigned)c.N && (unsigned)ny < (unsigned)c.N;
-            uint32_t row = L.grid[ok ? ny : 0];
-            ok = ok && ((row >> nx) & 1u);
-            if (ok) L.xy[idx * kBlock + tid] = (w & ~0xffu) | (uint32_t)nx | ((uint32_t)ny << 4);
+            uint32_t row = T.grid[ny & 15];
+            ok = ok && ((row >> (nx & 15)) & 1u);
+            if (ok) st.set_xy(idx, (uint32_t)nx | ((uint32_t)ny << 4));
         } else if (action == ACT_KILL) { // base.py:490-515
             uint32_t cm = 0;
-            const uint32_t crew = e.alive & crew_alive_mask;
+            const uint32_t crew = e.alive & ~e.imp;
+#pragma unroll
             for (int i = 0; i < A; i++)
-                if (((crew >> i) & 1u) && (L.xy[i * kBlock + tid] & 0xffu) == xy) cm |= 1u << i;
+                if (((crew >> i) & 1u) && st.xy(i) == xy) cm |= 1u << i;
             if (cm) {
                 uint32_t r = rng.bounded((uint32_t)__popc(cm)); // base.py:497
                 int victim = nth_set_bit(cm, r);
-                e.m_kv += 1u;                  // IMP_KILLED_CREW, base.py:508
-                e.alive &= ~(1u << victim);    // base.py:511
-                rc = (rc & ~(3u << (2 * victim))) | (RC_KILL << (2 * victim)); // base.py:514
-                rc = (rc & ~(3u << (2 * idx))) | (RC_KILL << (2 * idx));       // base.py:515
+                e.m_kv += 1u;                // IMP_KILLED_CREW, base.py:508
+                e.alive &= ~(1u << victim);  // base.py:511
+                set_code(rc, victim, RC_KILL); // base.py:514
+                set_code(rc, idx, RC_KILL);    // base.py:515
             }
         } else { // FIX (base.py:518-524) / SABOTAGE (527-533): first job on the cell (544-546)
             int job = -1;
+#pragma unroll
             for (int j = J - 1; j >= 0; j--)
-                if (L.job[j * kBlock + tid] == xy) job = j;
+                if (st.job(j) == xy) job = j;
             if (job >= 0) {
                 const uint32_t isdone = (e.jd >> job) & 1u;
                 if (action == ACT_FIX && !isdone) {
                     e.jd |= 1u << job;
                     e.m_fix += 1u;
-                    rc = (rc & ~(3u << (2 * idx))) | (RC_FIX << (2 * idx));
+                    set_code(rc, idx, RC_FIX);
                 } else if (action == ACT_SABOTAGE && isdone) {
                     e.jd &= ~(1u << job);
                     e.m_sab += 1u;
-                    rc = (rc & ~(3u << (2 * idx))) | (RC_SAB << (2 * idx));
+                    set_code(rc, idx, RC_SAB);
                 }
             }
         }
@@ -435,12 +534,12 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int 
     if (tagging) {
         // tagging.py:180: tag_counts *= alive_agents
         for (int i = 0; i < A; i++)
-            if (!((e.alive >> i) & 1u)) L.xy[i * kBlock + tid] &= 0xffu;
+            if (!((e.alive >> i) & 1u)) st.set_cnt(i, 0u);
         e.timer += 1u; // tagging.py:182
         if (e.timer >= (uint32_t)c.tag_interval) { // tagging.py:184-207
-            uint32_t best = 0, highest = (L.xy[tid] >> 8) & 0xffu;
+            uint32_t best = 0, highest = st.cnt(0);
             for (int i = 1; i < A; i++) { // np.argmax: first maximum
-                uint32_t v = (L.xy[i * kBlock + tid] >> 8) & 0xffu;
+                uint32_t v = st.cnt(i);
                 if (v > highest) { highest = v; best = (uint32_t)i; }
             }
             uint32_t quorum = ((uint32_t)__popc(e.alive) + 1u) / 2u;
@@ -450,7 +549,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int 
                 team += c.r_vote * (vimp ? -1.0 : 1.0); // tagging.py:196, sign as coded
                 e.m_kv += vimp ? (1u << 16) : (1u << 24);
             }
-            for (int i = 0; i < A; i++) L.xy[i * kBlock + tid] &= 0xffu; // tagging.py:237-241
+            for (int i = 0; i < A; i++) st.set_cnt(i, 0u); // tagging.py:237-241
             e.used = 0;
             e.timer = 0;
         }
@@ -460,7 +559,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int 
     {
         const int alive_imp = __popc(e.alive & e.imp), alive_all = __popc(e.alive), done_jobs = __popc(e.jd);
         double win = 0.0;
-        if (c.variant == SUSNET_VARIANT_ITG) {
+        if (S::variant(c) == SUSNET_VARIANT_ITG) {
             if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = c.r_end; }
             else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; win = -1.0 * c.r_end; }
         } else {
@@ -471,6 +570,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int 
     }
 
     // per-agent rewards: assignments (codes) -> _merge_rewards (base.py:553-563) -> zero fill (389-390)
+#pragma unroll
     for (int i = 0; i < A; i++) {
         uint32_t code = (rc >> (2 * i)) & 3u;
         double r = tagging ? 1.0 * c.r_tsr : 0.0; // tagging.py:162 / base.py:369
@@ -489,20 +589,21 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Lds &L, int 
     return 0;
 }
 
-// episode bookkeeping at an auto-reset: per-env lifetime sums (the multi-GPU metrics reduction input)
-__device__ __forceinline__ void accumulate_lifetime(const Consts &c, const State &s, int b, const Env &e, bool trunc) {
+// episode bookkeeping at an auto-reset: per-env lifetime sums (the multi-GPU metrics reduction input).
+// Fire-and-forget atomics on the lane's own words: no load latency on the stepping path.
+__device__ __forceinline__ void accumulate_lifetime(const Consts &c, const State &s, int64_t b, const Env &e, bool trunc) {
     uint32_t *L = s.life + b;
     const size_t st = (size_t)c.Bp;
-    L[SUSNET_L_EPISODES * st] += 1u;
-    if (e.flags & FLAG_CREW_WON) L[SUSNET_L_CREW_WON * st] += 1u;
-    if (e.flags & FLAG_IMP_WON) L[SUSNET_L_IMPOSTER_WON * st] += 1u;
-    if (trunc) L[SUSNET_L_TRUNCATED * st] += 1u;
-    if (e.m_kv & 0xffffu) L[SUSNET_L_KILLS * st] += e.m_kv & 0xffffu;
-    if (e.m_fix) L[SUSNET_L_COMPLETED_JOBS * st] += e.m_fix;
-    if (e.m_sab) L[SUSNET_L_SABOTAGED_JOBS * st] += e.m_sab;
-    if ((e.m_kv >> 16) & 0xffu) L[SUSNET_L_IMP_VOTED_OUT * st] += (e.m_kv >> 16) & 0xffu;
-    if (e.m_kv >> 24) L[SUSNET_L_CREW_VOTED_OUT * st] += e.m_kv >> 24;
-    L[SUSNET_L_EPISODE_STEPS * st] += e.m_steps;
+    atomicAdd(&L[SUSNET_L_EPISODES * st], 1u);
+    if (e.flags & FLAG_CREW_WON) atomicAdd(&L[SUSNET_L_CREW_WON * st], 1u);
+    if (e.flags & FLAG_IMP_WON) atomicAdd(&L[SUSNET_L_IMPOSTER_WON * st], 1u);
+    if (trunc) atomicAdd(&L[SUSNET_L_TRUNCATED * st], 1u);
+    if (e.m_kv & 0xffffu) atomicAdd(&L[SUSNET_L_KILLS * st], e.m_kv & 0xffffu);
+    if (e.m_fix) atomicAdd(&L[SUSNET_L_COMPLETED_JOBS * st], e.m_fix);
+    if (e.m_sab) atomicAdd(&L[SUSNET_L_SABOTAGED_JOBS * st], e.m_sab);
+    if ((e.m_kv >> 16) & 0xffu) atomicAdd(&L[SUSNET_L_IMP_VOTED_OUT * st], (e.m_kv >> 16) & 0xffu);
+    if (e.m_kv >> 24) atomicAdd(&L[SUSNET_L_CREW_VOTED_OUT * st], e.m_kv >> 24);
+    atomicAdd(&L[SUSNET_L_EPISODE_STEPS * st], e.m_steps);
 }
 
 } // namespace susnet

@@ -7,11 +7,11 @@
 //                                        featurizers of src/features/component.py:221-482
 //   PLANES  GlobalFeaturizer             src/features/model_ready.py:230-247 (+ component.py:83-131)
 //
-// Mechanism: the lane that owns an environment first writes that environment's observation ROW into an
-// LDS staging area in a compact form (one bit per element for the 0/1 planes, one byte per element for
-// everything else).  Then the whole wave streams the 64 rows -- which are contiguous in the [B][F] output
-// -- to HBM with 16-byte stores, expanding bits/bytes to float32 on the way.  A lane therefore never
-// writes a strided row of its own: every global store instruction covers 1 KiB of consecutive bytes.
+// Mechanism: the 64 rows a wave owns are CONTIGUOUS in the [B][F] output, so the wave builds exactly that
+// byte image in LDS -- one byte per element (small integers), or one bit per element for the 0/1 planes --
+// each lane writing only its own environment's row, and then streams the image to HBM with 16-byte
+// stores (bytes copied as they are for uint8 output, expanded to float32 otherwise).  No lane ever writes
+// a strided row of its own: every global store instruction covers up to 1 KiB of consecutive bytes.
 #pragma once
 
 #include "susnet_device.h"
@@ -24,12 +24,10 @@ struct ObsArgs {
     int32_t ncomp;
     int32_t comp[16];
     int32_t F, F2;          // elements per env of out / out2
-    int32_t words1, words2; // LDS staging words per row (odd) for segment 1 / 2
+    int32_t words1, words2; // LDS staging words of segment 1 / 2 (whole wave)
     void *out, *out2;
     int64_t tick_stride, tick_stride2; // rollout: elements between consecutive ticks
 };
-
-__host__ __device__ inline int odd_words(int w) { return (w & 1) ? w : w + 1; }
 
 __host__ __device__ inline int flat_component_size(int comp, int A, int N, int n_crew) {
     switch (comp) {
@@ -45,82 +43,93 @@ __host__ __device__ inline int flat_component_size(int comp, int A, int N, int n
     }
 }
 
-// ---- row fill (owning lane) -----------------------------------------------------------------------
-__device__ __forceinline__ void stage_zero(uint32_t *row, int words) {
-    for (int w = 0; w < words; w++) row[w] = 0u;
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void stage_byte(uint32_t *row, int f, int v) {
-    reinterpret_cast<uint8_t *>(row)[f] = (uint8_t)(int8_t)v;
-}
-__device__ __forceinline__ void stage_bit(uint32_t *row, int f) { row[f >> 5] |= 1u << (f & 31); }
 
-__device__ __forceinline__ void fill_raw(const Consts &c, const Lds &L, int tid, const Env &e, uint32_t *row) {
-    const int A = c.A, J = c.J;
+// ---- row fill (owning lane); `row` = this env's F bytes inside the packed image -----------------------
+__device__ __forceinline__ void put_b(uint8_t *row, int f, int v) { row[f] = (uint8_t)(int8_t)v; }
+
+template <class S, class Store>
+__device__ __forceinline__ void fill_raw(const Consts &c, const Store &st, const Env &e, uint8_t *row) {
+    const int A = S::A(c), J = S::J(c);
     int k = 0;
+#pragma unroll
     for (int i = 0; i < A; i++) {
-        uint32_t w = L.xy[i * kBlock + tid];
-        stage_byte(row, k++, w & 15u);
-        stage_byte(row, k++, (w >> 4) & 15u);
+        uint32_t w = st.xy(i);
+        put_b(row, k++, w & 15u);
+        put_b(row, k++, (w >> 4) & 15u);
     }
-    for (int i = 0; i < A; i++) stage_byte(row, k++, (e.alive >> i) & 1u);
-    const bool tagging = c.variant == SUSNET_VARIANT_TAGGING;
+#pragma unroll
+    for (int i = 0; i < A; i++) put_b(row, k++, (e.alive >> i) & 1u);
+    const bool tagging = S::tagging(c);
     if (J > 0 || tagging) {
+#pragma unroll
         for (int j = 0; j < J; j++) {
-            uint32_t w = L.job[j * kBlock + tid];
-            stage_byte(row, k++, w & 15u);
-            stage_byte(row, k++, (w >> 4) & 15u);
+            uint32_t w = st.job(j);
+            put_b(row, k++, w & 15u);
+            put_b(row, k++, (w >> 4) & 15u);
         }
-        for (int j = 0; j < J; j++) stage_byte(row, k++, (e.jd >> j) & 1u);
+#pragma unroll
+        for (int j = 0; j < J; j++) put_b(row, k++, (e.jd >> j) & 1u);
     }
     if (tagging) {
-        for (int i = 0; i < A; i++) stage_byte(row, k++, (e.used >> i) & 1u);
-        for (int i = 0; i < A; i++) stage_byte(row, k++, (L.xy[i * kBlock + tid] >> 8) & 0xffu);
-        stage_byte(row, k++, c.tag_interval - (int)e.timer);
+        for (int i = 0; i < A; i++) put_b(row, k++, (e.used >> i) & 1u);
+        for (int i = 0; i < A; i++) put_b(row, k++, st.cnt(i));
+        put_b(row, k++, c.tag_interval - (int)e.timer);
     }
 }
 
-__device__ __forceinline__ void fill_flat(const Consts &c, const ObsArgs &o, const Lds &L, int tid, const Env &e, uint32_t *row) {
-    const int A = c.A, N = c.N, NC = c.n_crew;
-    const uint32_t w0 = L.xy[tid];
+template <class S, class Store>
+__device__ __forceinline__ void fill_flat(const Consts &c, const ObsArgs &o, const Tables &T, const Store &st, const Env &e, uint8_t *row) {
+    const int A = S::A(c), N = c.N, NC = c.n_crew;
+    const uint32_t w0 = st.xy(0);
     const int ix = (int)(w0 & 15u), iy = (int)((w0 >> 4) & 15u); // "imposter" = agent 0 (component.py:262,289,...)
     int k = 0;
     for (int ci = 0; ci < o.ncomp; ci++) {
         const int comp = o.comp[ci];
         switch (comp) {
         case SUSNET_F_ONEHOT_POS: // component.py:226-240
+#pragma unroll
             for (int i = 0; i < A; i++)
                 if ((e.alive >> i) & 1u) {
-                    uint32_t w = L.xy[i * kBlock + tid];
-                    stage_byte(row, k + i * 2 * N + (int)(w & 15u), 1);
-                    stage_byte(row, k + i * 2 * N + N + (int)((w >> 4) & 15u), 1);
+                    uint32_t w = st.xy(i);
+                    put_b(row, k + i * 2 * N + (int)(w & 15u), 1);
+                    put_b(row, k + i * 2 * N + N + (int)((w >> 4) & 15u), 1);
                 }
             break;
         case SUSNET_F_COORD_POS: // component.py:389-399
+#pragma unroll
             for (int i = 0; i < A; i++) {
-                uint32_t w = L.xy[i * kBlock + tid];
-                stage_byte(row, k + 2 * i, w & 15u);
-                stage_byte(row, k + 2 * i + 1, (w >> 4) & 15u);
+                uint32_t w = st.xy(i);
+                put_b(row, k + 2 * i, w & 15u);
+                put_b(row, k + 2 * i + 1, (w >> 4) & 15u);
             }
             break;
         case SUSNET_F_ALIVE_CREW: // component.py:411-421
+#pragma unroll
             for (int i = 1; i < A; i++)
-                if ((e.alive >> i) & 1u) stage_byte(row, k + i - 1, 1);
+                if ((e.alive >> i) & 1u) put_b(row, k + i - 1, 1);
             break;
         case SUSNET_F_L1_CREW: // component.py:433-448
+#pragma unroll
             for (int i = 1; i < A; i++) {
-                uint32_t w = L.xy[i * kBlock + tid];
+                uint32_t w = st.xy(i);
                 int d = abs(ix - (int)(w & 15u)) + abs(iy - (int)((w >> 4) & 15u));
-                stage_byte(row, k + i - 1, ((e.alive >> i) & 1u) ? d : -1);
+                put_b(row, k + i - 1, ((e.alive >> i) & 1u) ? d : -1);
             }
             break;
         case SUSNET_F_CLOSEST_CREW: { // component.py:460-478: argmin, first minimum, dead = N + N
             int best = 0, bestd = 1 << 20;
+#pragma unroll
             for (int i = 1; i < A; i++) {
-                uint32_t w = L.xy[i * kBlock + tid];
+                uint32_t w = st.xy(i);
                 int d = ((e.alive >> i) & 1u) ? abs(ix - (int)(w & 15u)) + abs(iy - (int)((w >> 4) & 15u)) : N + N;
                 if (d < bestd) { bestd = d; best = i - 1; }
             }
-            if (NC > 0) stage_byte(row, k + best, 1);
+            if (NC > 0) put_b(row, k + best, 1);
             break;
         }
         case SUSNET_F_WALLS3X3: // component.py:286-296: zero-padded grid[x, y] around agent 0
@@ -128,31 +137,33 @@ __device__ __forceinline__ void fill_flat(const Consts &c, const ObsArgs &o, con
                 for (int b = 0; b < 3; b++) {
                     int gx = ix + a - 1, gy = iy + b - 1;
                     bool in = (unsigned)gx < (unsigned)N && (unsigned)gy < (unsigned)N;
-                    uint32_t rw = L.grid[in ? gx : 0];
-                    if (in && ((rw >> gy) & 1u)) stage_byte(row, k + a * 3 + b, 1);
+                    uint32_t rw = T.grid[gx & 15];
+                    if (in && ((rw >> (gy & 15)) & 1u)) put_b(row, k + a * 3 + b, 1);
                 }
             break;
         case SUSNET_F_DIST_TO_IMP: { // component.py:255-273: alive non-0 agents packed left
             int p = 0;
+#pragma unroll
             for (int i = 1; i < A; i++)
                 if ((e.alive >> i) & 1u) {
-                    uint32_t w = L.xy[i * kBlock + tid];
-                    stage_byte(row, k + p, ix - (int)(w & 15u));
-                    stage_byte(row, k + p + 1, iy - (int)((w >> 4) & 15u));
+                    uint32_t w = st.xy(i);
+                    put_b(row, k + p, ix - (int)(w & 15u));
+                    put_b(row, k + p + 1, iy - (int)((w >> 4) & 15u));
                     p += 2;
                 }
             break;
         }
         case SUSNET_F_ROOM_LOC: { // component.py:8-17,308-329 (9x9 quadrants)
             uint32_t cnt = 0; // eight 4-bit counters (at most 15 agents per bucket)
+#pragma unroll
             for (int i = 0; i < A; i++) {
                 if (!((e.alive >> i) & 1u)) continue;
-                uint32_t w = L.xy[i * kBlock + tid];
+                uint32_t w = st.xy(i);
                 int x = (int)(w & 15u), y = (int)((w >> 4) & 15u);
                 int room = (x < 5) ? (y < 5 ? 0 : 1) : (y >= 5 ? 2 : 3);
                 cnt += 1u << (4 * (((i == 0) ? 0 : 4) + room));
             }
-            for (int r = 0; r < 8; r++) stage_byte(row, k + r, (cnt >> (4 * r)) & 15u);
+            for (int r = 0; r < 8; r++) put_b(row, k + r, (cnt >> (4 * r)) & 15u);
             break;
         }
         default: break;
@@ -161,102 +172,119 @@ __device__ __forceinline__ void fill_flat(const Consts &c, const ObsArgs &o, con
     }
 }
 
-__device__ __forceinline__ void fill_planes(const Consts &c, const Lds &L, int tid, const Env &e, uint32_t *bits, uint32_t *bytes) {
-    const int A = c.A, J = c.J, N = c.N, NN = N * N;
+// planes: bit image [64][F] packed; set bit (row * F + f) with an LDS atomic (lanes share words)
+template <class S, class Store>
+__device__ __forceinline__ void fill_planes(const Consts &c, const Store &st, const Env &e, uint32_t *bits, int rowbit0, uint8_t *bytes) {
+    const int A = S::A(c), J = S::J(c), N = c.N, NN = N * N;
+#pragma unroll
     for (int i = 0; i < A; i++) // component.py:90-100: channel i, [x][y], only if alive
         if ((e.alive >> i) & 1u) {
-            uint32_t w = L.xy[i * kBlock + tid];
-            stage_bit(bits, i * NN + (int)(w & 15u) * N + (int)((w >> 4) & 15u));
+            uint32_t w = st.xy(i);
+            int g = rowbit0 + i * NN + (int)(w & 15u) * N + (int)((w >> 4) & 15u);
+            atomicOr(&bits[g >> 5], 1u << (g & 31));
         }
+#pragma unroll
     for (int j = 0; j < J; j++) { // component.py:116-127: channel A + int(done)
-        uint32_t w = L.job[j * kBlock + tid];
-        stage_bit(bits, (A + (int)((e.jd >> j) & 1u)) * NN + (int)(w & 15u) * N + (int)((w >> 4) & 15u));
+        uint32_t w = st.job(j);
+        int g = rowbit0 + (A + (int)((e.jd >> j) & 1u)) * NN + (int)(w & 15u) * N + (int)((w >> 4) & 15u);
+        atomicOr(&bits[g >> 5], 1u << (g & 31));
     }
     int k = 0; // model_ready.py:237-247: [alive, (tag_counts), job_status]
-    for (int i = 0; i < A; i++) stage_byte(bytes, k++, (e.alive >> i) & 1u);
-    if (c.variant == SUSNET_VARIANT_TAGGING)
-        for (int i = 0; i < A; i++) stage_byte(bytes, k++, (L.xy[i * kBlock + tid] >> 8) & 0xffu);
-    for (int j = 0; j < J; j++) stage_byte(bytes, k++, (e.jd >> j) & 1u);
-}
-
-// ---- cooperative wave store -------------------------------------------------------------------------
-// rows [0, nrows) of `stage` (row stride `words`) -> out[(b0 + row) * F + f], 4 elements per lane per pass.
-template <bool BITS>
-__device__ __forceinline__ void store_rows(const uint32_t *stage, int words, int F, int nrows, int64_t b0, void *out,
-                                           int dtype, bool is_signed, int lane) {
-    if (!out || F <= 0) return;
-    const int total = nrows * F;
-    const int64_t base = b0 * (int64_t)F;
-    for (int g = lane * 4; g < total; g += kWave * 4) {
-        int row = g / F, f = g - row * F;
-        int v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int r = row, ff = f + k;
-            while (ff >= F) { ff -= F; r++; }
-            int val = 0;
-            if (g + k < total) {
-                if (BITS) val = (stage[r * words + (ff >> 5)] >> (ff & 31)) & 1u;
-                else {
-                    uint8_t by = reinterpret_cast<const uint8_t *>(stage + r * words)[ff];
-                    val = is_signed ? (int)(int8_t)by : (int)by;
-                }
-            }
-            v[k] = val;
-        }
-        if (dtype == SUSNET_F32) {
-            float *o = reinterpret_cast<float *>(out) + base + g;
-            if (g + 3 < total) {
-                float4 q = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-                *reinterpret_cast<float4 *>(o) = q;
-            } else {
-                for (int k = 0; k < 4 && g + k < total; k++) o[k] = (float)v[k];
-            }
-        } else {
-            uint8_t *o = reinterpret_cast<uint8_t *>(out) + base + g;
-            if (g + 3 < total) {
-                uint32_t q = (uint32_t)(v[0] & 0xff) | ((uint32_t)(v[1] & 0xff) << 8) | ((uint32_t)(v[2] & 0xff) << 16) |
-                             ((uint32_t)(v[3] & 0xff) << 24);
-                *reinterpret_cast<uint32_t *>(o) = q;
-            } else {
-                for (int k = 0; k < 4 && g + k < total; k++) o[k] = (uint8_t)v[k];
-            }
-        }
+    for (int i = 0; i < A; i++) put_b(bytes, k++, (e.alive >> i) & 1u);
+    if (S::tagging(c))
+        for (int i = 0; i < A; i++) put_b(bytes, k++, st.cnt(i));
+#pragma unroll
+    for (int j = 0; j < J; j++) put_b(bytes, k++, (e.jd >> j) & 1u);
+}
+
+// ---- cooperative wave store of a packed image of `total` elements -------------------------------------
+// BYTES image, uint8 output: straight copy
+__device__ __forceinline__ void copy_bytes(const uint32_t *img, int total, uint8_t *dst, int lane) {
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const int vec = total & ~15;
+        for (int g = lane * 16; g < vec; g += kWave * 16)
+            *reinterpret_cast<uint4 *>(dst + g) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(img) + g);
+        for (int g = vec + lane; g < total; g += kWave) dst[g] = reinterpret_cast<const uint8_t *>(img)[g];
+    } else {
+        for (int g = lane; g < total; g += kWave) dst[g] = reinterpret_cast<const uint8_t *>(img)[g];
     }
 }
 
-// Fill this lane's row(s), then stream the wave's rows. `active` = this lane owns a real env.
-// `tick` selects the trajectory slice in rollouts (0 otherwise).
-__device__ __forceinline__ void write_obs(const Consts &c, const ObsArgs &o, const Lds &L, int tid, const Env &e, bool active,
-                                          int64_t b0, int nrows, int64_t tick) {
+// BYTES or BITS image, float32 output: 4 elements per lane per pass
+template <bool BITS>
+__device__ __forceinline__ void expand_f32(const uint32_t *img, int total, float *dst, bool is_signed, int lane) {
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+    for (int g = lane * 4; g < total; g += kWave * 4) {
+        float v[4];
+        if (BITS) {
+            uint32_t q = (img[g >> 5] >> (g & 31)) & 15u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (float)((q >> k) & 1u);
+        } else {
+            uint32_t q = img[g >> 2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t by = (q >> (8 * k)) & 0xffu;
+                v[k] = is_signed ? (float)(int)(int8_t)by : (float)by;
+            }
+        }
+        if (vec_ok && g + 3 < total) *reinterpret_cast<float4 *>(dst + g) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int k = 0; k < 4 && g + k < total; k++) dst[g + k] = v[k];
+    }
+}
+
+// BITS image, uint8 output
+__device__ __forceinline__ void expand_bits_u8(const uint32_t *img, int total, uint8_t *dst, int lane) {
+    for (int g = lane * 4; g < total; g += kWave * 4) {
+        uint32_t q = (img[g >> 5] >> (g & 31)) & 15u;
+        uint32_t packed = (q & 1u) | ((q & 2u) << 7) | ((q & 4u) << 14) | ((q & 8u) << 21);
+        if (g + 3 < total && (reinterpret_cast<uintptr_t>(dst + g) & 3u) == 0) *reinterpret_cast<uint32_t *>(dst + g) = packed;
+        else
+            for (int k = 0; k < 4 && g + k < total; k++) dst[g + k] = (uint8_t)((q >> k) & 1u);
+    }
+}
+
+// Build this wave's image(s) and stream them. `active` = this lane owns a real env; `tick` selects the
+// trajectory slice in rollouts (0 otherwise).
+template <class S, class Store>
+__device__ __forceinline__ void write_obs(const Consts &c, const ObsArgs &o, const Tables &T, const Store &st, int tid, const Env &e,
+                                          bool active, int64_t b0, int nrows, int64_t tick) {
     if (o.mode == SUSNET_OBS_NONE) return;
-    uint32_t *seg1 = L.stage;
-    uint32_t *seg2 = L.stage + kBlock * o.words1;
-    uint32_t *row1 = seg1 + tid * o.words1;
-    uint32_t *row2 = seg2 + tid * o.words2;
+    uint32_t *seg1 = T.stage;
+    uint32_t *seg2 = T.stage + o.words1;
+    const bool planes = o.mode == SUSNET_OBS_PLANES;
+    if (o.mode != SUSNET_OBS_RAW) { // RAW rows are fully overwritten; the others start from zeros
+        for (int w = tid; w < o.words1 + o.words2; w += kWave) seg1[w] = 0u;
+        wave_lds_fence();
+    }
     if (active) {
-        stage_zero(row1, o.words1);
-        if (o.mode == SUSNET_OBS_RAW) fill_raw(c, L, tid, e, row1);
-        else if (o.mode == SUSNET_OBS_FLAT) fill_flat(c, o, L, tid, e, row1);
-        else {
-            stage_zero(row2, o.words2);
-            fill_planes(c, L, tid, e, row1, row2);
+        uint8_t *row = reinterpret_cast<uint8_t *>(seg1) + tid * o.F;
+        if (o.mode == SUSNET_OBS_RAW) fill_raw<S>(c, st, e, row);
+        else if (o.mode == SUSNET_OBS_FLAT) fill_flat<S>(c, o, T, st, e, row);
+        else fill_planes<S>(c, st, e, seg1, tid * o.F, reinterpret_cast<uint8_t *>(seg2) + tid * o.F2);
+    }
+    wave_lds_fence();
+    const int total1 = nrows * o.F;
+    if (o.dtype == SUSNET_F32) {
+        float *d1 = reinterpret_cast<float *>(o.out) + tick * o.tick_stride + b0 * o.F;
+        if (planes) {
+            expand_f32<true>(seg1, total1, d1, false, tid);
+            if (o.out2) expand_f32<false>(seg2, nrows * o.F2, reinterpret_cast<float *>(o.out2) + tick * o.tick_stride2 + b0 * o.F2, false, tid);
+        } else {
+            expand_f32<false>(seg1, total1, d1, o.mode == SUSNET_OBS_FLAT, tid);
+        }
+    } else {
+        uint8_t *d1 = reinterpret_cast<uint8_t *>(o.out) + tick * o.tick_stride + b0 * o.F;
+        if (planes) {
+            expand_bits_u8(seg1, total1, d1, tid);
+            if (o.out2) copy_bytes(seg2, nrows * o.F2, reinterpret_cast<uint8_t *>(o.out2) + tick * o.tick_stride2 + b0 * o.F2, tid);
+        } else {
+            copy_bytes(seg1, total1, d1, tid);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const int esz = (o.dtype == SUSNET_F32) ? 4 : 1;
-    char *out1 = o.out ? reinterpret_cast<char *>(o.out) + tick * o.tick_stride * esz : nullptr;
-    if (o.mode == SUSNET_OBS_PLANES) {
-        store_rows<true>(seg1, o.words1, o.F, nrows, b0, out1, o.dtype, false, tid);
-        char *out2 = o.out2 ? reinterpret_cast<char *>(o.out2) + tick * o.tick_stride2 * esz : nullptr;
-        store_rows<false>(seg2, o.words2, o.F2, nrows, b0, out2, o.dtype, false, tid);
-    } else {
-        store_rows<false>(seg1, o.words1, o.F, nrows, b0, out1, o.dtype, o.mode == SUSNET_OBS_FLAT, tid);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence(); // the image is rebuilt next tick
 }
 
 } // namespace susnet
