@@ -78,6 +78,8 @@ __global__ __launch_bounds__(kBlock) void k_reset(Consts c, State s, const uint8
     const bool active = b < c.B;
     LdsStore st;
     Tables T = setup_lds<S>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
     Env e = {};
     if (active) {
         load_env<S>(c, s, st, b, e);
@@ -118,6 +120,8 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
     const bool active = b < c.B;
     typename StoreFor<S>::type st;
     Tables T = setup_lds<S>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
     Env e = {};
     if (active) {
         const int A = S::A(c);
@@ -155,6 +159,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     const int A = S::A(c);
     typename StoreFor<S>::type st;
     Tables T = setup_lds<S>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
     Env e = {};
     PhiloxRng rng;
     rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
@@ -197,6 +203,8 @@ __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o
     const bool active = b < c.B;
     LdsStore st;
     Tables T = setup_lds<S>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
     Env e = {};
     if (active) load_env<S>(c, s, st, b, e);
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
@@ -208,7 +216,8 @@ using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0>;  // ImposterTrainingGround 1
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
 using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
 
-static int pick_spec(const Consts &c) {
+static int pick_spec(const Consts &c, bool float_exact) {
+    if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
     if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return 2;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
@@ -323,6 +332,7 @@ struct susnet_env {
     Consts c;
     State s;
     bool bound = false;
+    bool float_exact = false;
     susnet_layout layout;
     uint64_t off_err, off_agent, off_job, off_jobdone, off_t, off_timer, off_flags, off_rng, off_msteps, off_mfix, off_msab,
         off_mkv, off_life;
@@ -398,8 +408,15 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
         delete e;
         return fail(SUSNET_E_INVALID, "grid has fewer free cells than jobs");
     }
-    c.r_kill = cfg->kill_reward; c.r_fix = cfg->complete_job_reward; c.r_sab = cfg->sabotage_reward;
-    c.r_tsr = cfg->time_step_reward; c.r_end = cfg->game_end_reward; c.r_dead = dead; c.r_vote = cfg->vote_reward;
+    const double rewards[7] = {cfg->kill_reward, cfg->complete_job_reward, cfg->sabotage_reward, cfg->time_step_reward,
+                               cfg->game_end_reward, dead, cfg->vote_reward};
+    e->float_exact = true;
+    for (int k = 0; k < 7; k++) {
+        c.dr[k] = rewards[k];
+        c.fr[k] = (float)rewards[k];
+        // integers below 2^20: every sum the step forms is exact in float32, signed zeros included
+        if (!(rewards[k] == (double)(long long)rewards[k] && rewards[k] > -1048576.0 && rewards[k] < 1048576.0)) e->float_exact = false;
+    }
     c.seed = cfg->seed; c.env_id_base = cfg->env_id_base;
 
     // state blob layout (every array 256-byte aligned; row stride Bp)
@@ -626,7 +643,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c) : 0;
+    const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c, env->float_exact) : 0;
     size_t sh = lds_bytes(env, o, env->c.auto_reset != 0, spec == 0);
     CHECK_LDS(sh);
     const dim3 g = grid_for(env), blk(kBlock);
@@ -651,7 +668,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     a.trunc = io->truncated;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
-    const int spec = pick_spec(env->c);
+    const int spec = pick_spec(env->c, env->float_exact);
     size_t sh = lds_bytes(env, o, true, spec == 0);
     CHECK_LDS(sh);
     hipStream_t st = static_cast<hipStream_t>(stream);

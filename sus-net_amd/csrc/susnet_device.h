@@ -55,9 +55,14 @@ struct Consts {
     int32_t n_valid, auto_reset, nr_imp, nr_crew; // nr_* = length of the role part of agent_action_map
     uint32_t grid_rows[SUSNET_MAX_GRID];          // bit j of row i = grid[i][j]
     uint32_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID / 4]; // np.argwhere(grid) order; bytes x | y << 4
-    double r_kill, r_fix, r_sab, r_tsr, r_end, r_dead, r_vote;
+    double dr[8];  // kill, fix, sabotage, time_step, game_end, dead_penalty, vote (reference: Python numbers)
+    float fr[8];   // the same as float32 (used by compiled-in kernels when every value is float-exact)
     uint64_t seed, env_id_base;
 };
+enum : int { RW_KILL = 0, RW_FIX = 1, RW_SAB = 2, RW_TSR = 3, RW_END = 4, RW_DEAD = 5, RW_VOTE = 6 };
+template <class RT> __device__ __forceinline__ RT rw(const Consts &c, int k);
+template <> __device__ __forceinline__ double rw<double>(const Consts &c, int k) { return c.dr[k]; }
+template <> __device__ __forceinline__ float rw<float>(const Consts &c, int k) { return c.fr[k]; }
 
 // Device pointers into the caller's state blob (SoA, row stride Bp).
 struct State {
@@ -83,6 +88,9 @@ template <int A_, int J_, int VAR_, int ORD_>
 struct Spec {
     static constexpr bool kGeneric = A_ < 0;
     static constexpr int kA = A_, kJ = J_;
+    // reward arithmetic type: double reproduces the reference's float64 chain for ANY constants; the
+    // compiled-in kernels are only selected when all constants are float-exact integers, so float is exact
+    using RT = typename std::conditional<(A_ < 0), double, float>::type;
     __device__ static __forceinline__ int A(const Consts &c) { return A_ >= 0 ? A_ : c.A; }
     __device__ static __forceinline__ int J(const Consts &c) { return J_ >= 0 ? J_ : c.J; }
     __device__ static __forceinline__ int variant(const Consts &c) { return VAR_ >= 0 ? VAR_ : c.variant; }
@@ -136,6 +144,13 @@ struct PhiloxRng {
     // bounded draw (also for n == 1), multiply-shift mapping onto [0, n)
     __device__ __forceinline__ void align() { cur = (cur + 3ull) & ~3ull; }
     __device__ __forceinline__ uint32_t bounded(uint32_t n) { return __umulhi(next(), n); }
+    // draw number k (compile-time, counted from the last align()) of a run: no cache check, no select
+    __device__ __forceinline__ uint32_t bounded_at(uint32_t n, int k) {
+        if ((k & 3) == 0) gen(cur >> 2);
+        cur++;
+        const uint32_t w = (k & 3) == 0 ? w0 : (k & 3) == 1 ? w1 : (k & 3) == 2 ? w2 : w3;
+        return __umulhi(w, n);
+    }
 };
 
 // Caller-supplied raw words consumed with numpy-legacy semantics (masked rejection, nothing drawn for a
@@ -158,6 +173,7 @@ struct TapeRng {
         return w;
     }
     __device__ __forceinline__ void align() {}
+    __device__ __forceinline__ uint32_t bounded_at(uint32_t n, int) { return bounded(n); }
     __device__ __forceinline__ uint32_t bounded(uint32_t n) { // np.random.randint(0, n)
         if (n <= 1u) return 0u;
         uint32_t mx = n - 1u, mask = mx;
@@ -174,11 +190,12 @@ struct TapeRng {
 struct Tables {
     const uint32_t *grid;  // [16] wall map rows
     const uint8_t *valid;  // [256] spawn cells, x | y << 4
+    uint32_t *comp;        // [16] flat observation component list (filled by the kernel when needed)
     uint8_t *perm;         // [n_valid][64] spawn permutation (TAPE resets only)
     uint32_t *stage;       // observation staging
 };
 
-constexpr uint32_t kTableWords = 16 + 64; // grid + valid
+constexpr uint32_t kTableWords = 16 + 64 + 16; // grid + valid + obs components
 
 __host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic) {
     return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u);
@@ -243,14 +260,15 @@ __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int
     smem[16 + tid] = c.valid_xy[tid];
     T.grid = smem;
     T.valid = reinterpret_cast<const uint8_t *>(smem + 16);
+    T.comp = smem + 80;
     uint32_t *rest = smem + kTableWords;
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
     T.perm = reinterpret_cast<uint8_t *>(rest);
     T.stage = rest;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return T;
 }
 
@@ -318,11 +336,12 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, uint32_t r) {
 }
 
 // np.random.shuffle / permutation on a nibble-packed list (base.py:374): i = n-1 .. 1, j in [0, i]
-template <class RNG>
+// STATIC: n is a compile-time constant and the run starts right after rng.align()
+template <bool STATIC, class RNG>
 __device__ __forceinline__ void shuffle_nibbles(RNG &rng, uint64_t &v, int n) {
 #pragma unroll
     for (int i = n - 1; i >= 1; i--) {
-        int j = (int)rng.bounded((uint32_t)i + 1u);
+        int j = (int)(STATIC ? rng.bounded_at((uint32_t)i + 1u, n - 1 - i) : rng.bounded((uint32_t)i + 1u));
         nibble_swap(v, i, j);
     }
 }
@@ -355,7 +374,7 @@ __device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Stor
     if (c.shuffle_imp) {
         if (RNG::kNumpy) {
             uint64_t perm = 0xFEDCBA9876543210ull;
-            shuffle_nibbles(rng, perm, A); // choice(range(A), n_imp, replace=False) == permutation(A)[:n_imp]
+            shuffle_nibbles<false>(rng, perm, A); // choice(range(A), n_imp, replace=False) == permutation(A)[:n_imp]
             e.imp = 0;
             for (int k = 0; k < c.n_imp; k++) e.imp |= 1u << nibble(perm, k);
         } else {
@@ -417,7 +436,10 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
     const int A = S::A(c);
     rng.align();
 #pragma unroll
-    for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (e.imp >> i) & 1u)));
+    for (int i = 0; i < A; i++) {
+        const uint32_t n = n_actions<S>(c, (e.imp >> i) & 1u);
+        st.set_act(i, S::kGeneric ? rng.bounded(n) : rng.bounded_at(n, i));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -427,10 +449,11 @@ struct RewardSink {
     void *ptr;       // NULL = drop
     int64_t sa, sb;  // element strides for (agent, env)
     int32_t f64;     // store double instead of float
-    __device__ __forceinline__ void put(int i, int64_t b, double r) const {
+    template <class RT>
+    __device__ __forceinline__ void put(int i, int64_t b, RT r) const {
         if (!ptr) return;
         int64_t k = (int64_t)i * sa + b * sb;
-        if (f64) reinterpret_cast<double *>(ptr)[k] = r;
+        if (f64) reinterpret_cast<double *>(ptr)[k] = (double)r;
         else reinterpret_cast<float *>(ptr)[k] = (float)r;
     }
 };
@@ -455,19 +478,20 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             else if (a < 0 || (uint32_t)a >= n_actions<S>(c, (e.imp >> i) & 1u)) bits |= SUSNET_ERRBIT_INDEX;
         }
         if (bits) {
-            for (int i = 0; i < A; i++) sink.put(i, b, 0.0);
+            for (int i = 0; i < A; i++) sink.put(i, b, 0.0f);
             return bits;
         }
     }
     if (e.flags & FLAG_FRESH) zero_metrics(e);
     e.m_steps += 1; // base.py:366
+    using RT = typename S::RT;
     uint32_t rc = 0; // 2-bit reward code per agent
-    double team = 0.0;
+    RT team = 0;
 
     uint64_t order = 0xFEDCBA9876543210ull;
     rng.align();
     const bool shuffled = S::order_random(c);
-    if (shuffled) shuffle_nibbles(rng, order, A); // base.py:372-374
+    if (shuffled) shuffle_nibbles<!S::kGeneric>(rng, order, A); // base.py:372-374
 
 #pragma unroll
     for (int k = 0; k < A; k++) {
@@ -546,7 +570,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             if (highest >= quorum) {
                 e.alive &= ~(1u << best);
                 bool vimp = (e.imp >> best) & 1u;
-                team += c.r_vote * (vimp ? -1.0 : 1.0); // tagging.py:196, sign as coded
+                team += rw<RT>(c, RW_VOTE) * (vimp ? (RT)-1 : (RT)1); // tagging.py:196, sign as coded
                 e.m_kv += vimp ? (1u << 16) : (1u << 24);
             }
             for (int i = 0; i < A; i++) st.set_cnt(i, 0u); // tagging.py:237-241
@@ -558,13 +582,14 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     // check_win_condition: base.py:409-460 / pred_prey.py:78-99
     {
         const int alive_imp = __popc(e.alive & e.imp), alive_all = __popc(e.alive), done_jobs = __popc(e.jd);
-        double win = 0.0;
+        RT win = 0;
+        const RT r_end = rw<RT>(c, RW_END);
         if (S::variant(c) == SUSNET_VARIANT_ITG) {
-            if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = c.r_end; }
-            else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; win = -1.0 * c.r_end; }
+            if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = r_end; }
+            else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; win = (RT)-1 * r_end; }
         } else {
-            if (alive_imp == 0 || done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = c.r_end; }
-            else if (alive_all - alive_imp <= alive_imp) { done = true; e.flags |= FLAG_IMP_WON; win = -1.0 * c.r_end; }
+            if (alive_imp == 0 || done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = r_end; }
+            else if (alive_all - alive_imp <= alive_imp) { done = true; e.flags |= FLAG_IMP_WON; win = (RT)-1 * r_end; }
         }
         team += win;
     }
@@ -573,14 +598,14 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
 #pragma unroll
     for (int i = 0; i < A; i++) {
         uint32_t code = (rc >> (2 * i)) & 3u;
-        double r = tagging ? 1.0 * c.r_tsr : 0.0; // tagging.py:162 / base.py:369
-        if (code == RC_KILL) r = c.r_kill;
-        else if (code == RC_FIX) r = c.r_fix;
-        else if (code == RC_SAB) r = -1.0 * c.r_sab;
+        RT r = tagging ? (RT)1 * rw<RT>(c, RW_TSR) : (RT)0; // tagging.py:162 / base.py:369
+        if (code == RC_KILL) r = rw<RT>(c, RW_KILL);
+        else if (code == RC_FIX) r = rw<RT>(c, RW_FIX);
+        else if (code == RC_SAB) r = (RT)-1 * rw<RT>(c, RW_SAB);
         r += team;
-        if (i < c.n_imp) r *= -1.0; // indices [:n_imposters], NOT the imposter mask (base.py:559)
-        if (!((e.alive >> i) & 1u)) r = c.r_dead; // base.py:562
-        if (!tagging && r == 0.0) r = c.r_tsr;    // base.py:389-390 (tagging.py has no fill)
+        if (i < c.n_imp) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
+        if (!((e.alive >> i) & 1u)) r = rw<RT>(c, RW_DEAD); // base.py:562
+        if (!tagging && r == (RT)0) r = rw<RT>(c, RW_TSR);  // base.py:389-390 (tagging.py has no fill)
         sink.put(i, b, r);
     }
     // base.py:392-395: t saturates at max_time_steps - 1

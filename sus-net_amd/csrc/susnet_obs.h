@@ -43,10 +43,13 @@ __host__ __device__ inline int flat_component_size(int comp, int A, int N, int n
     }
 }
 
+// A workgroup is ONE wave and the LDS executes a wave's instructions in issue order, so hand-offs between
+// lanes need only a compiler-level ordering point -- in particular NOT a wait for outstanding global stores
+// (a workgroup-scope fence would emit s_waitcnt vmcnt(0) every tick).
 __device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ---- row fill (owning lane); `row` = this env's F bytes inside the packed image -----------------------
@@ -89,7 +92,7 @@ __device__ __forceinline__ void fill_flat(const Consts &c, const ObsArgs &o, con
     const int ix = (int)(w0 & 15u), iy = (int)((w0 >> 4) & 15u); // "imposter" = agent 0 (component.py:262,289,...)
     int k = 0;
     for (int ci = 0; ci < o.ncomp; ci++) {
-        const int comp = o.comp[ci];
+        const int comp = (int)T.comp[ci];
         switch (comp) {
         case SUSNET_F_ONEHOT_POS: // component.py:226-240
 #pragma unroll

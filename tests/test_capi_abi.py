@@ -1,0 +1,129 @@
+"""CPU-only checks of the C ABI boundary: the header compiles as plain C, the ctypes mirror has the same
+struct layouts, the library loads and exports every declared symbol, and the host-side validation of
+`susnet_create` mirrors the reference constructors' asserts (no kernel is launched here)."""
+import ctypes as C
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("sus-net_amd")
+
+
+def test_header_is_plain_c_and_matches_ctypes(pkg, tmp_path):
+    L = pkg._lib
+    prog = tmp_path / "sizes.c"
+    structs = {"susnet_config": L.Config, "susnet_layout": L.Layout, "susnet_obs_spec": L.ObsSpec,
+               "susnet_step_io": L.StepIO, "susnet_rollout_io": L.RolloutIO, "susnet_state_view": L.StateView}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "susnet.h"', "int main(void){"]
+    for name, ct in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ["return 0;}"]
+    prog.write_text("\n".join(lines))
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, ct in structs.items():
+        assert int(out[name]) == C.sizeof(ct), name
+        for fname, _ in ct._fields_:
+            assert int(out[f"{name}.{fname}"]) == getattr(ct, fname).offset, f"{name}.{fname}"
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, "include", "susnet.h")).read()
+    declared = set(re.findall(r"\b(susnet_[a-z_]+)\s*\(", header))
+    assert declared == set(pkg._lib.EXPORTS), declared ^ set(pkg._lib.EXPORTS)
+    lib = pkg._lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.susnet_abi_version() == pkg._lib.ABI_VERSION
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    L = pkg._lib
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libsusnet_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        L.lib()
+
+
+def make_cfg(L, **kw):
+    cfg = L.Config()
+    cfg.struct_bytes, cfg.abi_version = C.sizeof(L.Config), L.ABI_VERSION
+    d = dict(variant=L.VARIANT_BASE, batch=8, n_imposters=1, n_crew=2, n_jobs=4, grid_n=9, max_time_steps=1000,
+             is_action_order_random=1, shuffle_imposter_index=1, tag_reset_interval=50, rng_mode=L.RNG_PHILOX)
+    d.update(kw)
+    for k, v in d.items():
+        setattr(cfg, k, v)
+    for i in range(min(cfg.grid_n, 16)):
+        cfg.grid_rows[i] = ((1 << cfg.grid_n) - 1) & 0xFFFF
+    return cfg
+
+
+def test_create_validates_like_the_reference_constructors(pkg):
+    L = pkg._lib
+    lib = L.lib()
+    h = C.c_void_p()
+
+    def create(**kw):
+        return lib.susnet_create(C.byref(make_cfg(L, **kw)), C.byref(h))
+
+    assert create() == 0
+    lay = L.Layout()
+    assert lib.susnet_get_layout(h, C.byref(lay)) == 0
+    # base.py:82-99,209: crew 6 actions, imposter 7, Discrete(8); flattened state 3A+3J (base.py:211-232)
+    assert (lay.n_agents, lay.n_actions_crew, lay.n_actions_imposter, lay.action_space_n, lay.obs_raw_size) == (3, 6, 7, 8, 21)
+    assert lay.state_bytes % 256 == 0 and lay.batch_padded == 256
+    lib.susnet_destroy(h)
+    # base.py:243-249
+    assert create(n_imposters=0) == L.E_INVALID and b"imposter" in lib.susnet_last_error()
+    assert create(n_crew=0) == L.E_INVALID
+    assert create(n_jobs=-1) == L.E_INVALID
+    assert create(n_imposters=2, n_crew=2) == L.E_INVALID and b"more crew" in lib.susnet_last_error().lower()
+    # pred_prey.py:75-76: only n_crew > 0 is required; 1v1 allowed; n_imposters forced to 1
+    assert create(variant=L.VARIANT_ITG, n_imposters=5, n_crew=1, n_jobs=0) == 0
+    assert lib.susnet_get_layout(h, C.byref(lay)) == 0
+    assert (lay.n_agents, lay.n_actions_crew, lay.n_actions_imposter, lay.obs_raw_size) == (2, 5, 6, 6)
+    lib.susnet_destroy(h)
+    # tagging.py:35-60: A-1 extra actions per agent, Discrete(8 + A), flattened state 3A+3J+2A+1
+    assert create(variant=L.VARIANT_TAGGING, n_imposters=1, n_crew=4, n_jobs=5) == 0
+    assert lib.susnet_get_layout(h, C.byref(lay)) == 0
+    assert (lay.n_agents, lay.n_actions_crew, lay.n_actions_imposter, lay.action_space_n, lay.obs_raw_size) == (5, 10, 11, 13, 41)
+    # calls that need device buffers are refused before any launch
+    assert lib.susnet_reset(h, None, None, None) == L.E_STATE
+    lib.susnet_destroy(h)
+    # build limits
+    assert create(n_crew=16) == L.E_INVALID
+    assert create(grid_n=17) == L.E_INVALID
+    assert create(struct_bytes=4) == L.E_INVALID
+    assert create(rng_mode=0) == L.E_INVALID
+
+
+def test_obs_sizes_follow_the_reference_featurizers(pkg):
+    L = pkg._lib
+    lib = L.lib()
+    h = C.c_void_p()
+    assert lib.susnet_create(C.byref(make_cfg(L, n_crew=2, grid_n=14)), C.byref(h)) == 0
+    spec = L.ObsSpec()
+    f1, f2 = C.c_int32(), C.c_int32()
+    spec.mode, spec.dtype = L.OBS_PLANES, L.F32
+    assert lib.susnet_obs_size(h, C.byref(spec), C.byref(f1), C.byref(f2)) == 0
+    assert (f1.value, f2.value) == (5 * 14 * 14, 3 + 4)  # model_ready.py:230-247
+    spec.mode, spec.n_components = L.OBS_FLAT, 3
+    for i, c in enumerate(["onehot_pos", "alive_crew", "closest_crew"]):
+        spec.components[i] = L.FLAT_COMPONENTS[c]
+    assert lib.susnet_obs_size(h, C.byref(spec), C.byref(f1), C.byref(f2)) == 0
+    assert f1.value == 3 * 28 + 2 + 2  # 84 + 2 + 2 = 88
+    spec.components[0] = L.FLAT_COMPONENTS["room_loc"]  # 9x9 only (component.py:8-17)
+    assert lib.susnet_obs_size(h, C.byref(spec), C.byref(f1), C.byref(f2)) == L.E_INVALID
+    lib.susnet_destroy(h)

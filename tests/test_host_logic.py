@@ -1,0 +1,65 @@
+"""CPU-only tests of the Python host side (no kernels): grids, names, sharding arithmetic."""
+import importlib
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_golden
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("sus-net_amd")
+
+
+def test_grids_match_the_reference_and_the_golden_traces(pkg):
+    g9 = load_golden(f"{GOLDEN_DIR}/base_1v2_j4_s0.npz")["meta"]["grid_used"]
+    np.testing.assert_array_equal(pkg.four_room_grid(9).astype(int), np.array(g9))  # base.py:171-197
+    g9n = load_golden(f"{GOLDEN_DIR}/itg_1v1_nowalls_s0.npz")["meta"]["grid_used"]
+    np.testing.assert_array_equal(pkg.four_room_grid(9, include_walls=False).astype(int), np.array(g9n))
+    g14 = load_golden(f"{GOLDEN_DIR}/base14_1v2_j4_s0.npz")["meta"]["grid_used"]
+    np.testing.assert_array_equal(pkg.four_room_grid(14).astype(int), np.array(g14))
+    for n in (9, 11, 14, 16):
+        g = pkg.four_room_grid(n)
+        np.testing.assert_array_equal(g, g.T)  # transpose-symmetric: the grid[y, x] quirk is benign on it
+
+
+def test_metric_names_and_order_are_the_reference_ones(pkg):
+    want = load_golden(f"{GOLDEN_DIR}/base_1v2_j4_s0.npz")["meta"]["metric_order"]
+    assert [m.value for m in pkg.SusMetrics] == want  # src/metrics.py:7-20
+    assert len(want) == pkg._lib.N_METRICS
+
+
+def test_action_tables_match_the_reference(pkg):
+    env = pkg.env
+    assert [a.value for a in env.CREW_ACTIONS] == [0, 1, 2, 3, 4, 6]          # base.py:82-89
+    assert [a.value for a in env.IMPOSTER_ACTIONS] == [0, 1, 2, 3, 4, 7, 5]   # base.py:91-99
+    assert [a.value for a in env.CREW_ACTIONS_SIMPLE] == [0, 1, 2, 3, 4]      # pred_prey.py:4-10
+    assert [a.value for a in env.IMPOSTER_ACTIONS_SIMPLE] == [0, 1, 2, 3, 4, 5]  # pred_prey.py:12-19
+    assert env.Action.KILL.is_job_action and env.Action.STAY.is_move_action
+
+
+def test_shard_ranges_partition_the_batch(pkg):
+    for total, world in ((262144, 8), (65536, 1), (1000, 3), (17, 16)):
+        spans = [pkg.dist.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+            assert s0 + c0 == s1
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    assert pkg.dist.shard_range(262144, 3, 8) == (3 * 32768, 32768)  # BASELINE config 4
+
+
+def test_obs_config_validation(pkg):
+    with pytest.raises(AssertionError):
+        pkg.ObsConfig("flat", ["nope"])
+    with pytest.raises(AssertionError):
+        pkg.ObsConfig("bogus")
+    assert pkg.ObsConfig("planes").code == pkg._lib.OBS_PLANES
+
+
+def test_env_refuses_non_gpu_devices(pkg):
+    with pytest.raises(ValueError):
+        pkg.BatchedFourRoomEnv(1, 2, 2, batch=2, device="cpu")
+    with pytest.raises(AssertionError):
+        pkg.BatchedFourRoomEnv(2, 2, 2, batch=2, device="cpu")  # reference ctor assert fires first (base.py:247)
