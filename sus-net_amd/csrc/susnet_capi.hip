@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -130,12 +131,12 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
         RNG rng = make_rng<RNG>(c, s, b);
         bool done, trunc;
-        uint32_t bits = step_env<S, true>(c, T, st, e, rng, a.rewards, b, done, trunc);
+        uint32_t bits = step_env<S, true, false>(c, T, st, e, rng, a.rewards, b, done, trunc);
         if (bits) atomicOr(s.err, bits);
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
         bool jobs_changed = false;
-        if (c.auto_reset && (done || trunc)) {
+        if (__builtin_expect(c.auto_reset && (done || trunc), 0)) {
             accumulate_lifetime(c, s, b, e, trunc);
             reset_env<S>(c, T, st, tid, e, rng);
             e.flags |= FLAG_FRESH; // info counters stay readable until the next step
@@ -149,13 +150,18 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
 }
 
 // Fused random rollout: n_ticks x {sample_actions; step; auto-reset} with the state held on chip.
-template <class S>
+// OUT selects what a tick stores, at compile time (run-time optional outputs cost uniform branches on a path
+// that is instruction-fetch bound): OUT_ANY = whatever pointers are non-null / any observation mode;
+// OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
+// uint8 observation (the populate()-shaped record)
+enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2 };
+template <class S, int OUT>
 __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
     const int tid = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
-    const bool active = b < c.B;
-    const int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
+    const int64_t b0 = (int64_t)blockIdx.x * c.epw, b = b0 + tid;
+    const bool active = tid < c.epw && b < c.B;
+    const int nrows = (int)((c.B - b0) < c.epw ? (c.B - b0) : c.epw);
     const int A = S::A(c);
     typename StoreFor<S>::type st;
     Tables T = setup_lds<S>(c, smem, tid, st);
@@ -172,22 +178,24 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     for (int tick = 0; tick < a.n_ticks; tick++) {
         if (active) {
             sample_actions_env<S>(c, st, e, rng);
-            if (a.actions) {
+            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.actions != nullptr)) {
 #pragma unroll
                 for (int i = 0; i < A; i++) a.actions[tick * AB + (int64_t)i * c.B + b] = (uint8_t)st.act(i);
             }
-            RewardSink sink{a.rewards ? (void *)(a.rewards + tick * AB) : nullptr, (int64_t)c.B, 1, 0};
+            RewardSink sink{(OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.rewards)) ? (void *)(a.rewards + tick * AB) : nullptr, (int64_t)c.B, 1, 0};
             bool done, trunc;
-            step_env<S, false>(c, T, st, e, rng, sink, b, done, trunc);
-            if (a.done) a.done[(int64_t)tick * c.B + b] = done ? 1 : 0;
-            if (a.trunc) a.trunc[(int64_t)tick * c.B + b] = trunc ? 1 : 0;
-            if (done || trunc) {
+            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, b, done, trunc);
+            else step_env<S, false, false>(c, T, st, e, rng, sink, b, done, trunc);
+            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.done != nullptr)) a.done[(int64_t)tick * c.B + b] = done ? 1 : 0;
+            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.trunc != nullptr)) a.trunc[(int64_t)tick * c.B + b] = trunc ? 1 : 0;
+            if (__builtin_expect(done || trunc, 0)) {
                 accumulate_lifetime(c, s, b, e, trunc);
                 reset_env<S>(c, T, st, tid, e, rng);
                 e.flags |= FLAG_FRESH;
             }
         }
-        write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (OUT == OUT_TRAJ_RAW8) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
     }
     if (active) {
         store_env<S>(c, s, st, b, e, true);
@@ -396,6 +404,13 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     c.shuffle_imp = cfg->shuffle_imposter_index ? 1 : 0;
     c.tag_interval = cfg->tag_reset_interval;
     c.auto_reset = cfg->auto_reset ? 1 : 0;
+    // environments per wave in the fused rollout: fewer than 64 when the batch would otherwise leave SIMDs
+    // idle (an MI355X has 1024 SIMDs; below one wave per SIMD the kernel is purely latency-bound)
+    c.epw = cfg->batch >= 65536 ? 64 : cfg->batch >= 32768 ? 32 : 16;
+    if (const char *ev = getenv("SUSNET_EPW")) {
+        int v = atoi(ev);
+        if (v == 16 || v == 32 || v == 64) c.epw = v;
+    }
     c.nr_imp = cfg->variant == SUSNET_VARIANT_ITG ? 6 : 7;  // pred_prey.py:12-19 / base.py:91-99
     c.nr_crew = cfg->variant == SUSNET_VARIANT_ITG ? 5 : 6; // pred_prey.py:4-10  / base.py:82-89
     c.n_valid = 0;
@@ -672,11 +687,23 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     size_t sh = lds_bytes(env, o, true, spec == 0);
     CHECK_LDS(sh);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 g = grid_for(env), blk(kBlock);
-    if (spec == 2) hipLaunchKernelGGL((k_rollout<SpecCfg2>), g, blk, sh, st, env->c, env->s, a, o);
-    else if (spec == 3) hipLaunchKernelGGL((k_rollout<SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
-    else if (spec == 4) hipLaunchKernelGGL((k_rollout<SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
-    else hipLaunchKernelGGL((k_rollout<GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
+    const dim3 g((unsigned)((env->c.B + env->c.epw - 1) / env->c.epw)), blk(kBlock);
+    const bool all_traj = a.actions && a.rewards && a.done && a.trunc;
+    const bool none_traj = !a.actions && !a.rewards && !a.done && !a.trunc;
+    const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
+                    : (all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8) ? OUT_TRAJ_RAW8 : OUT_ANY;
+#define LAUNCH_ROLLOUT(SPEC)                                                                                       \
+    do {                                                                                                           \
+        if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, env->c, env->s, a, o); \
+        else if (out == OUT_TRAJ_RAW8)                                                                             \
+            hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, env->c, env->s, a, o);            \
+        else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, env->c, env->s, a, o);                 \
+    } while (0)
+    if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
+    else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
+    else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
+    else LAUNCH_ROLLOUT(GenericSpec);
+#undef LAUNCH_ROLLOUT
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }

@@ -53,6 +53,7 @@ struct Consts {
     int32_t A, J, N, n_imp, n_crew, variant;
     int32_t max_t, order_random, shuffle_imp, tag_interval;
     int32_t n_valid, auto_reset, nr_imp, nr_crew; // nr_* = length of the role part of agent_action_map
+    int32_t epw, pad0;                            // environments per wave in the fused rollout (64, or 32: see DESIGN.md)
     uint32_t grid_rows[SUSNET_MAX_GRID];          // bit j of row i = grid[i][j]
     uint32_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID / 4]; // np.argwhere(grid) order; bytes x | y << 4
     double dr[8];  // kill, fix, sabotage, time_step, game_end, dead_penalty, vote (reference: Python numbers)
@@ -134,7 +135,7 @@ struct PhiloxRng {
     }
     __device__ __forceinline__ uint32_t next() {
         uint64_t b = cur >> 2;
-        if (b != blk) gen(b);
+        if (__builtin_expect(b != blk, 0)) gen(b);
         uint32_t s = (uint32_t)cur & 3u;
         cur++;
         uint32_t lo = (s & 1u) ? w1 : w0, hi = (s & 1u) ? w3 : w2;
@@ -450,8 +451,12 @@ struct RewardSink {
     int64_t sa, sb;  // element strides for (agent, env)
     int32_t f64;     // store double instead of float
     template <class RT>
+    __device__ __forceinline__ void put_bound(int i, int64_t b, RT r) const { // float32 [A][B] sink
+        reinterpret_cast<float *>(ptr)[(int64_t)i * sa + b] = (float)r;
+    }
+    template <class RT>
     __device__ __forceinline__ void put(int i, int64_t b, RT r) const {
-        if (!ptr) return;
+        if (__builtin_expect(ptr == nullptr, 0)) return;
         int64_t k = (int64_t)i * sa + b * sb;
         if (f64) reinterpret_cast<double *>(ptr)[k] = (double)r;
         else reinterpret_cast<float *>(ptr)[k] = (float)r;
@@ -461,7 +466,8 @@ struct RewardSink {
 __device__ __forceinline__ void set_code(uint32_t &rc, int idx, uint32_t code) { rc = (rc & ~(3u << (2 * idx))) | (code << (2 * idx)); }
 
 // returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
-template <class S, bool VALIDATE, class RNG, class Store>
+// SINK_ON: the reward sink is known to be bound (no null check per agent)
+template <class S, bool VALIDATE, bool SINK_ON, class RNG, class Store>
 __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const RewardSink &sink,
                                              int64_t b, bool &done, bool &trunc) {
     const int A = S::A(c), J = S::J(c);
@@ -482,7 +488,14 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             return bits;
         }
     }
-    if (e.flags & FLAG_FRESH) zero_metrics(e);
+    { // lazy metrics.reset() of an auto-reset episode (select form: no branch on the stepping path)
+        const bool fresh = (e.flags & FLAG_FRESH) != 0u;
+        e.m_steps = fresh ? 0u : e.m_steps;
+        e.m_fix = fresh ? 0u : e.m_fix;
+        e.m_sab = fresh ? 0u : e.m_sab;
+        e.m_kv = fresh ? 0u : e.m_kv;
+        e.flags = fresh ? (e.flags & ~(FLAG_FRESH | FLAG_CREW_WON | FLAG_IMP_WON)) : e.flags;
+    }
     e.m_steps += 1; // base.py:366
     using RT = typename S::RT;
     uint32_t rc = 0; // 2-bit reward code per agent
@@ -493,65 +506,79 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     const bool shuffled = S::order_random(c);
     if (shuffled) shuffle_nibbles<!S::kGeneric>(rng, order, A); // base.py:372-374
 
+    // The per-agent body is written as straight-line predicated code (selects instead of branches): with one
+    // wave per SIMD a taken branch is an instruction-fetch bubble nothing else can hide, and a 64-lane wave
+    // takes almost every data-dependent branch anyway.  Only genuinely rare work (a multi-candidate kill
+    // draw, votes, episode ends) stays behind a branch.
+    const bool itg = S::variant(c) == SUSNET_VARIANT_ITG;
 #pragma unroll
     for (int k = 0; k < A; k++) {
         const int idx = shuffled ? (int)nibble(order, k) : k;
         const uint32_t a = st.act(idx);
         const uint32_t is_imp = (e.imp >> idx) & 1u;
         const uint32_t nr = n_role_actions<S>(c, is_imp);
-        if (tagging && a >= nr) {
+        bool acts = (e.alive >> idx) & 1u; // base.py:477: dead agents do nothing
+        if (tagging) {
             // tagging.py:68-75,103-110: k-th OTHER agent ascending; the actor's own aliveness is not checked
+            const bool is_tag = a >= nr;
             uint32_t target = a - nr;
-            if (target >= (uint32_t)idx) target += 1u;
-            if (!((e.used >> idx) & 1u) && ((e.alive >> target) & 1u)) {
+            target += (target >= (uint32_t)idx) ? 1u : 0u;
+            target = is_tag ? target : 0u;
+            if (is_tag && !((e.used >> idx) & 1u) && ((e.alive >> target) & 1u)) {
                 st.set_cnt((int)target, st.cnt((int)target) + 1u); // tag_counts[target] += 1
                 e.used |= 1u << idx;
             }
-            continue;
+            acts = acts && !is_tag;
         }
-        if (!((e.alive >> idx) & 1u)) continue; // base.py:477
-        const int action = role_action<S>(c, is_imp, a);
+        // role-relative index -> Action (base.py:82-99; pred_prey.py:4-19)
+        const bool is_move = acts && a <= 4u;
+        const bool is_kill = acts && is_imp && a == (itg ? 5u : 6u);
+        const bool is_sab = acts && !itg && is_imp && a == 5u;
+        const bool is_fix = acts && !itg && !is_imp && a == 5u;
         const uint32_t xy = st.xy(idx);
-        if (action <= ACT_RIGHT) { // base.py:484-487, move() 69-79
-            int x = (int)(xy & 15u), y = (int)(xy >> 4);
-            int nx = x + (action == ACT_RIGHT) - (action == ACT_LEFT);
-            int ny = y + (action == ACT_UP) - (action == ACT_DOWN);
+        { // move: base.py:484-487, move() 69-79; a == 0 (STAY) re-validates the current cell, a no-op
+            const int x = (int)(xy & 15u), y = (int)(xy >> 4);
+            const int nx = x + (a == (uint32_t)ACT_RIGHT) - (a == (uint32_t)ACT_LEFT);
+            const int ny = y + (a == (uint32_t)ACT_UP) - (a == (uint32_t)ACT_DOWN);
             // base.py:548-551: in range and grid[pos[1], pos[0]] (TRANSPOSED w.r.t. the spawn lookup)
-            bool ok = (unsigned)nx < (unsigned)c.N && (unsigned)ny < (unsigned)c.N;
-            uint32_t row = T.grid[ny & 15];
-            ok = ok && ((row >> (nx & 15)) & 1u);
-            if (ok) st.set_xy(idx, (uint32_t)nx | ((uint32_t)ny << 4));
-        } else if (action == ACT_KILL) { // base.py:490-515
+            const uint32_t row = T.grid[ny & 15];
+            const bool ok = is_move && (unsigned)nx < (unsigned)c.N && (unsigned)ny < (unsigned)c.N && ((row >> (nx & 15)) & 1u);
+            st.set_xy(idx, ok ? ((uint32_t)nx | ((uint32_t)ny << 4)) : xy);
+        }
+        { // KILL: base.py:490-515
             uint32_t cm = 0;
-            const uint32_t crew = e.alive & ~e.imp;
+            const uint32_t crew = is_kill ? (e.alive & ~e.imp) : 0u;
 #pragma unroll
-            for (int i = 0; i < A; i++)
-                if (((crew >> i) & 1u) && st.xy(i) == xy) cm |= 1u << i;
-            if (cm) {
-                uint32_t r = rng.bounded((uint32_t)__popc(cm)); // base.py:497
-                int victim = nth_set_bit(cm, r);
-                e.m_kv += 1u;                // IMP_KILLED_CREW, base.py:508
-                e.alive &= ~(1u << victim);  // base.py:511
-                set_code(rc, victim, RC_KILL); // base.py:514
-                set_code(rc, idx, RC_KILL);    // base.py:515
+            for (int i = 0; i < A; i++) cm |= (((crew >> i) & 1u) && st.xy(i) == xy) ? (1u << i) : 0u;
+            const uint32_t nc = (uint32_t)__popc(cm);
+            uint32_t r = 0;
+            if (RNG::kNumpy) {
+                if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc); // base.py:497; numpy draws nothing for a single candidate
+            } else {
+                // production protocol: one word per kill, its value only matters with several candidates
+                if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc);
+                else rng.cur += (nc == 1u) ? 1ull : 0ull;
             }
-        } else { // FIX (base.py:518-524) / SABOTAGE (527-533): first job on the cell (544-546)
-            int job = -1;
+            const bool hit = nc != 0u;
+            const int victim = hit ? nth_set_bit(cm, r) : 0;
+            e.m_kv += hit ? 1u : 0u;                      // IMP_KILLED_CREW, base.py:508
+            e.alive &= ~(hit ? (1u << victim) : 0u);      // base.py:511
+            const uint32_t m = hit ? ((3u << (2 * victim)) | (3u << (2 * idx))) : 0u;
+            rc = (rc & ~m) | (((RC_KILL << (2 * victim)) | (RC_KILL << (2 * idx))) & m); // base.py:514-515
+        }
+        if (!itg && J > 0) { // FIX (base.py:518-524) / SABOTAGE (527-533): first job on the cell (544-546)
+            uint32_t jm = 0;
 #pragma unroll
-            for (int j = J - 1; j >= 0; j--)
-                if (st.job(j) == xy) job = j;
-            if (job >= 0) {
-                const uint32_t isdone = (e.jd >> job) & 1u;
-                if (action == ACT_FIX && !isdone) {
-                    e.jd |= 1u << job;
-                    e.m_fix += 1u;
-                    set_code(rc, idx, RC_FIX);
-                } else if (action == ACT_SABOTAGE && isdone) {
-                    e.jd &= ~(1u << job);
-                    e.m_sab += 1u;
-                    set_code(rc, idx, RC_SAB);
-                }
-            }
+            for (int j = 0; j < J; j++) jm |= (st.job(j) == xy) ? (1u << j) : 0u;
+            const uint32_t jbit = jm & (0u - jm); // lowest set bit = first job index
+            const bool isdone = (e.jd & jbit) != 0u;
+            const bool fix = is_fix && jbit != 0u && !isdone;
+            const bool sab = is_sab && jbit != 0u && isdone;
+            e.jd = fix ? (e.jd | jbit) : (sab ? (e.jd & ~jbit) : e.jd);
+            e.m_fix += fix ? 1u : 0u;
+            e.m_sab += sab ? 1u : 0u;
+            const uint32_t m = (fix || sab) ? (3u << (2 * idx)) : 0u;
+            rc = (rc & ~m) | (((fix ? RC_FIX : RC_SAB) << (2 * idx)) & m);
         }
     }
 
@@ -560,7 +587,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         for (int i = 0; i < A; i++)
             if (!((e.alive >> i) & 1u)) st.set_cnt(i, 0u);
         e.timer += 1u; // tagging.py:182
-        if (e.timer >= (uint32_t)c.tag_interval) { // tagging.py:184-207
+        if (__builtin_expect(e.timer >= (uint32_t)c.tag_interval, 0)) { // tagging.py:184-207
             uint32_t best = 0, highest = st.cnt(0);
             for (int i = 1; i < A; i++) { // np.argmax: first maximum
                 uint32_t v = st.cnt(i);
@@ -606,7 +633,8 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         if (i < c.n_imp) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
         if (!((e.alive >> i) & 1u)) r = rw<RT>(c, RW_DEAD); // base.py:562
         if (!tagging && r == (RT)0) r = rw<RT>(c, RW_TSR);  // base.py:389-390 (tagging.py has no fill)
-        sink.put(i, b, r);
+        if (SINK_ON) sink.put_bound(i, b, r);
+        else sink.put(i, b, r);
     }
     // base.py:392-395: t saturates at max_time_steps - 1
     if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;

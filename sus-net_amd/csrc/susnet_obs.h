@@ -204,7 +204,7 @@ __device__ __forceinline__ void fill_planes(const Consts &c, const Store &st, co
 // ---- cooperative wave store of a packed image of `total` elements -------------------------------------
 // BYTES image, uint8 output: straight copy
 __device__ __forceinline__ void copy_bytes(const uint32_t *img, int total, uint8_t *dst, int lane) {
-    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+    if (__builtin_expect((reinterpret_cast<uintptr_t>(dst) & 15u) == 0, 1)) {
         const int vec = total & ~15;
         for (int g = lane * 16; g < vec; g += kWave * 16)
             *reinterpret_cast<uint4 *>(dst + g) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(img) + g);
@@ -254,23 +254,23 @@ __device__ __forceinline__ void expand_bits_u8(const uint32_t *img, int total, u
 template <class S, class Store>
 __device__ __forceinline__ void write_obs(const Consts &c, const ObsArgs &o, const Tables &T, const Store &st, int tid, const Env &e,
                                           bool active, int64_t b0, int nrows, int64_t tick) {
-    if (o.mode == SUSNET_OBS_NONE) return;
+    if (__builtin_expect(o.mode == SUSNET_OBS_NONE, 0)) return;
     uint32_t *seg1 = T.stage;
     uint32_t *seg2 = T.stage + o.words1;
     const bool planes = o.mode == SUSNET_OBS_PLANES;
-    if (o.mode != SUSNET_OBS_RAW) { // RAW rows are fully overwritten; the others start from zeros
+    if (__builtin_expect(o.mode != SUSNET_OBS_RAW, 0)) { // RAW rows are fully overwritten; the others start from zeros
         for (int w = tid; w < o.words1 + o.words2; w += kWave) seg1[w] = 0u;
         wave_lds_fence();
     }
     if (active) {
         uint8_t *row = reinterpret_cast<uint8_t *>(seg1) + tid * o.F;
-        if (o.mode == SUSNET_OBS_RAW) fill_raw<S>(c, st, e, row);
+        if (__builtin_expect(o.mode == SUSNET_OBS_RAW, 1)) fill_raw<S>(c, st, e, row);
         else if (o.mode == SUSNET_OBS_FLAT) fill_flat<S>(c, o, T, st, e, row);
         else fill_planes<S>(c, st, e, seg1, tid * o.F, reinterpret_cast<uint8_t *>(seg2) + tid * o.F2);
     }
     wave_lds_fence();
     const int total1 = nrows * o.F;
-    if (o.dtype == SUSNET_F32) {
+    if (__builtin_expect(o.dtype == SUSNET_F32, 0)) {
         float *d1 = reinterpret_cast<float *>(o.out) + tick * o.tick_stride + b0 * o.F;
         if (planes) {
             expand_f32<true>(seg1, total1, d1, false, tid);
@@ -288,6 +288,17 @@ __device__ __forceinline__ void write_obs(const Consts &c, const ObsArgs &o, con
         }
     }
     wave_lds_fence(); // the image is rebuilt next tick
+}
+
+// compile-time flavour of write_obs for the raw uint8 observation (the rollout's populate()-shaped record)
+template <class S, class Store>
+__device__ __forceinline__ void write_obs_raw8(const Consts &c, const ObsArgs &o, const Tables &T, const Store &st, int tid, const Env &e,
+                                               bool active, int64_t b0, int nrows, int64_t tick) {
+    uint32_t *img = T.stage;
+    if (active) fill_raw<S>(c, st, e, reinterpret_cast<uint8_t *>(img) + tid * o.F);
+    wave_lds_fence();
+    copy_bytes(img, nrows * o.F, reinterpret_cast<uint8_t *>(o.out) + tick * o.tick_stride + b0 * o.F, tid);
+    wave_lds_fence();
 }
 
 } // namespace susnet
