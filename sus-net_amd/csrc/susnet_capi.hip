@@ -175,23 +175,35 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         rng.cur = s.rng[b];
     }
     const int64_t AB = (int64_t)A * c.B;
+    // per-lane output cursors, bumped once per tick (no 64-bit index arithmetic per store)
+    const int64_t bb = active ? b : 0;
+    uint8_t *pa = a.actions ? a.actions + bb : nullptr;
+    float *pr = a.rewards ? a.rewards + bb : nullptr;
+    uint8_t *pd = a.done ? a.done + bb : nullptr;
+    uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
     for (int tick = 0; tick < a.n_ticks; tick++) {
         if (active) {
             sample_actions_env<S>(c, st, e, rng);
-            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.actions != nullptr)) {
+            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
 #pragma unroll
-                for (int i = 0; i < A; i++) a.actions[tick * AB + (int64_t)i * c.B + b] = (uint8_t)st.act(i);
+                for (int i = 0; i < A; i++) pa[(int64_t)i * c.B] = (uint8_t)st.act(i);
             }
-            RewardSink sink{(OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.rewards)) ? (void *)(a.rewards + tick * AB) : nullptr, (int64_t)c.B, 1, 0};
+            RewardSink sink{(OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pr)) ? (void *)pr : nullptr, (int64_t)c.B, 1, 0};
             bool done, trunc;
-            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, b, done, trunc);
-            else step_env<S, false, false>(c, T, st, e, rng, sink, b, done, trunc);
-            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.done != nullptr)) a.done[(int64_t)tick * c.B + b] = done ? 1 : 0;
-            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && a.trunc != nullptr)) a.trunc[(int64_t)tick * c.B + b] = trunc ? 1 : 0;
+            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, 0, done, trunc);
+            else step_env<S, false, false>(c, T, st, e, rng, sink, 0, done, trunc);
+            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pd != nullptr)) *pd = done ? 1 : 0;
+            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pt != nullptr)) *pt = trunc ? 1 : 0;
             if (__builtin_expect(done || trunc, 0)) {
                 accumulate_lifetime(c, s, b, e, trunc);
                 reset_env<S>(c, T, st, tid, e, rng);
                 e.flags |= FLAG_FRESH;
+            }
+            if (OUT != OUT_NONE) {
+                pa = pa ? pa + AB : pa;
+                pr = pr ? pr + AB : pr;
+                pd = pd ? pd + c.B : pd;
+                pt = pt ? pt + c.B : pt;
             }
         }
         if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
@@ -220,13 +232,14 @@ __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o
 }
 
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
-using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0>;  // ImposterTrainingGround 1v1, no jobs
+using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0>;  // ImposterTrainingGround 1v1, no jobs, no walls
+using SpecCfg2W = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 1>; // the same on a walled map
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
 using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
 
 static int pick_spec(const Consts &c, bool float_exact) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
-    if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return 2;
+    if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return c.n_valid == c.N * c.N ? 2 : 5;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
     return 0;
@@ -666,6 +679,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     else if (spec == 2) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg2>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 3) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 4) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
+    else if (spec == 5) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg2W>), g, blk, sh, st, env->c, env->s, a, o);
     else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
@@ -702,6 +716,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
     else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
     else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
+    else if (spec == 5) LAUNCH_ROLLOUT(SpecCfg2W);
     else LAUNCH_ROLLOUT(GenericSpec);
 #undef LAUNCH_ROLLOUT
     HIP_TRY(hipGetLastError());

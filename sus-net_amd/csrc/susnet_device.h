@@ -85,8 +85,10 @@ struct State {
 };
 
 // Compile-time specialisation of a configuration; -1 = read the value from Consts at run time.
-template <int A_, int J_, int VAR_, int ORD_>
+// WALLS_: 0 = the map has no walls (a move is valid iff it stays in range), 1/-1 = look the wall map up
+template <int A_, int J_, int VAR_, int ORD_, int WALLS_ = -1>
 struct Spec {
+    static constexpr bool kNoWalls = WALLS_ == 0;
     static constexpr bool kGeneric = A_ < 0;
     static constexpr int kA = A_, kJ = J_;
     // reward arithmetic type: double reproduces the reference's float64 chain for ANY constants; the
@@ -100,7 +102,7 @@ struct Spec {
     __device__ static __forceinline__ uint32_t nr_imp(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 6u : 7u) : (uint32_t)c.nr_imp; }
     __device__ static __forceinline__ uint32_t nr_crew(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 5u : 6u) : (uint32_t)c.nr_crew; }
 };
-using GenericSpec = Spec<-1, -1, -1, -1>;
+using GenericSpec = Spec<-1, -1, -1, -1, -1>;
 
 // ---------------------------------------------------------------------------------------------------
 // word sources
@@ -541,7 +543,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             const int nx = x + (a == (uint32_t)ACT_RIGHT) - (a == (uint32_t)ACT_LEFT);
             const int ny = y + (a == (uint32_t)ACT_UP) - (a == (uint32_t)ACT_DOWN);
             // base.py:548-551: in range and grid[pos[1], pos[0]] (TRANSPOSED w.r.t. the spawn lookup)
-            const uint32_t row = T.grid[ny & 15];
+            const uint32_t row = S::kNoWalls ? 0xffffu : T.grid[ny & 15];
             const bool ok = is_move && (unsigned)nx < (unsigned)c.N && (unsigned)ny < (unsigned)c.N && ((row >> (nx & 15)) & 1u);
             st.set_xy(idx, ok ? ((uint32_t)nx | ((uint32_t)ny << 4)) : xy);
         }
