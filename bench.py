@@ -63,6 +63,27 @@ def stored_bytes_per_step(A, J, N, obs):
     return b
 
 
+def profiled_traffic(kernel_prefix, obs):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_pmc_summary.json; separate --pmc runs for FETCH_SIZE and WRITE_SIZE, KiB units; FETCH_SIZE
+    doubled per MI355X_MICROARCH.md's gfx950 correction).  bench.py cannot collect PMCs itself."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        wkey = {"raw": "pmc_WRITE_SIZE", "planes": "pmc_W_planes", "flat": "pmc_W_flat"}.get(obs)
+        w = next(v["WRITE_SIZE"]["mean_per_launch"] for k, v in d[wkey].items() if k.startswith(kernel_prefix))
+        f = 0.0
+        if obs == "raw":
+            f = next(v["FETCH_SIZE"]["mean_per_launch"] for k, v in d["pmc_FETCH_SIZE"].items() if k.startswith(kernel_prefix))
+        return (w + 2.0 * f) * 1024.0, os.path.basename(files[-1])
+    except (KeyError, StopIteration, ValueError):
+        return None, None
+
+
 def make_env(pkg, spec, batch, seed, env_id_base, device, obs_cfg=None):
     cls = {"itg": pkg.BatchedImposterTrainingGround, "base": pkg.BatchedFourRoomEnv}[spec["cls"]]
     kw = dict(spec["kw"])
@@ -210,6 +231,9 @@ def main():
     b_alg = algorithmic_bytes_per_step(A, J, N, args.obs)
     b_stored = stored_bytes_per_step(A, J, N, args.obs)
     achieved = steps_per_launch * b_alg / avg_launch_s / 1e9
+    traffic, traffic_src = (None, None)
+    if args.mode == "fused" and args.config == "cfg2" and B == 65536 and args.ticks == 128 and world == 1:
+        traffic, traffic_src = profiled_traffic("void k_rollout", args.obs)
     line = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": res["seconds"] * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -220,7 +244,8 @@ def main():
                    "agent_steps_per_s": value * A},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": steps_per_launch * b_alg, "stored_bytes_per_launch": steps_per_launch * b_stored,
             "kernel": "k_rollout" if args.mode == "fused" else "k_step<PhiloxRng>",
             "algorithmic_bytes_per_env_step": b_alg, "stored_bytes_per_env_step": b_stored,
             "achieved_stored_GBs": steps_per_launch * b_stored / avg_launch_s / 1e9,
@@ -237,6 +262,26 @@ def main():
         line["secondary"] = {"mode": other, "value": B * k2 / r2["seconds"], "unit": "env-steps/s",
                              "ms_per_step": r2["seconds"] * 1e3 / k2, "launches_per_step": 2 if other == "step" else 1.0 / args.ticks}
         del r2
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # the same rollout with the reference's float32 feature layouts fused in (HBM-write bound)
+        line["obs_modes"] = []
+        for om in ("flat", "planes"):
+            if om == args.obs:
+                continue
+            k3 = 512
+            save_mode, save_ticks = args.mode, args.ticks
+            args.mode = "fused"
+            r3 = measure("fused", om, k3, 128)
+            args.mode = save_mode
+            per_launch_s = (r3["device_ms"] / 1e3) / r3["launches"]
+            bs = stored_bytes_per_step(A, J, N, om)
+            ba = algorithmic_bytes_per_step(A, J, N, om)
+            line["obs_modes"].append({
+                "obs": om + ("(onehot_pos)" if om == "flat" else "") + " f32", "value": B * k3 / r3["seconds"], "unit": "env-steps/s",
+                "algorithmic_bytes_per_env_step": ba, "stored_bytes_per_env_step": bs,
+                "achieved_GBs": B * args.ticks * ba / per_launch_s / 1e9, "frac": B * args.ticks * ba / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                "avg_launch_us": per_launch_s * 1e6})
+            del r3
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(spec)
     elif rank == 0:
