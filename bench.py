@@ -37,7 +37,13 @@ CONFIGS = {
                  cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536),
     "cfg4": dict(workload="cfg4: FourRoomEnv 2v6, 14x14 walled, 4 jobs, batch 32768/GPU",
                  cls="base", kw=dict(n_imposters=2, n_crew=6, n_jobs=4), n=14, A=8, J=4, batch=32768),
+    # BASELINE.json configs[4]: cfg3's env driven by the reference-architecture MLP (no checkpoints ship with the
+    # reference: seeded random init), greedy imposter + uniformly random crew, everything on the device
+    "cfg5": dict(workload="cfg5: cfg3 env (1v2, 14x14 walled, 4 jobs) driven by MLP[88,256,128,64,16,7] imposter policy "
+                          "(torch-ROCm fp32 inference) + random crew, batch 65536/GPU",
+                 cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536, policy=True),
 }
+POLICY_COMPONENTS = ["onehot_pos", "alive_crew", "closest_crew"]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -196,10 +202,21 @@ def main():
 
     def measure(mode, obs_mode, K, W):
         oc = obs_config(obs_mode) if mode == "fused" else None
-        env = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=(obs_config(obs_mode) if mode == "step" else None))
+        step_obs = obs_config(obs_mode) if mode == "step" else None
+        if mode == "policy":
+            step_obs = pkg.ObsConfig("flat", POLICY_COMPONENTS)
+        env = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=step_obs)
         env.reset()
         bufs = env.alloc_rollout(args.ticks, obs=oc) if mode == "fused" else None
-        runner = (lambda n: run_fused(env, n, args.ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
+        if mode == "policy":
+            model = pkg.policy.reference_imposter_mlp(env, POLICY_COMPONENTS, seed=0)
+            pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS)
+
+            def runner(n):
+                pr.run(n)
+                return n
+        else:
+            runner = (lambda n: run_fused(env, n, args.ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
         runner(W)
         sync_all()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -219,6 +236,9 @@ def main():
         return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, env=env)
 
     K, W = args.steps, args.warmup
+    if spec.get("policy"):
+        args.mode, args.obs = "policy", "flat"
+        K, W = min(K, 1024), min(W, 64)
     res = measure(args.mode, args.obs, K, W)
     total_steps = B * world * K
     value = total_steps / res["seconds"]
@@ -228,6 +248,8 @@ def main():
     avg_launch_s = (res["device_ms"] / 1e3) / max(1, res["launches"] if args.mode == "fused" else dominant_launches)
     if args.mode == "fused" and K % args.ticks:
         avg_launch_s = (res["device_ms"] / 1e3) / (K / args.ticks)
+    if args.mode == "policy":
+        avg_launch_s = (res["device_ms"] / 1e3) / K  # one k_step per tick; the tick also holds 5 GEMMs + glue
     b_alg = algorithmic_bytes_per_step(A, J, N, args.obs)
     b_stored = stored_bytes_per_step(A, J, N, args.obs)
     achieved = steps_per_launch * b_alg / avg_launch_s / 1e9
@@ -255,14 +277,19 @@ def main():
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
     del res
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if args.mode == "policy":
+        line["roofline"].update(achieved=None, frac=None, kernel="k_step<PhiloxRng, Spec<3,4,..>> + hipBLASLt GEMMs",
+                                note="policy loop: per-tick time is dominated by the 5 fp32 GEMMs and host launch gaps, not by "
+                                     "the env kernel; no single-kernel roofline is claimed for this config")
+        line["steps"], line["warmup"] = K, W
+    if rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy":
         other = "step" if args.mode == "fused" else "fused"
         r2 = measure(other, args.obs, 512 if other == "step" else 2048, 64)
         k2 = 512 if other == "step" else 2048
         line["secondary"] = {"mode": other, "value": B * k2 / r2["seconds"], "unit": "env-steps/s",
                              "ms_per_step": r2["seconds"] * 1e3 / k2, "launches_per_step": 2 if other == "step" else 1.0 / args.ticks}
         del r2
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy":
         # the same rollout with the reference's float32 feature layouts fused in (HBM-write bound)
         line["obs_modes"] = []
         for om in ("flat", "planes"):

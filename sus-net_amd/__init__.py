@@ -8,7 +8,9 @@ from .env import (  # noqa: F401
     Action, BatchedFourRoomEnv, BatchedFourRoomEnvWithTagging, BatchedImposterTrainingGround, ObsConfig,
     StateFields, four_room_grid,
 )
-from . import _lib, build_hip, dist  # noqa: F401
+from . import _lib, build_hip, dist, features, policy  # noqa: F401
+from .policy import MLP, PolicyRollout, RandomEquiprobable  # noqa: F401
+from .features import FlatFeaturizer, GlobalFeaturizer, PerspectiveFeaturizer  # noqa: F401
 
 # reference names (src/environment/__init__.py:1-3)
 FourRoomEnv = BatchedFourRoomEnv

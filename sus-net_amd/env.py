@@ -364,6 +364,13 @@ class BatchedFourRoomEnv:
             view.tag_reset_timer = self._timer.data_ptr()
         L.check(self.lib.susnet_export_state(self._h, C.byref(view), self._stream()))
 
+    def refresh_roles(self):
+        """Refresh ``imposter_mask`` only (one small launch); needed when ``export_state=False``."""
+        view = L.StateView()
+        view.imposter_mask = self.imposter_mask.data_ptr()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_export_state(self._h, C.byref(view), self._stream()))
+
     def _state_tuple(self):  # base.py:317-323 / 397-402
         return (self.agent_positions, self.alive_agents,
                 *([self.job_positions, self.completed_jobs] if self.n_jobs > 0 else []))

@@ -310,6 +310,21 @@ def test_observations_match_reference_feature_fixtures(pkg):
             sp, non = env.observe(pkg.ObsConfig("planes"))
             np.testing.assert_array_equal(np_(sp), g["planes_spatial"])
             np.testing.assert_array_equal(np_(non), g["planes_non_spatial"])
+            # the reference's generate_featurized_states() contract (model_ready.py:175-216, 291-306)
+            pf = pkg.PerspectiveFeaturizer(env)
+            pf.fit()
+            for i, (psp, pns) in enumerate(pf.generate_featurized_states()):
+                np.testing.assert_array_equal(np_(psp)[:, 0], g["persp_spatial"][:, i])
+                np.testing.assert_array_equal(np_(pns)[:, 0], g["persp_non_spatial"][:, i])
+            gf = pkg.GlobalFeaturizer(env)
+            gf.fit()
+            views = gf.generate_featurized_states()
+            assert len(views) == env.n_agents and views[1][1].shape[-1] == non.shape[-1] + env.n_agents
+            assert float(views[1][1][0, 0, non.shape[-1] + 1]) == 1.0
+        ff = pkg.FlatFeaturizer(env, comps)
+        ff.fit()
+        zs, fs = ff.generate_featurized_states()[0]
+        assert tuple(zs.shape) == (S, 1, 1) and np.array_equal(np_(fs)[:, 0], want)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -372,3 +387,38 @@ def test_full_batch_invariants(pkg):
     traj2 = env2.rollout(T)
     assert torch.equal(traj2["actions"], traj["actions"]) and torch.equal(traj2["rewards"], traj["rewards"])
     assert not torch.equal(jobs0, env.job_positions)  # episodes did end and respawn
+
+
+# ------------------------------------------------------------------------------------------------
+# policy in the loop (BASELINE config 5): device-side obs -> MLP -> argmax -> step, checked by replaying the
+# recorded actions through the oracle
+# ------------------------------------------------------------------------------------------------
+def test_policy_rollout_matches_oracle_on_recorded_actions(pkg, oracle_mod):
+    B, steps, seed = 512, 60, 21
+    comps = ["onehot_pos", "alive_crew", "closest_crew"]
+    name = "base_1v2_j4_14"
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False,
+                        obs=pkg.ObsConfig("flat", comps))
+    env.reset()
+    ob.reset()
+    model = pkg.policy.reference_imposter_mlp(env, comps, seed=3)
+    assert [m.in_features for m in model.model if hasattr(m, "in_features")] == [88, 256, 128, 64, 16]
+    runner = pkg.PolicyRollout(env, model, crew_model=None, components=comps)
+    for s in range(steps):
+        np.testing.assert_array_equal(np_(env.obs), ob.obs_flat(comps), err_msg=f"fused flat obs step {s}")
+        a = runner.act().clone()
+        # the imposter slot is the MLP's greedy action on the fused observation
+        want = model(torch.zeros(B, 1, 1, device=env.device), env.obs).argmax(1)
+        got = a[env.imposter_mask]
+        assert torch.equal(got, want)
+        # the env's sample_actions drew from the Philox stream: mirror the draw in the oracle
+        oa = ob.sample_actions()
+        imp = ob.export()["imp"].astype(bool)
+        oa[imp] = np_(want)
+        np.testing.assert_array_equal(np_(a), oa)
+        _, rew, done, trunc, _ = env.step(a)
+        orew, odone, otrunc, rc = ob.step(oa)
+        assert rc == 0
+        assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64))
+        np.testing.assert_array_equal(np_(done), odone.astype(bool))
+        ob.reset(mask=(odone | otrunc).astype(bool))

@@ -63,3 +63,22 @@ def test_env_refuses_non_gpu_devices(pkg):
         pkg.BatchedFourRoomEnv(1, 2, 2, batch=2, device="cpu")
     with pytest.raises(AssertionError):
         pkg.BatchedFourRoomEnv(2, 2, 2, batch=2, device="cpu")  # reference ctor assert fires first (base.py:247)
+
+
+def test_mlp_checkpoint_format_matches_reference(pkg, tmp_path):
+    """{"state_dict", "config"} with the reference's module names (src/models/dqn.py:72-103, 322-329)."""
+    import torch
+
+    m = pkg.MLP([36, 256, 128, 64, 16, 6])
+    keys = list(m.state_dict().keys())
+    assert keys[:3] == ["model.0.weight", "model.0.bias", "model.1.weight"]  # Linear, PReLU, ...
+    assert keys[-2:] == ["model.8.weight", "model.8.bias"]  # last activation dropped
+    path = tmp_path / "ckpt.pt"
+    m.dump_to_checkpoint(path)
+    ck = torch.load(path)
+    assert set(ck) == {"state_dict", "config"} and ck["config"] == {"layer_dims": [36, 256, 128, 64, 16, 6]}
+    m2 = pkg.MLP.load_from_checkpoint(path)
+    x = torch.randn(5, 1, 36)
+    assert torch.equal(m(torch.zeros(5, 1, 1), x), m2(torch.zeros(5, 1, 1), x))
+    r = pkg.RandomEquiprobable(5)(torch.zeros(7, 1))
+    assert r.shape == (7, 5) and torch.all(r.sum(1) == 1)
