@@ -160,7 +160,12 @@ def main():
     import torch.distributed as dist
 
     pkg = importlib.import_module("sus-net_amd")
-    rank, world, local = pkg.dist.init_from_env("nccl")
+    # SUSNET_BENCH_BACKEND=gloo + SUSNET_BENCH_ONE_DEVICE=1 rehearse the N > 1 control flow on a 1-GPU box
+    backend = os.environ.get("SUSNET_BENCH_BACKEND", "nccl")
+    if os.environ.get("SUSNET_BENCH_ONE_DEVICE") == "1":
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = pkg.dist.init_from_env(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
@@ -228,7 +233,7 @@ def main():
         dt = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         env.poll_errors()

@@ -60,9 +60,12 @@ def all_gather_totals(local: torch.Tensor, group=None) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()):
         return local.unsqueeze(0).clone()
     world = dist.get_world_size(group)
+    dev = local.device
+    if dist.get_backend(group) != "nccl":  # gloo rehearsals: stage through the host
+        local = local.cpu()
     out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local, group=group)
-    return out.view(world, local.numel())
+    return out.view(world, local.numel()).to(dev)
 
 
 def node_metrics(env, group=None) -> Dict[str, int]:
