@@ -181,7 +181,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     float *pr = a.rewards ? a.rewards + bb : nullptr;
     uint8_t *pd = a.done ? a.done + bb : nullptr;
     uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
+    constexpr int kRawF = S::kGeneric ? 1 : (3 * S::kA + 3 * (S::kJ > 0 ? S::kJ : 0));
+    // raw image stored one tick late (hides the LDS round trip); only while one 16-byte chunk per lane carries it
+    // (measured: with 2-3 chunks held across the tick the extra live registers cost more than the latency saved)
+    constexpr bool kPipe = (OUT == OUT_TRAJ_RAW8) && !S::kGeneric && kRawF <= 16;
+    RawPipe<kRawF> pipe;
+    const int raw_total = nrows * kRawF;
+    uint8_t *obs_dst = kPipe ? reinterpret_cast<uint8_t *>(o.out) + b0 * kRawF : nullptr;
     for (int tick = 0; tick < a.n_ticks; tick++) {
+        if (kPipe && tick > 0) pipe.preload(T.stage, raw_total, tid);
         if (active) {
             sample_actions_env<S>(c, st, e, rng);
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
@@ -207,7 +215,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             }
         }
         if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        if (OUT == OUT_TRAJ_RAW8) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (OUT == OUT_TRAJ_RAW8 && !kPipe) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (kPipe) {
+            if (tick > 0) {
+                pipe.flush(T.stage, raw_total, obs_dst, tid);
+                obs_dst += o.tick_stride;
+            }
+            wave_lds_fence();
+            if (active) fill_raw<S>(c, st, e, reinterpret_cast<uint8_t *>(T.stage) + tid * kRawF);
+            wave_lds_fence();
+        }
+    }
+    if (kPipe) { // drain: the last tick's image
+        pipe.preload(T.stage, raw_total, tid);
+        pipe.flush(T.stage, raw_total, obs_dst, tid);
     }
     if (active) {
         store_env<S>(c, s, st, b, e, true);
@@ -705,7 +726,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool all_traj = a.actions && a.rewards && a.done && a.trunc;
     const bool none_traj = !a.actions && !a.rewards && !a.done && !a.trunc;
     const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
-                    : (all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8) ? OUT_TRAJ_RAW8 : OUT_ANY;
+                    : (all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0) ? OUT_TRAJ_RAW8 : OUT_ANY;
 #define LAUNCH_ROLLOUT(SPEC)                                                                                       \
     do {                                                                                                           \
         if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, env->c, env->s, a, o); \
