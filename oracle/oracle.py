@@ -97,6 +97,9 @@ def lib():
         L.so_batch_step.restype = C.c_int
         L.so_batch_random_rollout.argtypes = [P(SoEnv), C.c_int64, C.c_int64, C.c_int, P(C.c_int64), P(C.c_double)]
         L.so_batch_random_rollout.restype = C.c_int64
+        L.so_batch_sample_actions.argtypes = [P(SoEnv), C.c_int64, C.c_void_p]
+        L.so_batch_reset_masked.argtypes = [P(SoEnv), C.c_int64, C.c_void_p]
+        L.so_batch_obs_raw.argtypes = [P(SoEnv), C.c_int64, C.c_void_p]
         L.so_batch_export.argtypes = [P(SoEnv), C.c_int64] + [C.c_void_p] * 11
         L.so_batch_export.restype = None
         L.so_obs_flat_size.argtypes = [P(SoEnv), P(C.c_int32), C.c_int]
@@ -213,13 +216,12 @@ class OracleBatch:
         if mask is None:
             self.L.so_batch_reset(self.envs, self.B, threads)
         else:
-            for b in np.nonzero(np.asarray(mask))[0]:
-                self.L.so_reset(C.byref(self.envs[int(b)]))
+            m = np.ascontiguousarray(np.asarray(mask), dtype=np.uint8)
+            self.L.so_batch_reset_masked(self.envs, self.B, m.ctypes.data)
 
     def sample_actions(self) -> np.ndarray:
         out = np.zeros((self.B, self.A), dtype=np.int32)
-        for b in range(self.B):
-            self.L.so_sample_actions(C.byref(self.envs[b]), out[b].ctypes.data_as(C.POINTER(C.c_int32)))
+        self.L.so_batch_sample_actions(self.envs, self.B, out.ctypes.data)
         return out
 
     def step(self, actions, threads=1):
@@ -337,6 +339,12 @@ class OracleBatch:
                 e.n_role_actions[i] = (6 if e.imp_mask[i] else 5) if e.cfg.variant == 1 else (7 if e.imp_mask[i] else 6)
 
     # -- observations -----------------------------------------------------------------------------
+    def obs_raw_u8(self) -> np.ndarray:
+        n = self.L.so_obs_raw_size(C.byref(self.envs[0]))
+        out = np.zeros((self.B, n), dtype=np.uint8)
+        self.L.so_batch_obs_raw(self.envs, self.B, out.ctypes.data)
+        return out
+
     def obs_raw(self) -> np.ndarray:
         n = self.L.so_obs_raw_size(C.byref(self.envs[0]))
         out = np.zeros((self.B, n), dtype=np.float64)

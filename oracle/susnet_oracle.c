@@ -557,6 +557,24 @@ int so_batch_step(so_env *envs, int64_t B, const int32_t *actions, double *rewar
     return worst;
 }
 
+void so_batch_sample_actions(so_env *envs, int64_t B, int32_t *actions /*[B][A]*/) {
+    for (int64_t b = 0; b < B; b++) so_sample_actions(&envs[b], actions + b * envs[b].A);
+}
+
+void so_batch_reset_masked(so_env *envs, int64_t B, const uint8_t *mask) {
+    for (int64_t b = 0; b < B; b++)
+        if (mask[b]) so_reset(&envs[b]);
+}
+
+void so_batch_obs_raw(const so_env *envs, int64_t B, uint8_t *out /*[B][F]*/) {
+    int F = so_obs_raw_size(&envs[0]);
+    double tmp[8 * SO_MAX_AGENTS];
+    for (int64_t b = 0; b < B; b++) {
+        so_obs_raw(&envs[b], tmp);
+        for (int k = 0; k < F; k++) out[b * F + k] = (uint8_t)tmp[k];
+    }
+}
+
 /* dense export of the batched state (test convenience; avoids per-env Python loops) */
 void so_batch_export(const so_env *envs, int64_t B, int32_t *pos, uint8_t *alive, uint8_t *imp, int32_t *jobpos,
                      uint8_t *jobdone, uint8_t *used, int32_t *counts, int32_t *timer, int32_t *t, int64_t *metrics,

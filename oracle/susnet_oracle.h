@@ -125,6 +125,9 @@ int so_sizeof_env(void);
 void so_batch_reset(so_env *envs, int64_t B, int threads);
 int so_batch_step(so_env *envs, int64_t B, const int32_t *actions /*[B][A]*/, double *rewards /*[B][A]*/,
                   uint8_t *done, uint8_t *trunc, int threads);
+void so_batch_sample_actions(so_env *envs, int64_t B, int32_t *actions);
+void so_batch_reset_masked(so_env *envs, int64_t B, const uint8_t *mask);
+void so_batch_obs_raw(const so_env *envs, int64_t B, uint8_t *out);
 void so_batch_export(const so_env *envs, int64_t B, int32_t *pos, uint8_t *alive, uint8_t *imp, int32_t *jobpos,
                      uint8_t *jobdone, uint8_t *used, int32_t *counts, int32_t *timer, int32_t *t, int64_t *metrics,
                      uint64_t *cursor);

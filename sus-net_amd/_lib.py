@@ -10,7 +10,7 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libsusnet_hip.so"
-LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
+LIB_PATH = os.environ.get("SUSNET_LIB_PATH", os.path.join(PKG_DIR, LIB_NAME))  # override: A/B experiments only
 
 ABI_VERSION = 1
 MAX_AGENTS, MAX_JOBS, MAX_GRID, N_METRICS, N_LIFETIME = 16, 16, 16, 13, 12

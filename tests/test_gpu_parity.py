@@ -240,7 +240,7 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
         np.testing.assert_array_equal(dones[s], odone.astype(bool))
         np.testing.assert_array_equal(truncs[s], otrunc.astype(bool))
         ob.reset(mask=(odone | otrunc).astype(bool))
-        np.testing.assert_array_equal(obs[s], ob.obs_raw().astype(np.uint8), err_msg=f"{name} raw obs tick {s}")
+        np.testing.assert_array_equal(obs[s], ob.obs_raw_u8(), err_msg=f"{name} raw obs tick {s}")
     env._export(full=True)
     compare_full_state(env, ob, f"{name} after rollout")
     # a second launch continues the same streams
@@ -250,6 +250,29 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
         np.testing.assert_array_equal(np_(traj2["actions"])[s].T, oa)
         orew, odone, otrunc, _ = ob.step(oa)
         ob.reset(mask=(odone | otrunc).astype(bool))
+
+
+@pytest.mark.parametrize("name,B", [("base_2v6_j4_14", 32768 + 96), ("itg_1v1_nowalls", 65536 + 32), ("base_1v2_j4_14", 40000)])
+def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B):
+    """Batches >= 32768 / 65536 run 32 / 64 environments per wave (smaller ones 16): same results."""
+    T, seed = 24, 31
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+    env.reset()
+    ob.reset(threads=0)
+    traj = env.rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    torch.cuda.synchronize()
+    acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
+    for s in range(T):
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(acts[s].T, oa, err_msg=f"{name} actions tick {s}")
+        orew, odone, otrunc, rc = ob.step(oa, threads=0)
+        assert np.array_equal(rews[s].T.astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
+        np.testing.assert_array_equal(dones[s], odone.astype(bool))
+        np.testing.assert_array_equal(truncs[s], otrunc.astype(bool))
+        ob.reset(mask=(odone | otrunc).astype(bool))
+        np.testing.assert_array_equal(obs[s], ob.obs_raw_u8(), err_msg=f"{name} raw obs tick {s}")
+    env._export(full=True)
+    compare_full_state(env, ob, f"{name} after rollout")
 
 
 # ------------------------------------------------------------------------------------------------
