@@ -8,7 +8,8 @@ from .env import (  # noqa: F401
     Action, BatchedFourRoomEnv, BatchedFourRoomEnvWithTagging, BatchedImposterTrainingGround, ObsConfig,
     StateFields, four_room_grid,
 )
-from . import _lib, build_hip, dist, features, policy  # noqa: F401
+from . import _lib, build_hip, dist, features, policy, replay  # noqa: F401
+from .replay import Batch, DeviceReplayBuffer  # noqa: F401
 from .policy import MLP, PolicyRollout, RandomEquiprobable  # noqa: F401
 from .features import FlatFeaturizer, GlobalFeaturizer, PerspectiveFeaturizer  # noqa: F401
 

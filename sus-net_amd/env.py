@@ -84,6 +84,17 @@ def four_room_grid(n: int = 9, include_walls: bool = True) -> np.ndarray:
 _TORCH_TO_SUS = {torch.uint8: L.U8, torch.int32: L.I32, torch.int64: L.I64}
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 class ObsConfig:
     """Which fused observation the kernels write next to every step / reset / rollout tick.
 
@@ -228,6 +239,16 @@ class BatchedFourRoomEnv:
         self.obs_config = obs or ObsConfig(None)
         self._obs_spec, self.obs, self.obs_non_spatial = self._make_obs(self.obs_config, 1)
         self.agent_action_map = _ActionMapView(self)
+        self._rewards_view = self._rewards.t()  # [B, A] view of the [A][B] buffer
+        self._actions_view = self._actions.t()
+        io = L.StepIO()
+        io.rewards = self._rewards.data_ptr()
+        io.rewards_dtype = L.F32 if self._rewards.dtype == torch.float32 else L.F64
+        io.rewards_layout = L.LAYOUT_AB
+        io.done, io.truncated = self._done.data_ptr(), self._trunc.data_ptr()
+        if self._obs_spec is not None:
+            io.obs = C.pointer(self._obs_spec)
+        self._step_io = io
         if random_state is not None:  # base.py:125-126
             self._reseed(random_state)
 
@@ -241,6 +262,12 @@ class BatchedFourRoomEnv:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _on_device(self):
+        """Device guard only when another device is current (the context manager costs microseconds per call)."""
+        if torch.cuda.current_device() == self.device.index:
+            return _NULL_CTX
+        return torch.cuda.device(self.device)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -392,15 +419,17 @@ class BatchedFourRoomEnv:
 
     def sample_actions(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """base.py:326-330: uniform role-valid action index per agent; returns [B, A]."""
-        with torch.cuda.device(self.device):
+        with self._on_device():
             if out is None:
-                buf, dtype, layout = self._actions, L.U8, L.LAYOUT_AB  # [A][B] in memory, returned as a [B, A] view
-            else:
-                dtype, layout, buf = self._describe_actions(out)
+                L.check(self.lib.susnet_sample_actions(self._h, self._actions.data_ptr(), L.U8, L.LAYOUT_AB, self._stream()))
+                return self._actions_view  # [A][B] in memory, returned as a [B, A] view
+            dtype, layout, buf = self._describe_actions(out)
             L.check(self.lib.susnet_sample_actions(self._h, buf.data_ptr(), dtype, layout, self._stream()))
-        return buf.t() if out is None else buf
+        return buf
 
     def _describe_actions(self, a: torch.Tensor):
+        if a is self._actions_view:
+            return L.U8, L.LAYOUT_AB, a
         A, B = self.n_agents, self.batch
         if a.dtype not in _TORCH_TO_SUS:
             a = a.to(torch.int64)
@@ -424,24 +453,18 @@ class BatchedFourRoomEnv:
             a = a.reshape(1, -1)
         assert a.shape[-1] == self.n_agents or tuple(a.shape) == (self.n_agents, self.batch), (
             f"Expected {self.n_agents} actions, got {a.shape[-1]}")  # base.py:357-359
-        with torch.cuda.device(self.device):
-            if a.device != self.device:
-                a = a.to(self.device)
-            dtype, layout, a = self._describe_actions(a)
-            io = L.StepIO()
-            io.actions, io.actions_dtype, io.actions_layout = a.data_ptr(), dtype, layout
-            io.rewards = self._rewards.data_ptr()
-            io.rewards_dtype = L.F32 if self._rewards.dtype == torch.float32 else L.F64
-            io.rewards_layout = L.LAYOUT_AB
-            io.done, io.truncated = self._done.data_ptr(), self._trunc.data_ptr()
-            if self._obs_spec is not None:
-                io.obs = C.pointer(self._obs_spec)
+        if a.device != self.device:
+            a = a.to(self.device)
+        dtype, layout, a = self._describe_actions(a)
+        io = self._step_io
+        io.actions, io.actions_dtype, io.actions_layout = a.data_ptr(), dtype, layout
+        with self._on_device():
             L.check(self.lib.susnet_step(self._h, C.byref(io), self._stream()))
             if self.export_state:
                 self._export(full=False)
             if self.check_errors:
                 self.poll_errors()
-        return self._state_tuple(), self._rewards.t(), self._done, self._trunc, self.metrics.get_metrics()
+        return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics()
 
     def step4(self, agent_actions):
         """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""
@@ -629,10 +652,15 @@ class _MetricsView:
 
     def __init__(self, env):
         self._env = env
+        self._views = None
 
     def get_metrics(self) -> Dict[SusMetrics, torch.Tensor]:
-        m = self._env._metrics
-        return {metric: m[:, i] for i, metric in enumerate(SusMetrics)}
+        # column views of the persistent [B, 13] export buffer: built once, they alias it like the reference's
+        # state arrays alias the env's (refreshed in place by every step)
+        if self._views is None:
+            m = self._env._metrics
+            self._views = {metric: m[:, i] for i, metric in enumerate(SusMetrics)}
+        return self._views
 
     @property
     def metrics(self):

@@ -1,0 +1,90 @@
+"""Device-side sequence window + replay ring: the immediate consumer of the
+environment path, kept on the GPU so that batched rollouts become training batches without host copies.
+
+Mirrors the reference's ``ReplayBuffer`` (src/replay_memory.py:11-94): same tensors and shapes
+(``states [max, T, S]`` float32, ``actions [max, A]`` int64, ``rewards [max, A]`` float32,
+``next_states [max, T, S]``, ``dones [max, 1]`` bool, ``imposters [max, n_imp]`` int16), same ring arithmetic,
+same ``sample`` (uniform with replacement over the filled part) -- but ``add_batch`` writes B transitions at a
+time and everything lives on the env's device.  ``populate`` is the batched form of ``ReplayBuffer.populate``
+(src/replay_memory.py:96-143) with the ``np.roll`` sequence window of train.py:388-389: every env keeps the
+window of its last T flattened states (O1 layout, written by the step kernel's fused raw observation); a fresh
+episode's window is filled with its first state, as the reference does after ``reset``.
+
+This module is host glue over torch tensors (no kernels of its own).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import torch
+
+Batch = namedtuple("Batch", ("states", "actions", "rewards", "next_states", "imposters", "dones"))  # replay_memory.py:6-8
+
+
+class DeviceReplayBuffer:
+    def __init__(self, max_size: int, state_size: int, trajectory_size: int, n_agents: int, n_imposters: int, device="cuda"):
+        assert max_size > 0, "Replay buffer size must be positive"
+        assert trajectory_size > 0, "Trajectory size must be positive"
+        assert state_size > 0, "State size must be positive"
+        assert n_agents > 0, "Number of agents must be positive"
+        self.max_size, self.trajectory_size, self.state_size = max_size, trajectory_size, state_size
+        self.n_agents, self.n_imposters = n_agents, n_imposters
+        dev = torch.device(device)
+        self.states = torch.empty((max_size, trajectory_size, state_size), device=dev)
+        self.actions = torch.empty((max_size, n_agents), dtype=torch.long, device=dev)
+        self.rewards = torch.empty((max_size, n_agents), device=dev)
+        self.next_states = torch.empty((max_size, trajectory_size, state_size), device=dev)
+        self.dones = torch.empty((max_size, 1), dtype=torch.bool, device=dev)
+        self.imposters = torch.empty((max_size, n_imposters), dtype=torch.int16, device=dev)
+        self.idx = 0
+        self.size = 0
+
+    def add_batch(self, state, action, reward, next_state, done, imposters) -> None:
+        """N transitions at once; equivalent to N reference ``add`` calls in row order (replay_memory.py:50-73)."""
+        n = state.shape[0]
+        if n > self.max_size:  # only the last max_size rows would survive N sequential adds
+            cut = n - self.max_size
+            state, action, reward, next_state, done, imposters = (x[cut:] for x in (state, action, reward, next_state, done, imposters))
+            self.idx = (self.idx + cut) % self.max_size
+            n = self.max_size
+        pos = (self.idx + torch.arange(n, device=self.states.device)) % self.max_size
+        self.states[pos] = state.to(self.states.dtype)
+        self.actions[pos] = action.to(torch.long)
+        self.rewards[pos] = reward.to(self.rewards.dtype)
+        self.next_states[pos] = next_state.to(self.next_states.dtype)
+        self.dones[pos] = done.reshape(n, 1).to(torch.bool)
+        self.imposters[pos] = imposters.to(torch.int16)
+        self.idx = (self.idx + n) % self.max_size
+        self.size = min(self.size + n, self.max_size)
+
+    def sample(self, batch_size) -> Batch:  # replay_memory.py:75-94
+        assert self.size > 0, "Replay buffer is empty, can't sample"
+        i = torch.randint(0, self.size, (batch_size,), device=self.states.device)
+        return Batch(states=self.states[i], actions=self.actions[i], rewards=self.rewards[i], next_states=self.next_states[i],
+                     imposters=self.imposters[i], dones=self.dones[i])
+
+    @torch.no_grad()
+    def populate(self, env, num_steps: int) -> int:
+        """Random-policy rollout into the ring: ``num_steps`` lockstep ticks of ``env`` (B transitions each).
+        ``env`` must be built with ``obs=ObsConfig('raw')`` (float32) and ``auto_reset=True``."""
+        assert env.obs_config.mode == "raw" and env.auto_reset, "populate needs the fused raw observation and auto-reset"
+        assert env.obs.shape[-1] == self.state_size
+        T = self.trajectory_size
+        env.reset()
+        window = env.obs.unsqueeze(1).repeat(1, T, 1)  # replay_memory.py:112-113: the first state T times
+        added = 0
+        for _ in range(num_steps):
+            if not env.export_state:
+                env.refresh_roles()
+            imposters = env.imposter_idxs  # roles of the acting episode (replay_memory.py:117)
+            a = env.sample_actions().clone()
+            _, rew, done, trunc, _ = env.step(a)
+            ended = done | trunc
+            nxt = torch.roll(window, shifts=-1, dims=1)  # replay_memory.py:122-127 / train.py:388-389
+            nxt[:, -1] = env.obs
+            # NOTE: with same-step auto-reset env.obs of an ended env is already the NEW episode's first state;
+            # the stored transition keeps `done` so a learner never bootstraps across the boundary.
+            self.add_batch(window, a, rew, nxt, done, imposters)
+            window = torch.where(ended.view(-1, 1, 1), env.obs.unsqueeze(1).expand(-1, T, -1), nxt)
+            added += env.batch
+        return added

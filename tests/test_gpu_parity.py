@@ -445,3 +445,27 @@ def test_policy_rollout_matches_oracle_on_recorded_actions(pkg, oracle_mod):
         assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64))
         np.testing.assert_array_equal(np_(done), odone.astype(bool))
         ob.reset(mask=(odone | otrunc).astype(bool))
+
+
+def test_device_replay_populate(pkg):
+    """Batched ReplayBuffer.populate (src/replay_memory.py:96-143): window roll, ring layout, episode boundaries."""
+    B, T = 256, 3
+    env = pkg.BatchedFourRoomEnv(1, 2, 2, batch=B, auto_reset=True, seed=8, obs=pkg.ObsConfig("raw"), max_time_steps=30)
+    S = env.flattened_state_size
+    buf = pkg.DeviceReplayBuffer(B * 50, S, T, env.n_agents, env.n_imposters, device=env.device)
+    added = buf.populate(env, 40)
+    assert added == B * 40 and buf.size == B * 40 and buf.idx == B * 40
+    n = B * 40
+    st = buf.states[:n].view(40, B, T, S)
+    nx = buf.next_states[:n].view(40, B, T, S)
+    dn = buf.dones[:n].view(40, B)
+    # the window rolls: next_states[:, :-1] == states[:, 1:] for every transition
+    assert torch.equal(nx[:, :, :-1], st[:, :, 1:])
+    # the next tick starts from the rolled window unless the episode ended (then it is T copies of the new first state)
+    rew_done = dn[:-1]
+    cont = ~rew_done
+    same = (st[1:] == nx[:-1]).flatten(2).all(-1)
+    assert bool(same[cont].float().mean() > 0.95)  # truncated episodes also restart; done-free rows continue exactly
+    fresh = st[1:][rew_done]
+    assert bool((fresh == fresh[:, :1]).all())
+    assert buf.actions[:n].max() < 7 and buf.imposters[:n].min() >= 0 and buf.imposters[:n].max() < env.n_agents

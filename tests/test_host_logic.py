@@ -82,3 +82,29 @@ def test_mlp_checkpoint_format_matches_reference(pkg, tmp_path):
     assert torch.equal(m(torch.zeros(5, 1, 1), x), m2(torch.zeros(5, 1, 1), x))
     r = pkg.RandomEquiprobable(5)(torch.zeros(7, 1))
     assert r.shape == (7, 5) and torch.all(r.sum(1) == 1)
+
+
+def test_replay_ring_equals_sequential_reference_adds(pkg):
+    """add_batch == N single adds of the reference ring (src/replay_memory.py:50-73), incl. wrap-around."""
+    import torch
+
+    T, S, A, NI, MAX = 2, 5, 3, 1, 7
+    buf = pkg.DeviceReplayBuffer(MAX, S, T, A, NI, device="cpu")
+    buf.states.zero_()  # torch.empty like the reference; zeroed here so untouched rows compare equal
+    buf.actions.zero_()
+    ref = dict(states=torch.zeros(MAX, T, S), actions=torch.zeros(MAX, A, dtype=torch.long), idx=0, size=0)
+    g = torch.Generator().manual_seed(0)
+    for n in (3, 4, 2, 9, 1):
+        st = torch.rand(n, T, S, generator=g)
+        ac = torch.randint(0, 6, (n, A), generator=g)
+        buf.add_batch(st, ac, torch.rand(n, A, generator=g), torch.rand(n, T, S, generator=g), torch.zeros(n, dtype=torch.bool),
+                      torch.zeros(n, NI, dtype=torch.int16))
+        for k in range(n):
+            ref["states"][ref["idx"]] = st[k]
+            ref["actions"][ref["idx"]] = ac[k]
+            ref["idx"] = (ref["idx"] + 1) % MAX
+            ref["size"] = min(ref["size"] + 1, MAX)
+        assert (buf.idx, buf.size) == (ref["idx"], ref["size"])
+        assert torch.equal(buf.states, ref["states"]) and torch.equal(buf.actions, ref["actions"])
+    b = buf.sample(11)
+    assert b.states.shape == (11, T, S) and b.dones.shape == (11, 1) and b.imposters.dtype == torch.int16
