@@ -189,12 +189,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def run_fused(env, n_ticks, T, bufs):
+    def run_fused(env, n_ticks, T, bufs, events=None):
         done = 0
         launches = 0
+        stream = torch.cuda.current_stream(device)
         while done < n_ticks:
             t = min(T, n_ticks - done)
-            env.rollout_into(t, bufs)
+            if events is not None:  # HIP events bracketing THIS launch on the launch stream
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                env.rollout_into(t, bufs)
+                e1.record(stream)
+                events.append((e0, e1, t))
+            else:
+                env.rollout_into(t, bufs)
             done += t
             launches += 1
         return launches
@@ -222,6 +230,7 @@ def main():
                 return n
         else:
             runner = (lambda n: run_fused(env, n, args.ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
+        per_launch_events = [] if mode == "fused" else None
         runner(W)
         sync_all()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -232,13 +241,19 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
+        per_launch_us = None
+        if per_launch_events is not None:  # outside the timed region: 16 launches, each bracketed by its own event pair
+            run_fused(env, 16 * args.ticks, args.ticks, bufs, per_launch_events)
+            torch.cuda.synchronize(device)
+            full = [a.elapsed_time(b) * 1e3 for a, b, t in per_launch_events if t == args.ticks]
+            per_launch_us = sum(full) / max(1, len(full))
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         env.poll_errors()
         metrics = pkg.dist.node_metrics(env)  # the ONE collective: all-gather of the episode totals
-        return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, env=env)
+        return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, env=env, per_launch_us=per_launch_us)
 
     K, W = args.steps, args.warmup
     if spec.get("policy"):
@@ -253,6 +268,9 @@ def main():
     avg_launch_s = (res["device_ms"] / 1e3) / max(1, res["launches"] if args.mode == "fused" else dominant_launches)
     if args.mode == "fused" and K % args.ticks:
         avg_launch_s = (res["device_ms"] / 1e3) / (K / args.ticks)
+    launch_interval_us = avg_launch_s * 1e6  # timed region / launches (what the throughput is made of)
+    if args.mode == "fused" and res.get("per_launch_us"):
+        avg_launch_s = res["per_launch_us"] / 1e6  # mean of per-launch event pairs (what rocprofv3 reports per dispatch)
     if args.mode == "policy":
         avg_launch_s = (res["device_ms"] / 1e3) / K  # one k_step per tick; the tick also holds 5 GEMMs + glue
     b_alg = algorithmic_bytes_per_step(A, J, N, args.obs)
@@ -276,8 +294,9 @@ def main():
             "kernel": "k_rollout" if args.mode == "fused" else "k_step<PhiloxRng>",
             "algorithmic_bytes_per_env_step": b_alg, "stored_bytes_per_env_step": b_stored,
             "achieved_stored_GBs": steps_per_launch * b_stored / avg_launch_s / 1e9,
-            "env_steps_per_launch": steps_per_launch, "avg_launch_us": avg_launch_s * 1e6,
-            "note": "timed with HIP events on the launch stream over the timed region; see profiles/ for rocprofv3",
+            "env_steps_per_launch": steps_per_launch, "avg_launch_us": avg_launch_s * 1e6, "launch_interval_us": launch_interval_us,
+            "note": "avg_launch_us = mean of HIP-event pairs around each launch of the timed region, on the launch stream; "
+                    "launch_interval_us = timed region / launches; rocprofv3 summaries in profiles/",
         },
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
@@ -305,7 +324,7 @@ def main():
             args.mode = "fused"
             r3 = measure("fused", om, k3, 128)
             args.mode = save_mode
-            per_launch_s = (r3["device_ms"] / 1e3) / r3["launches"]
+            per_launch_s = (r3["per_launch_us"] / 1e6) if r3.get("per_launch_us") else (r3["device_ms"] / 1e3) / r3["launches"]
             bs = stored_bytes_per_step(A, J, N, om)
             ba = algorithmic_bytes_per_step(A, J, N, om)
             line["obs_modes"].append({
