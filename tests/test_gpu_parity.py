@@ -410,6 +410,19 @@ def test_full_batch_invariants(pkg):
     traj2 = env2.rollout(T)
     assert torch.equal(traj2["actions"], traj["actions"]) and torch.equal(traj2["rewards"], traj["rewards"])
     assert not torch.equal(jobs0, env.job_positions)  # episodes did end and respawn
+    # back-to-back launches are ordered on the stream: 4 x 16 ticks == 1 x 64 ticks (the state blob written by one
+    # launch is what the next one loads)
+    env3 = pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, grid_size=14, auto_reset=True, seed=123, check_errors=False)
+    env3.reset()
+    bufs = env3.alloc_rollout(16)
+    chunks = []
+    for _ in range(4):
+        env3.rollout_into(16, bufs)
+        chunks.append(bufs["rewards"].clone())
+    assert torch.equal(torch.cat(chunks), traj["rewards"])
+    env3._export(full=True)
+    torch.cuda.synchronize()
+    assert torch.equal(env3.agent_positions, env.agent_positions) and torch.equal(env3.job_positions, env.job_positions)
 
 
 # ------------------------------------------------------------------------------------------------
