@@ -568,7 +568,7 @@ void so_batch_reset_masked(so_env *envs, int64_t B, const uint8_t *mask) {
 
 void so_batch_obs_raw(const so_env *envs, int64_t B, uint8_t *out /*[B][F]*/) {
     int F = so_obs_raw_size(&envs[0]);
-    double tmp[8 * SO_MAX_AGENTS];
+    double tmp[5 * SO_MAX_AGENTS + 3 * SO_MAX_JOBS + 1];
     for (int64_t b = 0; b < B; b++) {
         so_obs_raw(&envs[b], tmp);
         for (int k = 0; k < F; k++) out[b * F + k] = (uint8_t)tmp[k];

@@ -22,22 +22,26 @@ Batch = namedtuple("Batch", ("states", "actions", "rewards", "next_states", "imp
 
 
 class DeviceReplayBuffer:
+    # field -> (per-row shape builder, dtype): the reference's tensor zoo (replay_memory.py:33-44) as a table
+    _FIELDS = {
+        "states": (lambda o: (o.trajectory_size, o.state_size), torch.float32),
+        "actions": (lambda o: (o.n_agents,), torch.long),
+        "rewards": (lambda o: (o.n_agents,), torch.float32),
+        "next_states": (lambda o: (o.trajectory_size, o.state_size), torch.float32),
+        "dones": (lambda o: (1,), torch.bool),
+        "imposters": (lambda o: (o.n_imposters,), torch.int16),
+    }
+
     def __init__(self, max_size: int, state_size: int, trajectory_size: int, n_agents: int, n_imposters: int, device="cuda"):
-        assert max_size > 0, "Replay buffer size must be positive"
-        assert trajectory_size > 0, "Trajectory size must be positive"
-        assert state_size > 0, "State size must be positive"
-        assert n_agents > 0, "Number of agents must be positive"
+        for name, value in (("Replay buffer size", max_size), ("Trajectory size", trajectory_size), ("State size", state_size),
+                            ("Number of agents", n_agents)):
+            assert value > 0, f"{name} must be positive"
         self.max_size, self.trajectory_size, self.state_size = max_size, trajectory_size, state_size
         self.n_agents, self.n_imposters = n_agents, n_imposters
         dev = torch.device(device)
-        self.states = torch.empty((max_size, trajectory_size, state_size), device=dev)
-        self.actions = torch.empty((max_size, n_agents), dtype=torch.long, device=dev)
-        self.rewards = torch.empty((max_size, n_agents), device=dev)
-        self.next_states = torch.empty((max_size, trajectory_size, state_size), device=dev)
-        self.dones = torch.empty((max_size, 1), dtype=torch.bool, device=dev)
-        self.imposters = torch.empty((max_size, n_imposters), dtype=torch.int16, device=dev)
-        self.idx = 0
-        self.size = 0
+        for field, (shape, dtype) in self._FIELDS.items():
+            setattr(self, field, torch.empty((max_size, *shape(self)), dtype=dtype, device=dev))
+        self.idx = self.size = 0  # ring cursor and fill level
 
     def add_batch(self, state, action, reward, next_state, done, imposters) -> None:
         """N transitions at once; equivalent to N reference ``add`` calls in row order (replay_memory.py:50-73)."""

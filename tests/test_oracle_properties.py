@@ -1,0 +1,94 @@
+"""CPU-only properties of the oracle's word sources and of the production (Philox) draw protocol."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_sanitizer_selftest():
+    """AddressSanitizer + UBSan walk over every env class / word source / observation (CPU build only)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "selftest"])
+    out = subprocess.check_output([os.path.join(ROOT, "oracle", "_build", "selftest")], text=True)
+    assert "selftest ok" in out
+
+
+def _run(ob, steps):
+    ob.reset()
+    log = []
+    for _ in range(steps):
+        a = ob.sample_actions()
+        rew, done, trunc, rc = ob.step(a)
+        assert rc == 0
+        log.append((a.copy(), rew.copy(), done.copy(), trunc.copy()))
+        ob.reset(mask=(done | trunc).astype(bool))
+    return log, ob.export()
+
+
+def test_tape_of_mt19937_words_equals_mt19937_mode(oracle_mod):
+    """Feeding numpy's raw stream as a tape reproduces the seeded run: the TAPE source has numpy semantics."""
+    om = oracle_mod
+    B, steps = 6, 300
+    for variant, kw in (("base", dict(n_imposters=2, n_crew=5, n_jobs=3)), ("tagging", dict(n_imposters=1, n_crew=3, n_jobs=2, tag_reset_interval=5)),
+                        ("itg", dict(n_crew=3, n_jobs=1, shuffle_imposter_index=True))):
+        cfg = om.make_config(variant, max_time_steps=40, **kw)
+        a = om.OracleBatch(cfg, B)
+        a.seed_mt(range(100, 100 + B))
+        b = om.OracleBatch(cfg, B)
+        b.set_tapes(np.stack([om.mt19937_words(100 + i, 20000) for i in range(B)]))
+        la, ea = _run(a, steps)
+        lb, eb = _run(b, steps)
+        for x, y in zip(la, lb):
+            for u, v in zip(x, y):
+                np.testing.assert_array_equal(u, v)
+        for k in ea:
+            np.testing.assert_array_equal(ea[k], eb[k], err_msg=k)
+        assert not b.tape_overflow.any()
+
+
+def _chi2(counts, expected):
+    return float(((counts - expected) ** 2 / expected).sum())
+
+
+def test_philox_protocol_draws_are_uniform(oracle_mod):
+    """The production protocol claims the reference's DISTRIBUTIONS (uniform spawn cells with replacement,
+    uniform job cells without replacement, uniform role-valid actions, uniform imposter index): chi-square."""
+    om = oracle_mod
+    B = 20000
+    cfg = om.make_config("base", n_imposters=1, n_crew=3, n_jobs=4)
+    ob = om.OracleBatch(cfg, B)
+    ob.set_philox(2024, 0, 0)
+    ob.reset()
+    e = ob.export()
+    grid = om.reference_grid(True)
+    valid = np.argwhere(grid)
+    nv = len(valid)  # 68 free cells
+    cell_id = {tuple(v): i for i, v in enumerate(valid)}
+    # spawn cells: uniform over the 68 free cells (df = 67; 99.9 % quantile ~ 110)
+    ids = np.array([cell_id[tuple(p)] for p in e["pos"].reshape(-1, 2)])
+    c = np.bincount(ids, minlength=nv).astype(float)
+    assert _chi2(c, len(ids) / nv) < 120
+    # job cells: distinct within an env, uniform marginally
+    jid = np.array([[cell_id[tuple(p)] for p in row] for row in e["jobpos"]])
+    assert (np.sort(jid, axis=1)[:, 1:] != np.sort(jid, axis=1)[:, :-1]).all()
+    c = np.bincount(jid.ravel(), minlength=nv).astype(float)
+    assert _chi2(c, jid.size / nv) < 120
+    # imposter index uniform over the 4 agents (df = 3; 99.9 % ~ 16.3)
+    imp = e["imp"].argmax(1)
+    assert _chi2(np.bincount(imp, minlength=4).astype(float), B / 4) < 17
+    # actions: crew uniform over 6, imposter over 7
+    a = ob.sample_actions()
+    is_imp = e["imp"].astype(bool)
+    ci = np.bincount(a[is_imp], minlength=7).astype(float)
+    cc = np.bincount(a[~is_imp], minlength=6).astype(float)
+    assert a[~is_imp].max() == 5 and a[is_imp].max() == 6
+    assert _chi2(ci, ci.sum() / 7) < 23 and _chi2(cc, cc.sum() / 6) < 21
+    # streams of different envs / seeds differ, same (seed, env id) repeats
+    ob2 = om.OracleBatch(cfg, 4)
+    ob2.set_philox(2024, 0, 0)
+    ob2.reset()
+    np.testing.assert_array_equal(ob2.export()["pos"], e["pos"][:4])
+    ob2.set_philox(2025, 0, 0)
+    ob2.reset()
+    assert not np.array_equal(ob2.export()["pos"], e["pos"][:4])
