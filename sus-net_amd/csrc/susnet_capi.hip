@@ -188,25 +188,46 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     RawPipe<kRawF> pipe;
     const int raw_total = nrows * kRawF;
     uint8_t *obs_dst = kPipe ? reinterpret_cast<uint8_t *>(o.out) + b0 * kRawF : nullptr;
+#ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long seg2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); seg[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
     for (int tick = 0; tick < a.n_ticks; tick++) {
+#ifdef SUSNET_STAMPS
+        tprev = __builtin_readcyclecounter();
+#endif
         if (kPipe && tick > 0) pipe.preload(T.stage, raw_total, tid);
+        STAMP(0);
         if (active) {
             sample_actions_env<S>(c, st, e, rng);
+            STAMP(1);
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
 #pragma unroll
                 for (int i = 0; i < A; i++) pa[(int64_t)i * c.B] = (uint8_t)st.act(i);
             }
+            STAMP(2);
             RewardSink sink{(OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pr)) ? (void *)pr : nullptr, (int64_t)c.B, 1, 0};
             bool done, trunc;
+#ifdef SUSNET_STAMPS
+            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            else step_env<S, false, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+#else
             if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, 0, done, trunc);
             else step_env<S, false, false>(c, T, st, e, rng, sink, 0, done, trunc);
+#endif
+            STAMP(3);
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pd != nullptr)) *pd = done ? 1 : 0;
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pt != nullptr)) *pt = trunc ? 1 : 0;
+            STAMP(4);
             if (__builtin_expect(done || trunc, 0)) {
                 accumulate_lifetime(c, s, b, e, trunc);
                 reset_env<S>(c, T, st, tid, e, rng);
                 e.flags |= FLAG_FRESH;
             }
+            STAMP(5);
             if (OUT != OUT_NONE) {
                 pa = pa ? pa + AB : pa;
                 pr = pr ? pr + AB : pr;
@@ -225,7 +246,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             if (active) fill_raw<S>(c, st, e, reinterpret_cast<uint8_t *>(T.stage) + tid * kRawF);
             wave_lds_fence();
         }
+        STAMP(6);
     }
+#ifdef SUSNET_STAMPS
+    if (blockIdx.x == 100 && tid == 0)
+        for (int k = 0; k < 8; k++) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 2 + k, seg[k]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 10 + k, seg2[k]);
+        }
+#endif
     if (kPipe) { // drain: the last tick's image
         pipe.preload(T.stage, raw_total, tid);
         pipe.flush(T.stage, raw_total, obs_dst, tid);
@@ -253,14 +282,13 @@ __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o
 }
 
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
-using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0>;  // ImposterTrainingGround 1v1, no jobs, no walls
-using SpecCfg2W = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 1>; // the same on a walled map
+using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0>;  // ImposterTrainingGround 1v1, no jobs (any wall map)
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
 using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
 
 static int pick_spec(const Consts &c, bool float_exact) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
-    if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return c.n_valid == c.N * c.N ? 2 : 5;
+    if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return 2;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
     return 0;
@@ -452,6 +480,16 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
         c.grid_rows[i] = cfg->grid_rows[i] & ((1u << N) - 1u);
         for (int j = 0; j < N; j++)
             if ((cfg->grid_rows[i] >> j) & 1u) reinterpret_cast<uint8_t *>(c.valid_xy)[c.n_valid++] = (uint8_t)(i | (j << 4)); // argwhere order; x = i, y = j
+    }
+    { // (action row, cell) -> next cell
+        uint8_t *mt = reinterpret_cast<uint8_t *>(c.move_tab);
+        for (int a = 0; a < 6; a++)
+            for (int cell = 0; cell < 256; cell++) {
+                int x = cell & 15, y = cell >> 4;
+                int nx = x + (a == ACT_RIGHT) - (a == ACT_LEFT), ny = y + (a == ACT_UP) - (a == ACT_DOWN);
+                bool ok = a >= 1 && a <= 4 && nx >= 0 && ny >= 0 && nx < N && ny < N && ((c.grid_rows[ny] >> nx) & 1u);
+                mt[a * 256 + cell] = (uint8_t)(ok ? (nx | (ny << 4)) : cell);
+            }
     }
     if (c.n_valid < 1 || c.n_valid < J) {
         delete e;
@@ -700,7 +738,6 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     else if (spec == 2) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg2>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 3) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 4) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
-    else if (spec == 5) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg2W>), g, blk, sh, st, env->c, env->s, a, o);
     else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
@@ -737,7 +774,6 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
     else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
     else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
-    else if (spec == 5) LAUNCH_ROLLOUT(SpecCfg2W);
     else LAUNCH_ROLLOUT(GenericSpec);
 #undef LAUNCH_ROLLOUT
     HIP_TRY(hipGetLastError());

@@ -56,6 +56,9 @@ struct Consts {
     int32_t epw, pad0;                            // environments per wave in the fused rollout (64, or 32: see DESIGN.md)
     uint32_t grid_rows[SUSNET_MAX_GRID];          // bit j of row i = grid[i][j]
     uint32_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID / 4]; // np.argwhere(grid) order; bytes x | y << 4
+    // move_tab[a][cell] = cell after role-relative action a in {STAY, UP, DOWN, LEFT, RIGHT, other}: the whole of
+    // move() + _is_valid_position() (base.py:69-79, 548-551, transposed wall lookup included) as one byte lookup
+    uint32_t move_tab[6 * 64];
     double dr[8];  // kill, fix, sabotage, time_step, game_end, dead_penalty, vote (reference: Python numbers)
     float fr[8];   // the same as float32 (used by compiled-in kernels when every value is float-exact)
     uint64_t seed, env_id_base;
@@ -85,10 +88,8 @@ struct State {
 };
 
 // Compile-time specialisation of a configuration; -1 = read the value from Consts at run time.
-// WALLS_: 0 = the map has no walls (a move is valid iff it stays in range), 1/-1 = look the wall map up
-template <int A_, int J_, int VAR_, int ORD_, int WALLS_ = -1>
+template <int A_, int J_, int VAR_, int ORD_>
 struct Spec {
-    static constexpr bool kNoWalls = WALLS_ == 0;
     static constexpr bool kGeneric = A_ < 0;
     static constexpr int kA = A_, kJ = J_;
     // reward arithmetic type: double reproduces the reference's float64 chain for ANY constants; the
@@ -102,7 +103,7 @@ struct Spec {
     __device__ static __forceinline__ uint32_t nr_imp(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 6u : 7u) : (uint32_t)c.nr_imp; }
     __device__ static __forceinline__ uint32_t nr_crew(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 5u : 6u) : (uint32_t)c.nr_crew; }
 };
-using GenericSpec = Spec<-1, -1, -1, -1, -1>;
+using GenericSpec = Spec<-1, -1, -1, -1>;
 
 // ---------------------------------------------------------------------------------------------------
 // word sources
@@ -193,12 +194,13 @@ struct TapeRng {
 struct Tables {
     const uint32_t *grid;  // [16] wall map rows
     const uint8_t *valid;  // [256] spawn cells, x | y << 4
+    const uint8_t *move;   // [6][256] next cell per (action row, cell)
     uint32_t *comp;        // [16] flat observation component list (filled by the kernel when needed)
     uint8_t *perm;         // [n_valid][64] spawn permutation (TAPE resets only)
     uint32_t *stage;       // observation staging
 };
 
-constexpr uint32_t kTableWords = 16 + 64 + 16; // grid + valid + obs components
+constexpr uint32_t kTableWords = 16 + 64 + 16 + 384; // grid + valid + obs components + move table
 
 __host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic) {
     return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u);
@@ -264,6 +266,9 @@ __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int
     T.grid = smem;
     T.valid = reinterpret_cast<const uint8_t *>(smem + 16);
     T.comp = smem + 80;
+#pragma unroll
+    for (int k = 0; k < 6; k++) smem[96 + k * kBlock + tid] = c.move_tab[k * kBlock + tid];
+    T.move = reinterpret_cast<const uint8_t *>(smem + 96);
     uint32_t *rest = smem + kTableWords;
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
@@ -471,7 +476,13 @@ __device__ __forceinline__ void set_code(uint32_t &rc, int idx, uint32_t code) {
 // SINK_ON: the reward sink is known to be bound (no null check per agent)
 template <class S, bool VALIDATE, bool SINK_ON, class RNG, class Store>
 __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const RewardSink &sink,
-                                             int64_t b, bool &done, bool &trunc) {
+                                             int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr) {
+#ifdef SUSNET_STAMPS
+    unsigned long long sprev = __builtin_readcyclecounter();
+#define SSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); if (sg) sg[k] += tn - sprev; sprev = tn; } while (0)
+#else
+#define SSTAMP(k) do {} while (0)
+#endif
     const int A = S::A(c), J = S::J(c);
     const bool tagging = S::tagging(c);
     done = false;
@@ -513,6 +524,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     // takes almost every data-dependent branch anyway.  Only genuinely rare work (a multi-candidate kill
     // draw, votes, episode ends) stays behind a branch.
     const bool itg = S::variant(c) == SUSNET_VARIANT_ITG;
+    SSTAMP(0);
 #pragma unroll
     for (int k = 0; k < A; k++) {
         const int idx = shuffled ? (int)nibble(order, k) : k;
@@ -538,15 +550,11 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         const bool is_sab = acts && !itg && is_imp && a == 5u;
         const bool is_fix = acts && !itg && !is_imp && a == 5u;
         const uint32_t xy = st.xy(idx);
-        { // move: base.py:484-487, move() 69-79; a == 0 (STAY) re-validates the current cell, a no-op
-            const int x = (int)(xy & 15u), y = (int)(xy >> 4);
-            const int nx = x + (a == (uint32_t)ACT_RIGHT) - (a == (uint32_t)ACT_LEFT);
-            const int ny = y + (a == (uint32_t)ACT_UP) - (a == (uint32_t)ACT_DOWN);
-            // base.py:548-551: in range and grid[pos[1], pos[0]] (TRANSPOSED w.r.t. the spawn lookup)
-            const uint32_t row = S::kNoWalls ? 0xffffu : T.grid[ny & 15];
-            const bool ok = is_move && (unsigned)nx < (unsigned)c.N && (unsigned)ny < (unsigned)c.N && ((row >> (nx & 15)) & 1u);
-            st.set_xy(idx, ok ? ((uint32_t)nx | ((uint32_t)ny << 4)) : xy);
+        { // move: base.py:484-487 = one lookup in the (action, cell) table; rows 0 and 5 are the identity
+            const uint32_t arow = is_move ? a : 0u;
+            st.set_xy(idx, T.move[arow * 256u + xy]);
         }
+        SSTAMP(1);
         { // KILL: base.py:490-515
             uint32_t cm = 0;
             const uint32_t crew = is_kill ? (e.alive & ~e.imp) : 0u;
@@ -554,7 +562,11 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             for (int i = 0; i < A; i++) cm |= (((crew >> i) & 1u) && st.xy(i) == xy) ? (1u << i) : 0u;
             const uint32_t nc = (uint32_t)__popc(cm);
             uint32_t r = 0;
-            if (RNG::kNumpy) {
+            // with a single crew member compiled in there is never more than one candidate: no draw logic at all
+            constexpr bool kOneCrew = !S::kGeneric && S::kA == 2;
+            if (kOneCrew) {
+                if (!RNG::kNumpy) rng.cur += nc; // production protocol: one (unused) word per kill
+            } else if (RNG::kNumpy) {
                 if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc); // base.py:497; numpy draws nothing for a single candidate
             } else {
                 // production protocol: one word per kill, its value only matters with several candidates
@@ -562,12 +574,13 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
                 else rng.cur += (nc == 1u) ? 1ull : 0ull;
             }
             const bool hit = nc != 0u;
-            const int victim = hit ? nth_set_bit(cm, r) : 0;
+            const int victim = kOneCrew ? (__ffs((int)(cm | 0x10000u)) - 1) & 15 : (hit ? nth_set_bit(cm, r) : 0);
             e.m_kv += hit ? 1u : 0u;                      // IMP_KILLED_CREW, base.py:508
             e.alive &= ~(hit ? (1u << victim) : 0u);      // base.py:511
             const uint32_t m = hit ? ((3u << (2 * victim)) | (3u << (2 * idx))) : 0u;
             rc = (rc & ~m) | (((RC_KILL << (2 * victim)) | (RC_KILL << (2 * idx))) & m); // base.py:514-515
         }
+        SSTAMP(2);
         if (!itg && J > 0) { // FIX (base.py:518-524) / SABOTAGE (527-533): first job on the cell (544-546)
             uint32_t jm = 0;
 #pragma unroll
@@ -584,6 +597,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         }
     }
 
+    SSTAMP(3);
     if (tagging) {
         // tagging.py:180: tag_counts *= alive_agents
         for (int i = 0; i < A; i++)
@@ -623,6 +637,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         team += win;
     }
 
+    SSTAMP(4);
     // per-agent rewards: assignments (codes) -> _merge_rewards (base.py:553-563) -> zero fill (389-390)
 #pragma unroll
     for (int i = 0; i < A; i++) {
@@ -641,6 +656,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     // base.py:392-395: t saturates at max_time_steps - 1
     if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;
     else e.t += 1u;
+    SSTAMP(5);
     return 0;
 }
 

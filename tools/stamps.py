@@ -1,0 +1,33 @@
+"""Diagnostic: cycle shares of the fused rollout's per-tick segments (needs a -DSUSNET_STAMPS build loaded through
+SUSNET_LIB_PATH).  Never quote this build's run time; read the SHARES."""
+import importlib
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+
+pkg = importlib.import_module("sus-net_amd")
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+spec = bench.CONFIGS[cfg]
+env = bench.make_env(pkg, spec, spec["batch"], 1234, 0, torch.device("cuda:0"))
+env.reset()
+T, reps = 128, 8
+bufs = env.alloc_rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+env.rollout_into(T, bufs)
+torch.cuda.synchronize()
+env._state[16:16 + 128].zero_()
+for _ in range(reps):
+    env.rollout_into(T, bufs)
+torch.cuda.synchronize()
+seg = env._state[16:16 + 64].view(torch.int64).tolist()
+names = ["preload", "sample(philox)", "action stores", "step_env", "done/trunc stores", "episode end", "obs flush+fill", "-"]
+tot = sum(seg)
+for n, v in zip(names, seg):
+    print(f"{n:20s} {v / (T * reps):9.1f} ticks-of-s_memtime per tick  {100.0 * v / max(1, tot):5.1f} %")
+print("total per tick", tot / (T * reps))
+seg2 = env._state[80:80 + 64].view(torch.int64).tolist()
+names2 = ["prologue(fresh,align,shuffle)", "moves (all agents)", "kills (all agents)", "fix/sabotage (all agents)", "tagging+win check", "rewards+trunc", "-", "-"]
+for n, v in zip(names2, seg2):
+    print(f"  step_env: {n:32s} {v / (T * reps):9.1f}")
