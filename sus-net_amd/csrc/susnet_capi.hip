@@ -174,6 +174,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         load_env<S>(c, s, st, b, e);
         rng.cur = s.rng[b];
     }
+    LifeAcc life;
+    life.clear();
     const int64_t AB = (int64_t)A * c.B;
     // per-lane output cursors, bumped once per tick (no 64-bit index arithmetic per store)
     const int64_t bb = active ? b : 0;
@@ -182,12 +184,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     uint8_t *pd = a.done ? a.done + bb : nullptr;
     uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
     constexpr int kRawF = S::kGeneric ? 1 : (3 * S::kA + 3 * (S::kJ > 0 ? S::kJ : 0));
-    // raw image stored one tick late (hides the LDS round trip); only while one 16-byte chunk per lane carries it
-    // (measured: with 2-3 chunks held across the tick the extra live registers cost more than the latency saved)
-    constexpr bool kPipe = (OUT == OUT_TRAJ_RAW8) && !S::kGeneric && kRawF <= 16;
-    RawPipe<kRawF> pipe;
-    const int raw_total = nrows * kRawF;
-    uint8_t *obs_dst = kPipe ? reinterpret_cast<uint8_t *>(o.out) + b0 * kRawF : nullptr;
+    // compiled-in configurations write their raw uint8 row straight from registers (a few 4-byte stores per lane:
+    // the 64 rows of a wave are contiguous, so every touched line is fully written within the tick); measured
+    // faster than the LDS image + 16-byte copy-out, also when that copy-out was software-pipelined across ticks
+    constexpr bool kDirect = (OUT == OUT_TRAJ_RAW8) && !S::kGeneric;
+    uint8_t *obs_row = kDirect ? reinterpret_cast<uint8_t *>(o.out) + bb * kRawF : nullptr;
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     unsigned long long seg2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -199,7 +200,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #ifdef SUSNET_STAMPS
         tprev = __builtin_readcyclecounter();
 #endif
-        if (kPipe && tick > 0) pipe.preload(T.stage, raw_total, tid);
         STAMP(0);
         if (active) {
             sample_actions_env<S>(c, st, e, rng);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pt != nullptr)) *pt = trunc ? 1 : 0;
             STAMP(4);
             if (__builtin_expect(done || trunc, 0)) {
-                accumulate_lifetime(c, s, b, e, trunc);
+                life.add_episode(e, trunc);
                 reset_env<S>(c, T, st, tid, e, rng);
                 e.flags |= FLAG_FRESH;
             }
@@ -236,15 +236,26 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             }
         }
         if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        if (OUT == OUT_TRAJ_RAW8 && !kPipe) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        if (kPipe) {
-            if (tick > 0) {
-                pipe.flush(T.stage, raw_total, obs_dst, tid);
-                obs_dst += o.tick_stride;
+        if (OUT == OUT_TRAJ_RAW8 && !kDirect) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (kDirect) {
+            if (active) {
+                uint8_t row[kRawF + 4];
+                fill_raw<S>(c, st, e, row);
+                // 4-byte stores (naturally aligned when F % 4 == 0, otherwise the hardware's unaligned global
+                // access splits them), then a 2-byte and a 1-byte tail
+                constexpr int kW = kRawF / 4 * 4;
+#pragma unroll
+                for (int k = 0; k < kW; k += 4) {
+                    const uint32_t w = (uint32_t)row[k] | ((uint32_t)row[k + 1] << 8) | ((uint32_t)row[k + 2] << 16) | ((uint32_t)row[k + 3] << 24);
+                    __builtin_memcpy(obs_row + k, &w, 4);
+                }
+                if (kRawF - kW >= 2) {
+                    const uint16_t h = (uint16_t)(row[kW] | (row[kW + 1] << 8));
+                    __builtin_memcpy(obs_row + kW, &h, 2);
+                }
+                if ((kRawF - kW) & 1) obs_row[kRawF - 1] = row[kRawF - 1];
             }
-            wave_lds_fence();
-            if (active) fill_raw<S>(c, st, e, reinterpret_cast<uint8_t *>(T.stage) + tid * kRawF);
-            wave_lds_fence();
+            obs_row += o.tick_stride;
         }
         STAMP(6);
     }
@@ -255,13 +266,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 10 + k, seg2[k]);
         }
 #endif
-    if (kPipe) { // drain: the last tick's image
-        pipe.preload(T.stage, raw_total, tid);
-        pipe.flush(T.stage, raw_total, obs_dst, tid);
-    }
     if (active) {
         store_env<S>(c, s, st, b, e, true);
         s.rng[b] = rng.cur;
+        life.flush(c, s, b);
     }
 }
 

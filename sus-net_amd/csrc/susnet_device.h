@@ -660,6 +660,32 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     return 0;
 }
 
+// Register-resident flavour for the fused rollout (VGPRs are plentiful at one wave per SIMD): branch-free adds
+// at episode end, one flush per launch.
+struct LifeAcc {
+    uint32_t v[10];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = 0;
+    }
+    __device__ __forceinline__ void add_episode(const Env &e, bool trunc) {
+        v[SUSNET_L_EPISODES] += 1u;
+        v[SUSNET_L_CREW_WON] += (e.flags & FLAG_CREW_WON) ? 1u : 0u;
+        v[SUSNET_L_IMPOSTER_WON] += (e.flags & FLAG_IMP_WON) ? 1u : 0u;
+        v[SUSNET_L_TRUNCATED] += trunc ? 1u : 0u;
+        v[SUSNET_L_KILLS] += e.m_kv & 0xffffu;
+        v[SUSNET_L_COMPLETED_JOBS] += e.m_fix;
+        v[SUSNET_L_SABOTAGED_JOBS] += e.m_sab;
+        v[SUSNET_L_IMP_VOTED_OUT] += (e.m_kv >> 16) & 0xffu;
+        v[SUSNET_L_CREW_VOTED_OUT] += e.m_kv >> 24;
+        v[SUSNET_L_EPISODE_STEPS] += e.m_steps;
+    }
+    __device__ __forceinline__ void flush(const Consts &c, const State &s, int64_t b) const {
+#pragma unroll
+        for (int k = 0; k < 10; k++) s.life[(size_t)k * c.Bp + b] += v[k];
+    }
+};
+
 // episode bookkeeping at an auto-reset: per-env lifetime sums (the multi-GPU metrics reduction input).
 // Fire-and-forget atomics on the lane's own words: no load latency on the stepping path.
 __device__ __forceinline__ void accumulate_lifetime(const Consts &c, const State &s, int64_t b, const Env &e, bool trunc) {

@@ -301,29 +301,4 @@ __device__ __forceinline__ void write_obs_raw8(const Consts &c, const ObsArgs &o
     wave_lds_fence();
 }
 
-// Software-pipelined flavour for compiled-in configurations: the image built in tick t is read back at the START
-// of tick t+1 (so the LDS round trip hides under that tick's work) and stored at its end.  F is a compile-time
-// constant; a lane carries ceil(64 F / 1024) 16-byte chunks.
-template <int F>
-struct RawPipe {
-    static constexpr int kChunks = (kWave * F + 1023) / 1024;
-    uint4 r[kChunks];
-    __device__ __forceinline__ void preload(const uint32_t *img, int total, int lane) {
-#pragma unroll
-        for (int k = 0; k < kChunks; k++) {
-            const int g = (k * kWave + lane) * 16;
-            if (g + 15 < total) r[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(img) + g);
-        }
-    }
-    __device__ __forceinline__ void flush(const uint32_t *img, int total, uint8_t *dst, int lane) const {
-#pragma unroll
-        for (int k = 0; k < kChunks; k++) {
-            const int g = (k * kWave + lane) * 16;
-            if (g + 15 < total) *reinterpret_cast<uint4 *>(dst + g) = r[k];
-        }
-        if (__builtin_expect((total & 15) != 0, 0)) // only the last, partial wave of a batch
-            for (int g = (total & ~15) + lane; g < total; g += kWave) dst[g] = reinterpret_cast<const uint8_t *>(img)[g];
-    }
-};
-
 } // namespace susnet
