@@ -524,6 +524,17 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     // takes almost every data-dependent branch anyway.  Only genuinely rare work (a multi-candidate kill
     // draw, votes, episode ends) stays behind a branch.
     const bool itg = S::variant(c) == SUSNET_VARIANT_ITG;
+    // Compiled-in configurations look every agent's destination cell up FRONT (an agent only ever moves itself, so
+    // its cell cannot change before its turn): the A LDS reads are issued back to back instead of exposing one
+    // LDS round trip per agent inside the sequential loop.
+    PackedBytes<(S::kA > 0 ? S::kA : 1)> dest;
+    if (!S::kGeneric) {
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            const uint32_t ai = st.act(i);
+            dest.set(i, T.move[(ai <= 4u ? ai : 0u) * 256u + st.xy(i)]);
+        }
+    }
     SSTAMP(0);
 #pragma unroll
     for (int k = 0; k < A; k++) {
@@ -551,8 +562,12 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         const bool is_fix = acts && !itg && !is_imp && a == 5u;
         const uint32_t xy = st.xy(idx);
         { // move: base.py:484-487 = one lookup in the (action, cell) table; rows 0 and 5 are the identity
-            const uint32_t arow = is_move ? a : 0u;
-            st.set_xy(idx, T.move[arow * 256u + xy]);
+            if (S::kGeneric) {
+                const uint32_t arow = is_move ? a : 0u;
+                st.set_xy(idx, T.move[arow * 256u + xy]);
+            } else {
+                st.set_xy(idx, is_move ? dest.get(idx) : xy);
+            }
         }
         SSTAMP(1);
         { // KILL: base.py:490-515
