@@ -570,33 +570,37 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             }
         }
         SSTAMP(1);
-        { // KILL: base.py:490-515
+        // KILL: base.py:490-515.  Two wave-uniform gates (ballots): the candidate search runs only if some lane's
+        // agent attempts a kill this turn, the resolution only if some lane found a victim.
+        if (__builtin_amdgcn_ballot_w64(is_kill) != 0ull) {
             uint32_t cm = 0;
             const uint32_t crew = is_kill ? (e.alive & ~e.imp) : 0u;
 #pragma unroll
             for (int i = 0; i < A; i++) cm |= (((crew >> i) & 1u) && st.xy(i) == xy) ? (1u << i) : 0u;
-            const uint32_t nc = (uint32_t)__popc(cm);
-            uint32_t r = 0;
-            // with a single crew member compiled in there is never more than one candidate: no draw logic at all
-            constexpr bool kOneCrew = !S::kGeneric && S::kA == 2;
-            if (kOneCrew) {
-                if (!RNG::kNumpy) rng.cur += nc; // production protocol: one (unused) word per kill
-            } else if (RNG::kNumpy) {
-                if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc); // base.py:497; numpy draws nothing for a single candidate
-            } else {
-                // production protocol: one word per kill, its value only matters with several candidates
-                if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc);
-                else rng.cur += (nc == 1u) ? 1ull : 0ull;
+            if (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
+                const uint32_t nc = (uint32_t)__popc(cm);
+                uint32_t r = 0;
+                // with a single crew member compiled in there is never more than one candidate: no draw logic at all
+                constexpr bool kOneCrew = !S::kGeneric && S::kA == 2;
+                if (kOneCrew) {
+                    if (!RNG::kNumpy) rng.cur += nc; // production protocol: one (unused) word per kill
+                } else if (RNG::kNumpy) {
+                    if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc); // base.py:497; numpy draws nothing for a single candidate
+                } else {
+                    // production protocol: one word per kill, its value only matters with several candidates
+                    if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc);
+                    else rng.cur += (nc == 1u) ? 1ull : 0ull;
+                }
+                const bool hit = nc != 0u;
+                const int victim = kOneCrew ? (__ffs((int)(cm | 0x10000u)) - 1) & 15 : (hit ? nth_set_bit(cm, r) : 0);
+                e.m_kv += hit ? 1u : 0u;                      // IMP_KILLED_CREW, base.py:508
+                e.alive &= ~(hit ? (1u << victim) : 0u);      // base.py:511
+                const uint32_t m = hit ? ((3u << (2 * victim)) | (3u << (2 * idx))) : 0u;
+                rc = (rc & ~m) | (((RC_KILL << (2 * victim)) | (RC_KILL << (2 * idx))) & m); // base.py:514-515
             }
-            const bool hit = nc != 0u;
-            const int victim = kOneCrew ? (__ffs((int)(cm | 0x10000u)) - 1) & 15 : (hit ? nth_set_bit(cm, r) : 0);
-            e.m_kv += hit ? 1u : 0u;                      // IMP_KILLED_CREW, base.py:508
-            e.alive &= ~(hit ? (1u << victim) : 0u);      // base.py:511
-            const uint32_t m = hit ? ((3u << (2 * victim)) | (3u << (2 * idx))) : 0u;
-            rc = (rc & ~m) | (((RC_KILL << (2 * victim)) | (RC_KILL << (2 * idx))) & m); // base.py:514-515
         }
         SSTAMP(2);
-        if (!itg && J > 0) { // FIX (base.py:518-524) / SABOTAGE (527-533): first job on the cell (544-546)
+        if (!itg && J > 0 && __builtin_amdgcn_ballot_w64(is_fix || is_sab) != 0ull) { // FIX (base.py:518-524) / SABOTAGE (527-533): first job on the cell (544-546)
             uint32_t jm = 0;
 #pragma unroll
             for (int j = 0; j < J; j++) jm |= (st.job(j) == xy) ? (1u << j) : 0u;
