@@ -512,6 +512,21 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
         // integers below 2^20: every sum the step forms is exact in float32, signed zeros included
         if (!(rewards[k] == (double)(long long)rewards[k] && rewards[k] > -1048576.0 && rewards[k] < 1048576.0)) e->float_exact = false;
     }
+    for (int t = 0; t < 3; t++) // reward table: [win none/crew/imposter][index < n_imposters][dead][assignment code]
+        for (int neg = 0; neg < 2; neg++)
+            for (int dd = 0; dd < 2; dd++)
+                for (int code = 0; code < 4; code++) {
+                    double r = 0.0;                                    // base.py:369
+                    if (code == RC_KILL) r = rewards[0];               // base.py:514-515
+                    else if (code == RC_FIX) r = rewards[1];           // base.py:523
+                    else if (code == RC_SAB) r = -1.0 * rewards[2];    // base.py:532
+                    const double team = t == 0 ? 0.0 : (t == 1 ? rewards[4] : -1.0 * rewards[4]); // base.py:435,446
+                    r += team;                                         // base.py:557
+                    if (neg) r *= -1.0;                                // base.py:559
+                    if (dd) r = dead;                                  // base.py:562
+                    if (r == 0.0) r = rewards[3];                      // base.py:389-390
+                    c.rew_tab[t * 16 + neg * 8 + dd * 4 + code] = (float)r;
+                }
     c.seed = cfg->seed; c.env_id_base = cfg->env_id_base;
 
     // state blob layout (every array 256-byte aligned; row stride Bp)

@@ -61,6 +61,9 @@ struct Consts {
     uint32_t move_tab[6 * 64];
     double dr[8];  // kill, fix, sabotage, time_step, game_end, dead_penalty, vote (reference: Python numbers)
     float fr[8];   // the same as float32 (used by compiled-in kernels when every value is float-exact)
+    // reward of one agent as a table over (win: none/crew/imposter, index < n_imposters, dead, assignment code):
+    // assignments -> _merge_rewards -> zero fill (base.py:514-515,523,532,553-563,389-390) evaluated on the host
+    float rew_tab[48];
     uint64_t seed, env_id_base;
 };
 enum : int { RW_KILL = 0, RW_FIX = 1, RW_SAB = 2, RW_TSR = 3, RW_END = 4, RW_DEAD = 5, RW_VOTE = 6 };
@@ -196,11 +199,12 @@ struct Tables {
     const uint8_t *valid;  // [256] spawn cells, x | y << 4
     const uint8_t *move;   // [6][256] next cell per (action row, cell)
     uint32_t *comp;        // [16] flat observation component list (filled by the kernel when needed)
+    const float *rew;      // [48] reward table (non-tagging variants)
     uint8_t *perm;         // [n_valid][64] spawn permutation (TAPE resets only)
     uint32_t *stage;       // observation staging
 };
 
-constexpr uint32_t kTableWords = 16 + 64 + 16 + 384; // grid + valid + obs components + move table
+constexpr uint32_t kTableWords = 16 + 64 + 16 + 384 + 64; // grid + valid + obs components + move table + rewards
 
 __host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic) {
     return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u);
@@ -269,6 +273,8 @@ __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int
 #pragma unroll
     for (int k = 0; k < 6; k++) smem[96 + k * kBlock + tid] = c.move_tab[k * kBlock + tid];
     T.move = reinterpret_cast<const uint8_t *>(smem + 96);
+    if (tid < 48) reinterpret_cast<float *>(smem + 480)[tid] = c.rew_tab[tid];
+    T.rew = reinterpret_cast<const float *>(smem + 480);
     uint32_t *rest = smem + kTableWords;
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
@@ -642,35 +648,50 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     }
 
     // check_win_condition: base.py:409-460 / pred_prey.py:78-99
+    uint32_t wsel = 0; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
     {
         const int alive_imp = __popc(e.alive & e.imp), alive_all = __popc(e.alive), done_jobs = __popc(e.jd);
         RT win = 0;
         const RT r_end = rw<RT>(c, RW_END);
         if (S::variant(c) == SUSNET_VARIANT_ITG) {
-            if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = r_end; }
-            else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; win = (RT)-1 * r_end; }
+            if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = r_end; wsel = 16u; }
+            else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; win = (RT)-1 * r_end; wsel = 32u; }
         } else {
-            if (alive_imp == 0 || done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = r_end; }
-            else if (alive_all - alive_imp <= alive_imp) { done = true; e.flags |= FLAG_IMP_WON; win = (RT)-1 * r_end; }
+            if (alive_imp == 0 || done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; win = r_end; wsel = 16u; }
+            else if (alive_all - alive_imp <= alive_imp) { done = true; e.flags |= FLAG_IMP_WON; win = (RT)-1 * r_end; wsel = 32u; }
         }
         team += win;
     }
 
     SSTAMP(4);
     // per-agent rewards: assignments (codes) -> _merge_rewards (base.py:553-563) -> zero fill (389-390)
+    if (!S::kGeneric && !tagging) {
+        // compiled-in, non-tagging: one lookup per agent in the host-evaluated table (all reads issued back to back)
+        const uint32_t tsel = wsel;
 #pragma unroll
-    for (int i = 0; i < A; i++) {
-        uint32_t code = (rc >> (2 * i)) & 3u;
-        RT r = tagging ? (RT)1 * rw<RT>(c, RW_TSR) : (RT)0; // tagging.py:162 / base.py:369
-        if (code == RC_KILL) r = rw<RT>(c, RW_KILL);
-        else if (code == RC_FIX) r = rw<RT>(c, RW_FIX);
-        else if (code == RC_SAB) r = (RT)-1 * rw<RT>(c, RW_SAB);
-        r += team;
-        if (i < c.n_imp) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
-        if (!((e.alive >> i) & 1u)) r = rw<RT>(c, RW_DEAD); // base.py:562
-        if (!tagging && r == (RT)0) r = rw<RT>(c, RW_TSR);  // base.py:389-390 (tagging.py has no fill)
-        if (SINK_ON) sink.put_bound(i, b, r);
-        else sink.put(i, b, r);
+        for (int i = 0; i < A; i++) {
+            const uint32_t code = (rc >> (2 * i)) & 3u;
+            const uint32_t dead = ((e.alive >> i) & 1u) ? 0u : 4u;
+            const uint32_t neg = (i < c.n_imp) ? 8u : 0u;
+            const float r = T.rew[tsel + neg + dead + code];
+            if (SINK_ON) sink.put_bound(i, b, r);
+            else sink.put(i, b, r);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            uint32_t code = (rc >> (2 * i)) & 3u;
+            RT r = tagging ? (RT)1 * rw<RT>(c, RW_TSR) : (RT)0; // tagging.py:162 / base.py:369
+            if (code == RC_KILL) r = rw<RT>(c, RW_KILL);
+            else if (code == RC_FIX) r = rw<RT>(c, RW_FIX);
+            else if (code == RC_SAB) r = (RT)-1 * rw<RT>(c, RW_SAB);
+            r += team;
+            if (i < c.n_imp) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
+            if (!((e.alive >> i) & 1u)) r = rw<RT>(c, RW_DEAD); // base.py:562
+            if (!tagging && r == (RT)0) r = rw<RT>(c, RW_TSR);  // base.py:389-390 (tagging.py has no fill)
+            if (SINK_ON) sink.put_bound(i, b, r);
+            else sink.put(i, b, r);
+        }
     }
     // base.py:392-395: t saturates at max_time_steps - 1
     if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;

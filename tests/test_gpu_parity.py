@@ -203,6 +203,25 @@ def test_hip_matches_oracle_philox_autoreset(pkg, oracle_mod, name):
     assert life[0] == episodes, "lifetime episode count"
 
 
+@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "base_1v2_j4_14", "base_2v6_j4_14"])
+def test_hip_matches_oracle_without_reset_after_done(pkg, oracle_mod, name):
+    """Callers may keep stepping a finished episode (the reference allows it): compiled-in kernels included."""
+    B, steps, seed = 512, 220, 13
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=False, check_errors=False)
+    env.reset()
+    ob.reset()
+    for s in range(steps):
+        a = env.sample_actions().clone()
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(np_(a), oa)
+        _, rew, done, trunc, _ = env.step(a)
+        orew, odone, otrunc, rc = ob.step(oa)
+        assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards step {s}"
+        np.testing.assert_array_equal(np_(done), odone.astype(bool))
+        np.testing.assert_array_equal(np_(env._metrics), ob.export()["metrics"])
+    compare_full_state(env, ob, f"{name} coasting")
+
+
 def test_sharding_is_invisible(pkg, oracle_mod):
     """Env b of a shard with env_id_base = k behaves exactly as env k + b of one big batch."""
     name, B, seed = "base_2v6_j4_14", 1024, 5
