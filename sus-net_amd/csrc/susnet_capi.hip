@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(Consts c, State s, const uint8
     const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
     const bool active = b < c.B;
     LdsStore st;
-    Tables T = setup_lds<S>(c, smem, tid, st);
+    Tables T = setup_lds<S, false>(c, smem, tid, st);
     if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
     wave_lds_fence();
     Env e = {};
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out,
     const int tid = threadIdx.x;
     const int64_t b = (int64_t)blockIdx.x * kBlock + tid;
     LdsStore st;
-    setup_lds<S>(c, smem, tid, st);
+    setup_lds<S, false>(c, smem, tid, st);
     if (b >= c.B) return;
     Env e = {};
     load_env<S>(c, s, st, b, e);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o
     const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
     const bool active = b < c.B;
     LdsStore st;
-    Tables T = setup_lds<S>(c, smem, tid, st);
+    Tables T = setup_lds<S, false>(c, smem, tid, st);
     if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
     wave_lds_fence();
     Env e = {};

@@ -262,7 +262,8 @@ template <>
 struct StoreFor<GenericSpec> { using type = LdsStore; };
 
 // Fill the wave-shared tables (all 64 lanes take part) and carve the rest of the dynamic LDS.
-template <class S>
+// STEP_TABLES: also load the move and reward tables (kernels that step); the others only need grid + spawn cells
+template <class S, bool STEP_TABLES = true>
 __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
     Tables T;
     if (tid < SUSNET_MAX_GRID) smem[tid] = c.grid_rows[tid];
@@ -270,10 +271,12 @@ __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int
     T.grid = smem;
     T.valid = reinterpret_cast<const uint8_t *>(smem + 16);
     T.comp = smem + 80;
+    if (STEP_TABLES) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) smem[96 + k * kBlock + tid] = c.move_tab[k * kBlock + tid];
+        for (int k = 0; k < 6; k++) smem[96 + k * kBlock + tid] = c.move_tab[k * kBlock + tid];
+        if (tid < 48) reinterpret_cast<float *>(smem + 480)[tid] = c.rew_tab[tid];
+    }
     T.move = reinterpret_cast<const uint8_t *>(smem + 96);
-    if (tid < 48) reinterpret_cast<float *>(smem + 480)[tid] = c.rew_tab[tid];
     T.rew = reinterpret_cast<const float *>(smem + 480);
     uint32_t *rest = smem + kTableWords;
     st.init(rest, c.A, c.J, tid);
