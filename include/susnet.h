@@ -210,8 +210,12 @@ int susnet_get_layout(const susnet_env *env, susnet_layout *out);
 int susnet_bind_state(susnet_env *env, void *state_blob, uint64_t bytes, void *stream);
 /* TAPE mode: per-env raw 32-bit words, tape[b][0..words_per_env); cursors restart at 0. */
 int susnet_bind_tape(susnet_env *env, const uint32_t *tape, int64_t words_per_env);
-/* PHILOX mode: reseed / reposition every env's stream. */
+/* PHILOX mode: reseed / reposition every env's stream (also rewinds the handle's tick counter to 0). */
 int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void *stream);
+/* PHILOX mode draws agent actions from a second stream indexed by the number of steps the handle has taken
+ * ("tick"; advanced by susnet_step / susnet_rollout, NOT by susnet_sample_actions -- sampling twice before a
+ * step returns the same actions).  Set and/or read it (either pointer may be NULL). */
+int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get);
 
 int susnet_reset(susnet_env *env, const uint8_t *mask /* [B] or NULL = all */, const susnet_obs_spec *obs,
                  void *stream);

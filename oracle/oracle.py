@@ -40,7 +40,7 @@ class SoRng(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("mt", C.c_uint32 * 624), ("mti", C.c_int32), ("tape", C.POINTER(C.c_uint32)),
         ("tape_len", C.c_int64), ("seed", C.c_uint64), ("env_id", C.c_uint64), ("cursor", C.c_uint64),
-        ("overflow", C.c_int32),
+        ("tick", C.c_uint64), ("overflow", C.c_int32),
     ]
 
 
@@ -82,6 +82,7 @@ def lib():
         L.so_seed_mt.argtypes = [P(SoEnv), C.c_uint32]
         L.so_set_tape.argtypes = [P(SoEnv), P(C.c_uint32), C.c_int64]
         L.so_set_philox.argtypes = [P(SoEnv), C.c_uint64, C.c_uint64, C.c_uint64]
+        L.so_set_tick.argtypes = [P(SoEnv), C.c_uint64]
         L.so_philox4x32_10.argtypes = [P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
         L.so_next_u32.argtypes = [P(SoEnv)]
         L.so_next_u32.restype = C.c_uint32
@@ -202,6 +203,10 @@ class OracleBatch:
     def set_philox(self, seed: int, env_id_base: int = 0, cursor: int = 0):
         for b in range(self.B):
             self.L.so_set_philox(C.byref(self.envs[b]), seed, env_id_base + b, cursor)
+
+    def set_tick(self, tick: int):
+        for b in range(self.B):
+            self.L.so_set_tick(C.byref(self.envs[b]), tick)
 
     def raw_words(self, n: int) -> np.ndarray:
         """Draw n raw words from every env's source (advances it)."""

@@ -84,6 +84,18 @@ void so_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
     for (int i = 0; i < 4; i++) out[i] = c[i];
 }
 
+/* Two streams share the key and the env id: the per-env EVENT stream (reset / step-internal draws; tag 0) and the
+ * ACTION stream (tag bit 31 of counter word 1), whose word index is tick * A + agent with `tick` the number of
+ * steps taken -- identical for all envs stepped in lockstep, so a wave generates action blocks under uniform
+ * control flow and every generated word is used. */
+#define SO_ACTION_STREAM_TAG 0x80000000u
+static uint32_t philox_word_tagged(uint64_t seed, uint64_t env_id, uint64_t cursor, uint32_t tag) {
+    uint64_t block = cursor >> 2;
+    uint32_t c[4] = {(uint32_t)block, (uint32_t)(block >> 32) | tag, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return c[cursor & 3];
+}
+
 static uint32_t philox_word(uint64_t seed, uint64_t env_id, uint64_t cursor) {
     uint64_t block = cursor >> 2;
     uint32_t c[4] = {(uint32_t)block, (uint32_t)(block >> 32), (uint32_t)env_id, (uint32_t)(env_id >> 32)};
@@ -135,7 +147,10 @@ void so_set_philox(so_env *e, uint64_t seed, uint64_t env_id, uint64_t cursor) {
     e->rng.env_id = env_id;
     e->rng.cursor = cursor;
     e->rng.overflow = 0;
+    e->rng.tick = 0;
 }
+
+void so_set_tick(so_env *e, uint64_t tick) { e->rng.tick = tick; }
 
 /* numpy legacy bounded draw on [0, max]: smallest all-ones mask >= max, reject until <= max.
  * max == 0 consumes nothing (observed: choice([x]) / shuffle of one item draw no word). */
@@ -327,7 +342,17 @@ void so_reset(so_env *e) {
 
 /* base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order */
 void so_sample_actions(so_env *e, int32_t *actions) {
-    draw_align(e);
+    if (e->rng.kind == SO_RNG_PHILOX) {
+        /* production protocol: agent i's action at step `tick` is word tick * W + i of the action stream; sampling
+         * does not advance anything (the step does), so repeated calls before a step return the same actions */
+        /* a tick owns W words: 2 when A <= 2, A rounded up to a multiple of 4 otherwise (static word assignment) */
+        const uint64_t W = e->A <= 2 ? 2u : (uint64_t)((e->A + 3) & ~3);
+        for (int i = 0; i < e->A; i++) {
+            uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * W + (uint64_t)i, SO_ACTION_STREAM_TAG);
+            actions[i] = (int)(((uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i)) >> 32);
+        }
+        return;
+    }
     for (int i = 0; i < e->A; i++) actions[i] = draw_bounded(e, so_n_actions(e, i));
 }
 
@@ -513,6 +538,7 @@ int so_step(so_env *e, const int32_t *actions, double *rewards, int32_t *done_ou
     if (e->t == e->cfg.max_time_steps - 1) truncated = 1; /* base.py:392-395: t saturates */
     else e->t += 1;
 
+    e->rng.tick += 1; /* production action stream: one tick per step taken */
     if (rewards)
         for (int i = 0; i < A; i++) rewards[i] = e->rewards[i];
     if (done_out) *done_out = done;

@@ -78,6 +78,7 @@ typedef struct so_rng {
     uint64_t seed;    /* philox key */
     uint64_t env_id;  /* philox counter hi */
     uint64_t cursor;  /* words consumed so far (all kinds) */
+    uint64_t tick;    /* steps taken: index of the production ACTION stream */
     int32_t overflow; /* tape exhausted */
 } so_rng;
 
@@ -113,6 +114,7 @@ int so_env_init(so_env *e, const so_config *cfg);
 void so_seed_mt(so_env *e, uint32_t seed);                        /* np.random.seed(seed) */
 void so_set_tape(so_env *e, const uint32_t *words, int64_t n_words);
 void so_set_philox(so_env *e, uint64_t seed, uint64_t env_id, uint64_t cursor);
+void so_set_tick(so_env *e, uint64_t tick);
 void so_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]); /* raw block (KAT) */
 uint32_t so_next_u32(so_env *e);                                  /* one raw word */
 void so_reset(so_env *e);                                         /* base.py:251 / tagging.py:62 */

@@ -30,7 +30,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 # every symbol include/susnet.h declares
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
-    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_reset", "susnet_sample_actions", "susnet_step",
+    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_step",
     "susnet_rollout", "susnet_observe", "susnet_obs_size", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_poll_errors",
 ]
@@ -139,6 +139,7 @@ def lib():
     L.susnet_bind_state.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.susnet_bind_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.susnet_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.susnet_tick.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
     L.susnet_reset.argtypes = [C.c_void_p, C.c_void_p, P(ObsSpec), C.c_void_p]
     L.susnet_sample_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.susnet_step.argtypes = [C.c_void_p, P(StepIO), C.c_void_p]

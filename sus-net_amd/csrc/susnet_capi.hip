@@ -27,6 +27,7 @@ struct StepArgs {
 
 struct RolloutArgs {
     int32_t n_ticks;
+    uint64_t tick_base; // steps this handle has taken before the launch (index of the action stream)
     uint8_t *actions; // [T][A][B]
     float *rewards;   // [T][A][B]
     uint8_t *done, *trunc; // [T][B]
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(Consts c, State s, const uint8
 }
 
 template <class RNG>
-__global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out, int32_t dtype, int64_t sa, int64_t sb) {
+__global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out, int32_t dtype, int64_t sa, int64_t sb, uint64_t tick) {
     using S = GenericSpec;
     extern __shared__ uint32_t smem[];
     const int tid = threadIdx.x;
@@ -108,7 +109,9 @@ __global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out,
     Env e = {};
     load_env<S>(c, s, st, b, e);
     RNG rng = make_rng<RNG>(c, s, b);
-    sample_actions_env<S>(c, st, e, rng);
+    ActionStream as;
+    as.init();
+    sample_actions_env<S>(c, st, e, rng, as, tick);
     for (int i = 0; i < c.A; i++) store_action(out, dtype, (int64_t)i * sa + b * sb, st.act(i));
     finish_rng(s, b, rng);
 }
@@ -170,6 +173,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     Env e = {};
     PhiloxRng rng;
     rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
+    ActionStream as;
+    as.init();
     if (active) {
         load_env<S>(c, s, st, b, e);
         rng.cur = s.rng[b];
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #endif
         STAMP(0);
         if (active) {
-            sample_actions_env<S>(c, st, e, rng);
+            sample_actions_env<S>(c, st, e, rng, as, a.tick_base + (uint64_t)tick);
             STAMP(1);
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
 #pragma unroll
@@ -411,6 +416,7 @@ struct susnet_env {
     State s;
     bool bound = false;
     bool float_exact = false;
+    uint64_t ticks = 0; // steps taken (index of the production action stream)
     susnet_layout layout;
     uint64_t off_err, off_agent, off_job, off_jobdone, off_t, off_timer, off_flags, off_rng, off_msteps, off_mfix, off_msab,
         off_mkv, off_life;
@@ -615,6 +621,7 @@ extern "C" int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void
     if (int rc = check_bound(env)) return rc;
     env->c.seed = seed;
     env->cfg.seed = seed;
+    env->ticks = 0;
     hipLaunchKernelGGL(k_fill_cursor, dim3((unsigned)((env->c.B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), env->c,
                        env->s, cursor);
     HIP_TRY(hipGetLastError());
@@ -725,9 +732,9 @@ extern "C" int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t
     size_t sh = lds_bytes(env, o, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (env->cfg.rng_mode == SUSNET_RNG_TAPE)
-        hipLaunchKernelGGL(k_sample<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb);
+        hipLaunchKernelGGL(k_sample<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb, env->ticks);
     else
-        hipLaunchKernelGGL(k_sample<PhiloxRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb);
+        hipLaunchKernelGGL(k_sample<PhiloxRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb, env->ticks);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }
@@ -763,6 +770,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     else if (spec == 4) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
     else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
     HIP_TRY(hipGetLastError());
+    env->ticks += 1;
     return SUSNET_OK;
 }
 
@@ -772,6 +780,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     if (env->cfg.rng_mode != SUSNET_RNG_PHILOX) return fail(SUSNET_E_INVALID, "susnet_rollout needs the PHILOX stream");
     RolloutArgs a;
     a.n_ticks = io->n_ticks;
+    a.tick_base = env->ticks;
     a.actions = io->actions;
     a.rewards = io->rewards;
     a.done = io->done;
@@ -800,6 +809,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     else LAUNCH_ROLLOUT(GenericSpec);
 #undef LAUNCH_ROLLOUT
     HIP_TRY(hipGetLastError());
+    env->ticks += (uint64_t)io->n_ticks;
     return SUSNET_OK;
 }
 
@@ -828,6 +838,13 @@ extern "C" int susnet_import_state(susnet_env *env, const susnet_state_view *vie
     if (!view) return fail(SUSNET_E_INVALID, "null view");
     hipLaunchKernelGGL(k_import, grid_for(env), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->c, env->s, *view);
     HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get) {
+    if (!env) return fail(SUSNET_E_INVALID, "null handle");
+    if (set) env->ticks = *set;
+    if (get) *get = env->ticks;
     return SUSNET_OK;
 }
 

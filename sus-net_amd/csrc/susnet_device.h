@@ -160,6 +160,29 @@ struct PhiloxRng {
     }
 };
 
+// ACTION stream of the production protocol (counter word 1 tagged with bit 31), indexed by `tick` = steps taken so
+// far: the same for every env stepped in lockstep, so blocks are generated under wave-uniform control flow
+// (see sample_actions_env for the word assignment; 1v1: one Philox block per TWO ticks).
+constexpr uint32_t kActionStreamTag = 0x80000000u;
+struct ActionStream {
+    uint64_t blk;          // block currently held (uniform across the wave)
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ void init() { blk = ~0ull; w0 = w1 = w2 = w3 = 0; }
+    __device__ __forceinline__ void gen(const PhiloxRng &r, uint64_t b) {
+        uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32) | kActionStreamTag, c2 = r.e0, c3 = r.e1;
+        uint32_t a = r.k0, d = r.k1;
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ d;
+            c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+            a += 0x9E3779B9u; d += 0xBB67AE85u;
+        }
+        w0 = c0; w1 = c1; w2 = c2; w3 = c3;
+        blk = b;
+    }
+};
+
 // Caller-supplied raw words consumed with numpy-legacy semantics (masked rejection, nothing drawn for a
 // one-element range): fed numpy's MT19937 output the decisions equal the reference's.
 struct TapeRng {
@@ -447,15 +470,36 @@ __device__ __forceinline__ void zero_metrics(Env &e) {
     e.flags &= ~(FLAG_FRESH | FLAG_CREW_WON | FLAG_IMP_WON);
 }
 
-// base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order
-template <class S, class RNG, class Store>
-__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, RNG &rng) {
+// base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order.
+// TAPE: numpy semantics on the env's own word stream.  PHILOX: word tick * A + i of the action stream.
+template <class S, class Store>
+__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, TapeRng &rng, ActionStream &, uint64_t) {
     const int A = S::A(c);
-    rng.align();
+    for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (e.imp >> i) & 1u)));
+}
+// A tick owns W words of the action stream, W = 2 for A <= 2 and A rounded up to a multiple of 4 otherwise, so that
+// which word an agent reads is static: with A <= 2 one Philox block serves TWO ticks (even tick: words 0,1 and the
+// generation, under a scalar branch on the tick's parity; odd tick: words 2,3), otherwise W/4 blocks per tick.
+template <class S, class Store>
+__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, PhiloxRng &rng, ActionStream &as, uint64_t tick) {
+    const int A = S::A(c);
+    if (A <= 2) {
+        const bool odd = (tick & 1ull) != 0ull;
+        const uint64_t b = tick >> 1;
+        if (!odd || as.blk != b) as.gen(rng, b);
 #pragma unroll
-    for (int i = 0; i < A; i++) {
-        const uint32_t n = n_actions<S>(c, (e.imp >> i) & 1u);
-        st.set_act(i, S::kGeneric ? rng.bounded(n) : rng.bounded_at(n, i));
+        for (int i = 0; i < A; i++) {
+            const uint32_t w = odd ? (i == 0 ? as.w2 : as.w3) : (i == 0 ? as.w0 : as.w1);
+            st.set_act(i, __umulhi(w, n_actions<S>(c, (e.imp >> i) & 1u)));
+        }
+    } else {
+        const uint64_t blocks = (uint64_t)((A + 3) >> 2);
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            if ((i & 3) == 0) as.gen(rng, tick * blocks + (uint64_t)(i >> 2));
+            const uint32_t w = (i & 3) == 0 ? as.w0 : (i & 3) == 1 ? as.w1 : (i & 3) == 2 ? as.w2 : as.w3;
+            st.set_act(i, __umulhi(w, n_actions<S>(c, (e.imp >> i) & 1u)));
+        }
     }
 }
 

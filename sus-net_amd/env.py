@@ -573,6 +573,18 @@ class BatchedFourRoomEnv:
                 self._export(full=True)
             torch.cuda.current_stream(self.device).synchronize()
 
+    @property
+    def tick(self) -> int:
+        """Steps this handle has taken (index of the Philox action stream; see susnet_tick)."""
+        v = C.c_uint64(0)
+        L.check(self.lib.susnet_tick(self._h, None, C.byref(v)))
+        return int(v.value)
+
+    @tick.setter
+    def tick(self, value: int):
+        v = C.c_uint64(int(value))
+        L.check(self.lib.susnet_tick(self._h, C.byref(v), None))
+
     def rng_cursor(self) -> torch.Tensor:
         cur = torch.zeros(self.batch, dtype=torch.int64, device=self.device)
         view = L.StateView()
