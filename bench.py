@@ -37,6 +37,8 @@ CONFIGS = {
                  cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536),
     "cfg4": dict(workload="cfg4: FourRoomEnv 2v6, 14x14 walled, 4 jobs, batch 32768/GPU",
                  cls="base", kw=dict(n_imposters=2, n_crew=6, n_jobs=4), n=14, A=8, J=4, batch=32768),
+    "tag5": dict(workload="tag5: FourRoomEnvWithTagging 1v4, 9x9 walled, 5 jobs, votes every 50 steps (notebooks/experiment.ipynb), batch 65536/GPU",
+                 cls="tagging", kw=dict(n_imposters=1, n_crew=4, n_jobs=5), n=9, A=5, J=5, batch=65536),
     # BASELINE.json configs[4]: cfg3's env driven by the reference-architecture MLP (no checkpoints ship with the
     # reference: seeded random init), greedy imposter + uniformly random crew, everything on the device
     "cfg5": dict(workload="cfg5: cfg3 env (1v2, 14x14 walled, 4 jobs) driven by MLP[88,256,128,64,16,7] imposter policy "
@@ -61,7 +63,7 @@ def stored_bytes_per_step(A, J, N, obs):
     """What the fused rollout actually writes per env-step: actions u8 + rewards f32 + done + trunc + obs."""
     b = A + 4 * A + 2
     if obs == "raw":
-        b += 3 * A + (3 * J if J else 0)
+        b += 3 * A + (3 * J if J else 0)  # (+ 2A + 1 with tagging; not counted)
     elif obs == "flat":
         b += 4 * A * 2 * N
     elif obs == "planes":
@@ -91,7 +93,8 @@ def profiled_traffic(kernel_prefix, obs):
 
 
 def make_env(pkg, spec, batch, seed, env_id_base, device, obs_cfg=None):
-    cls = {"itg": pkg.BatchedImposterTrainingGround, "base": pkg.BatchedFourRoomEnv}[spec["cls"]]
+    cls = {"itg": pkg.BatchedImposterTrainingGround, "base": pkg.BatchedFourRoomEnv,
+           "tagging": pkg.BatchedFourRoomEnvWithTagging}[spec["cls"]]
     kw = dict(spec["kw"])
     walls = kw.pop("include_walls", True)
     return cls(**kw, grid=pkg.four_room_grid(spec["n"], walls), batch=batch, device=device, rng="philox", seed=seed,

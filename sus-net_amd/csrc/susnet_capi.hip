@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     float *pr = a.rewards ? a.rewards + bb : nullptr;
     uint8_t *pd = a.done ? a.done + bb : nullptr;
     uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
-    constexpr int kRawF = S::kGeneric ? 1 : (3 * S::kA + 3 * (S::kJ > 0 ? S::kJ : 0));
+    constexpr int kRawF = S::kRawF;
     // compiled-in configurations write their raw uint8 row straight from registers (a few 4-byte stores per lane:
     // the 64 rows of a wave are contiguous, so every touched line is fully written within the tick); measured
     // faster than the LDS image + 16-byte copy-out, also when that copy-out was software-pipelined across ticks
@@ -298,12 +298,14 @@ __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o
 using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0>;  // ImposterTrainingGround 1v1, no jobs (any wall map)
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
 using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
+using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
 
 static int pick_spec(const Consts &c, bool float_exact) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
     if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return 2;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
+    if (c.A == 5 && c.J == 5 && c.variant == SUSNET_VARIANT_TAGGING && c.order_random) return 6;
     return 0;
 }
 
@@ -768,6 +770,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     else if (spec == 2) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg2>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 3) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 4) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
+    else if (spec == 6) hipLaunchKernelGGL((k_step<PhiloxRng, SpecTag5>), g, blk, sh, st, env->c, env->s, a, o);
     else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
     HIP_TRY(hipGetLastError());
     env->ticks += 1;
@@ -806,6 +809,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
     else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
     else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
+    else if (spec == 6) LAUNCH_ROLLOUT(SpecTag5);
     else LAUNCH_ROLLOUT(GenericSpec);
 #undef LAUNCH_ROLLOUT
     HIP_TRY(hipGetLastError());

@@ -95,6 +95,10 @@ template <int A_, int J_, int VAR_, int ORD_>
 struct Spec {
     static constexpr bool kGeneric = A_ < 0;
     static constexpr int kA = A_, kJ = J_;
+    // flattened_state_size (base.py:230-232; tagging.py:42-60) when the configuration is compiled in
+    static constexpr int kRawF = A_ < 0 ? 1
+                                 : 3 * A_ + ((J_ > 0 || VAR_ == SUSNET_VARIANT_TAGGING) ? 3 * (J_ > 0 ? J_ : 0) : 0) +
+                                       (VAR_ == SUSNET_VARIANT_TAGGING ? 2 * A_ + 1 : 0);
     // reward arithmetic type: double reproduces the reference's float64 chain for ANY constants; the
     // compiled-in kernels are only selected when all constants are float-exact integers, so float is exact
     using RT = typename std::conditional<(A_ < 0), double, float>::type;

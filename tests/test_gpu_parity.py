@@ -271,7 +271,8 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
         ob.reset(mask=(odone | otrunc).astype(bool))
 
 
-@pytest.mark.parametrize("name,B", [("base_2v6_j4_14", 32768 + 96), ("itg_1v1_nowalls", 65536 + 32), ("base_1v2_j4_14", 40000)])
+@pytest.mark.parametrize("name,B", [("base_2v6_j4_14", 32768 + 96), ("itg_1v1_nowalls", 65536 + 32), ("base_1v2_j4_14", 40000),
+                                    ("tagging_1v4_j5", 4096), ("itg_1v5_j3", 2048)])
 def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B):
     """Batches >= 32768 / 65536 run 32 / 64 environments per wave (smaller ones 16): same results."""
     T, seed = 24, 31
