@@ -257,12 +257,19 @@ struct LdsStore {
 
 // compiled-in flavour (A, J <= 8): byte lanes of packed VGPR words -- a data-dependent index is a shift,
 // never a memory access (per-lane arrays indexed at run time would be demoted to scratch memory)
+template <int N_, bool WIDE = (N_ > 4)>
+struct PackedBytes;
 template <int N_>
-struct PackedBytes {
-    using W = typename std::conditional<(N_ <= 4), uint32_t, uint64_t>::type;
-    W w = 0;
+struct PackedBytes<N_, false> { // up to 4 bytes in one VGPR
+    uint32_t w = 0;
+    __device__ __forceinline__ uint32_t get(int i) const { return (w >> (8 * i)) & 0xffu; }
+    __device__ __forceinline__ void set(int i, uint32_t v) { w = (w & ~(0xffu << (8 * i))) | ((v & 0xffu) << (8 * i)); }
+};
+template <int N_>
+struct PackedBytes<N_, true> { // 5..8 bytes in a VGPR pair (measured faster than two halves + selects)
+    uint64_t w = 0;
     __device__ __forceinline__ uint32_t get(int i) const { return (uint32_t)(w >> (8 * i)) & 0xffu; }
-    __device__ __forceinline__ void set(int i, uint32_t v) { w = (w & ~((W)0xffu << (8 * i))) | ((W)(v & 0xffu) << (8 * i)); }
+    __device__ __forceinline__ void set(int i, uint32_t v) { w = (w & ~((uint64_t)0xffu << (8 * i))) | ((uint64_t)(v & 0xffu) << (8 * i)); }
 };
 
 template <int A, int J>
@@ -374,6 +381,12 @@ __device__ __forceinline__ void nibble_swap(uint64_t &v, int i, int j) {
     uint64_t d = (uint64_t)(nibble(v, i) ^ nibble(v, j));
     v ^= (d << (4 * i)) ^ (d << (4 * j)); // cancels when i == j
 }
+// 32-bit flavour (up to 8 entries): what compiled-in configurations use
+__device__ __forceinline__ uint32_t nibble(uint32_t v, int i) { return (v >> (4 * i)) & 15u; }
+__device__ __forceinline__ void nibble_swap(uint32_t &v, int i, int j) {
+    uint32_t d = nibble(v, i) ^ nibble(v, j);
+    v ^= (d << (4 * i)) ^ (d << (4 * j));
+}
 __device__ __forceinline__ int nth_set_bit(uint32_t m, uint32_t r) {
     for (uint32_t k = 0; k < r; k++) m &= m - 1u;
     return __ffs((int)m) - 1;
@@ -381,8 +394,8 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, uint32_t r) {
 
 // np.random.shuffle / permutation on a nibble-packed list (base.py:374): i = n-1 .. 1, j in [0, i]
 // STATIC: n is a compile-time constant and the run starts right after rng.align()
-template <bool STATIC, class RNG>
-__device__ __forceinline__ void shuffle_nibbles(RNG &rng, uint64_t &v, int n) {
+template <bool STATIC, class RNG, class ORD>
+__device__ __forceinline__ void shuffle_nibbles(RNG &rng, ORD &v, int n) {
 #pragma unroll
     for (int i = n - 1; i >= 1; i--) {
         int j = (int)(STATIC ? rng.bounded_at((uint32_t)i + 1u, n - 1 - i) : rng.bounded((uint32_t)i + 1u));
@@ -571,7 +584,8 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     uint32_t rc = 0; // 2-bit reward code per agent
     RT team = 0;
 
-    uint64_t order = 0xFEDCBA9876543210ull;
+    using OrderT = typename std::conditional<(!S::kGeneric && S::kA <= 8), uint32_t, uint64_t>::type;
+    OrderT order = (OrderT)0xFEDCBA9876543210ull; // identity permutation, 4 bits per turn
     rng.align();
     const bool shuffled = S::order_random(c);
     if (shuffled) shuffle_nibbles<!S::kGeneric>(rng, order, A); // base.py:372-374
