@@ -176,8 +176,8 @@ typedef struct susnet_step_io {
  * optional (NULL = not stored).  Philox stream only. */
 typedef struct susnet_rollout_io {
     int32_t n_ticks;
-    uint8_t *actions;   /* out [T][A][B] u8 */
-    float *rewards;     /* out [T][A][B] f32 */
+    uint8_t *actions;   /* out [T][B][A] u8  (env-major: what reference callers index as actions[b]) */
+    float *rewards;     /* out [T][B][A] f32 */
     uint8_t *done;      /* out [T][B] */
     uint8_t *truncated; /* out [T][B] */
     const susnet_obs_spec *obs; /* out pointer is [T][B][obs_size]; observation AFTER each tick */

@@ -28,8 +28,8 @@ struct StepArgs {
 struct RolloutArgs {
     int32_t n_ticks;
     uint64_t tick_base; // steps this handle has taken before the launch (index of the action stream)
-    uint8_t *actions; // [T][A][B]
-    float *rewards;   // [T][A][B]
+    uint8_t *actions; // [T][B][A]
+    float *rewards;   // [T][B][A]
     uint8_t *done, *trunc; // [T][B]
 };
 
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     const int64_t AB = (int64_t)A * c.B;
     // per-lane output cursors, bumped once per tick (no 64-bit index arithmetic per store)
     const int64_t bb = active ? b : 0;
-    uint8_t *pa = a.actions ? a.actions + bb : nullptr;
-    float *pr = a.rewards ? a.rewards + bb : nullptr;
+    uint8_t *pa = a.actions ? a.actions + bb * A : nullptr; // env-major rows: one lane writes its A values with wide stores
+    float *pr = a.rewards ? a.rewards + bb * A : nullptr;
     uint8_t *pd = a.done ? a.done + bb : nullptr;
     uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
     constexpr int kRawF = S::kRawF;
@@ -210,11 +210,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             sample_actions_env<S>(c, st, e, rng, as, a.tick_base + (uint64_t)tick);
             STAMP(1);
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
+                if (!S::kGeneric) {
+                    uint32_t av[S::kA > 0 ? S::kA : 1];
 #pragma unroll
-                for (int i = 0; i < A; i++) pa[(int64_t)i * c.B] = (uint8_t)st.act(i);
+                    for (int i = 0; i < A; i++) av[i] = st.act(i);
+                    store_row_u8<(S::kA > 0 ? S::kA : 1)>(pa, av);
+                } else {
+                    for (int i = 0; i < A; i++) pa[i] = (uint8_t)st.act(i);
+                }
             }
             STAMP(2);
-            RewardSink sink{(OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pr)) ? (void *)pr : nullptr, (int64_t)c.B, 1, 0};
+            RewardSink sink{(OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pr)) ? (void *)pr : nullptr, 1, 0, 0};
             bool done, trunc;
 #ifdef SUSNET_STAMPS
             if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, 0, done, trunc, seg2);

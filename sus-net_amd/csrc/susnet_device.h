@@ -528,8 +528,8 @@ struct RewardSink {
     int64_t sa, sb;  // element strides for (agent, env)
     int32_t f64;     // store double instead of float
     template <class RT>
-    __device__ __forceinline__ void put_bound(int i, int64_t b, RT r) const { // float32 [A][B] sink
-        reinterpret_cast<float *>(ptr)[(int64_t)i * sa + b] = (float)r;
+    __device__ __forceinline__ void put_bound(int i, int64_t, RT r) const { // float32 env-major row at ptr
+        reinterpret_cast<float *>(ptr)[i] = (float)r;
     }
     template <class RT>
     __device__ __forceinline__ void put(int i, int64_t b, RT r) const {
@@ -540,10 +540,39 @@ struct RewardSink {
     }
 };
 
+// N consecutive values at p (p is naturally aligned to N * sizeof(T) when N is a power of two): widest stores
+template <int N>
+__device__ __forceinline__ void store_row_f32(float *p, const float *v) {
+    if (N % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k += 4) *reinterpret_cast<float4 *>(p + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+    } else if (N % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k += 2) *reinterpret_cast<float2 *>(p + k) = make_float2(v[k], v[k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) p[k] = v[k];
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_row_u8(uint8_t *p, const uint32_t *v) { // N bytes, p aligned like N's largest power-of-two divisor
+    constexpr int kW = N / 4 * 4;
+#pragma unroll
+    for (int k = 0; k < kW; k += 4) {
+        const uint32_t w = (v[k] & 0xffu) | ((v[k + 1] & 0xffu) << 8) | ((v[k + 2] & 0xffu) << 16) | ((v[k + 3] & 0xffu) << 24);
+        __builtin_memcpy(p + k, &w, 4);
+    }
+    if (N - kW >= 2) {
+        const uint16_t h = (uint16_t)((v[kW] & 0xffu) | ((v[kW + 1] & 0xffu) << 8));
+        __builtin_memcpy(p + kW, &h, 2);
+    }
+    if ((N - kW) & 1) p[N - 1] = (uint8_t)v[N - 1];
+}
+
 __device__ __forceinline__ void set_code(uint32_t &rc, int idx, uint32_t code) { rc = (rc & ~(3u << (2 * idx))) | (code << (2 * idx)); }
 
 // returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
-// SINK_ON: the reward sink is known to be bound (no null check per agent)
+// SINK_ON: the reward sink is known to be bound to this env's float32 row (rollout trajectory, [T][B][A])
 template <class S, bool VALIDATE, bool SINK_ON, class RNG, class Store>
 __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const RewardSink &sink,
                                              int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr) {
@@ -733,15 +762,17 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     if (!S::kGeneric && !tagging) {
         // compiled-in, non-tagging: one lookup per agent in the host-evaluated table (all reads issued back to back)
         const uint32_t tsel = wsel;
+        float rr[S::kA > 0 ? S::kA : 1];
 #pragma unroll
         for (int i = 0; i < A; i++) {
             const uint32_t code = (rc >> (2 * i)) & 3u;
             const uint32_t dead = ((e.alive >> i) & 1u) ? 0u : 4u;
             const uint32_t neg = (i < c.n_imp) ? 8u : 0u;
             const float r = T.rew[tsel + neg + dead + code];
-            if (SINK_ON) sink.put_bound(i, b, r);
+            if (SINK_ON) rr[i] = r;
             else sink.put(i, b, r);
         }
+        if (SINK_ON) store_row_f32<(S::kA > 0 ? S::kA : 1)>(reinterpret_cast<float *>(sink.ptr), rr);
     } else {
 #pragma unroll
         for (int i = 0; i < A; i++) {

@@ -474,13 +474,13 @@ class BatchedFourRoomEnv:
 
     def alloc_rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None):
         """Allocate (once) the trajectory buffers a fused rollout of up to ``n_ticks`` ticks writes:
-        actions u8 [T, A, B], rewards f32 [T, A, B], done / truncated bool [T, B], obs [T, B, ...]."""
+        actions u8 [T, B, A], rewards f32 [T, B, A], done / truncated bool [T, B], obs [T, B, ...]."""
         T, A, B = int(n_ticks), self.n_agents, self.batch
         out = {"n_ticks": T}
         if "actions" in store:
-            out["actions"] = torch.empty(T, A, B, dtype=torch.uint8, device=self.device)
+            out["actions"] = torch.empty(T, B, A, dtype=torch.uint8, device=self.device)
         if "rewards" in store:
-            out["rewards"] = torch.empty(T, A, B, dtype=torch.float32, device=self.device)
+            out["rewards"] = torch.empty(T, B, A, dtype=torch.float32, device=self.device)
         if "done" in store:
             out["done"] = torch.empty(T, B, dtype=torch.bool, device=self.device)
         if "truncated" in store:

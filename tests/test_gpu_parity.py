@@ -253,9 +253,9 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
     acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
     for s in range(T):
         oa = ob.sample_actions()
-        np.testing.assert_array_equal(acts[s].T, oa, err_msg=f"{name} actions tick {s}")
+        np.testing.assert_array_equal(acts[s], oa, err_msg=f"{name} actions tick {s}")
         orew, odone, otrunc, rc = ob.step(oa)
-        assert np.array_equal(rews[s].T.astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
+        assert np.array_equal(rews[s].astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
         np.testing.assert_array_equal(dones[s], odone.astype(bool))
         np.testing.assert_array_equal(truncs[s], otrunc.astype(bool))
         ob.reset(mask=(odone | otrunc).astype(bool))
@@ -266,7 +266,7 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
     traj2 = env.rollout(7)
     for s in range(7):
         oa = ob.sample_actions()
-        np.testing.assert_array_equal(np_(traj2["actions"])[s].T, oa)
+        np.testing.assert_array_equal(np_(traj2["actions"])[s], oa)
         orew, odone, otrunc, _ = ob.step(oa)
         ob.reset(mask=(odone | otrunc).astype(bool))
 
@@ -284,9 +284,9 @@ def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B):
     acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
     for s in range(T):
         oa = ob.sample_actions()
-        np.testing.assert_array_equal(acts[s].T, oa, err_msg=f"{name} actions tick {s}")
+        np.testing.assert_array_equal(acts[s], oa, err_msg=f"{name} actions tick {s}")
         orew, odone, otrunc, rc = ob.step(oa, threads=0)
-        assert np.array_equal(rews[s].T.astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
+        assert np.array_equal(rews[s].astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
         np.testing.assert_array_equal(dones[s], odone.astype(bool))
         np.testing.assert_array_equal(truncs[s], otrunc.astype(bool))
         ob.reset(mask=(odone | otrunc).astype(bool))
