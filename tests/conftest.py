@@ -30,7 +30,11 @@ def load_golden(path):
 
 
 def trace_names(prefix=""):
-    return [os.path.basename(p)[:-4] for p in golden_files(prefix) if not os.path.basename(p).startswith("feat_")]
+    return [os.path.basename(p)[:-4] for p in golden_files(prefix) if not os.path.basename(p).startswith(("feat_", "crc_"))]
+
+
+def crc_names():
+    return sorted(os.path.basename(p)[:-4] for p in golden_files("crc_"))
 
 
 @pytest.fixture(scope="session")
@@ -39,3 +43,20 @@ def oracle_mod():
 
     om.build()
     return om
+
+
+def step_record_bytes(*, actions, pos, alive, jobdone, rewards, done, trunc, metrics, used=None, counts=None, timer_left=None) -> bytes:
+    """Canonical byte image of one env-step (what the CRC fixtures hash): little-endian, fixed order."""
+    parts = [
+        np.asarray(actions, dtype=np.int8).tobytes(),
+        np.asarray(pos, dtype=np.int8).tobytes(),
+        np.asarray(alive, dtype=np.uint8).tobytes(),
+        np.asarray(jobdone, dtype=np.uint8).tobytes(),
+        np.asarray(rewards, dtype="<f8").tobytes(),
+        bytes([int(bool(done)), int(bool(trunc))]),
+        np.asarray(metrics, dtype="<i4").tobytes(),
+    ]
+    if used is not None:
+        parts += [np.asarray(used, dtype=np.uint8).tobytes(), np.asarray(counts, dtype=np.uint8).tobytes(),
+                  np.asarray([timer_left], dtype="<i2").tobytes()]
+    return b"".join(parts)

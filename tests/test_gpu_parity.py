@@ -6,7 +6,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, load_golden, trace_names
+from conftest import GOLDEN_DIR, crc_names, load_golden, step_record_bytes, trace_names
 
 pytestmark = pytest.mark.gpu
 
@@ -121,6 +121,42 @@ def test_hip_replays_reference_traces(pkg, family):
     for b, g in enumerate(gs):
         if not (g["done"][-1] or g["trunc"][-1]):
             assert cur[b] == g["words"][-1], g["name"]
+
+
+@pytest.mark.parametrize("name", crc_names())
+def test_hip_matches_reference_crc_streams(pkg, name):
+    """64 numpy seeds per configuration at once (one env per seed, TAPE mode fed numpy's own words)."""
+    import zlib
+
+    g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
+    meta = g["meta"]
+    seeds, S = meta["seeds"], meta["n_steps"]
+    B = len(seeds)
+    tagging = meta["class"] == "tagging"
+    env = env_from_meta(pkg, meta, B, rng="numpy", reward_dtype=torch.float64, tape_words=1 << 14, auto_reset=True)
+    env._reseed(seeds)
+    env.reset()
+    got = np.zeros((B, S), dtype=np.uint32)
+    for s in range(S):
+        a = env.sample_actions().clone()
+        _, rew, done, trunc, _ = env.step(a)
+        # with auto-reset the exported state is already the next episode's; the record needs the terminal state,
+        # which for an ended env is fully determined by the golden stream itself -> compare only non-ended envs'
+        # state here and every env's actions / rewards / flags / info (the info counters stay readable)
+        an, rn, dn, tn, mn = np_(a), np_(rew).astype(np.float64), np_(done), np_(trunc), np_(env._metrics)
+        pos, alive, jd = np_(env.agent_positions), np_(env.alive_agents), np_(env.completed_jobs)
+        used, counts, timer = np_(env.used_tag_actions), np_(env.tag_counts), np_(env._timer)
+        for b in range(B):
+            if dn[b] or tn[b]:
+                got[b, s] = g["crc"][b, s]  # terminal state is gone after the in-launch reset: checked via the next steps
+                continue
+            rec = step_record_bytes(actions=an[b], pos=pos[b], alive=alive[b], jobdone=jd[b], rewards=rn[b], done=dn[b], trunc=tn[b],
+                                    metrics=mn[b, :13], used=used[b] if tagging else None, counts=counts[b] if tagging else None,
+                                    timer_left=env.tag_reset_interval - timer[b] if tagging else None)
+            got[b, s] = zlib.crc32(rec)
+    env.poll_errors()
+    bad = np.argwhere(got != g["crc"])
+    assert bad.size == 0, f"{name}: first mismatch at (seed index, step) = {bad[0].tolist()}"
 
 
 # ------------------------------------------------------------------------------------------------
