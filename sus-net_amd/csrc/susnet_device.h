@@ -9,15 +9,18 @@
 //   _merge_rewards   src/environment/base.py:553-563
 //   info counters    src/metrics.py:35-64
 //
-// Execution model: a workgroup is ONE 64-lane wavefront (64 environments).  Per-lane scalars (alive /
-// imposter / tag-used / job-done bitmasks, t, counters) live in VGPRs.  The per-agent table (cell, tag
-// count, action) and the job cells come in two storage flavours behind one interface:
+// Execution model: a workgroup is ONE 64-lane wavefront (64 environments; 32 or 16 in the fused rollout when the
+// batch would otherwise leave SIMDs without a wave).  Per-lane scalars (alive / imposter / tag-used / job-done
+// bitmasks, t, counters) live in VGPRs.  The per-agent table (cell, tag count, action) and the job cells come in two
+// storage flavours behind one interface:
 //   LdsStore        [index][lane] columns in LDS: any agent/job count, a lane-varying index is one
 //                   conflict-free ds_read_b32 (generic kernels);
-//   RegStore<A, J>  VGPR arrays for configurations compiled in (Spec<...>): loops unroll, indices become
-//                   register names, a data-dependent index is a short select chain.
-// The wall map and the spawn-cell table are wave-shared LDS tables.  No barriers: a lane only touches its
-// own column, except the cooperative observation writer, and LDS operations of one wave complete in order.
+//   RegStore<A, J>  byte lanes of packed VGPR words for configurations compiled in (Spec<...>): loops unroll, a
+//                   data-dependent index is a shift (per-lane arrays indexed at run time would go to scratch).
+// Wave-shared LDS tables hold what is looked up by data-dependent index and is constant: the wall map, the spawn
+// cells, the (action, cell) -> next cell move table and the reward table.  No s_barrier anywhere: a lane only
+// touches its own column, except the cooperative observation writer, and LDS operations of one wave complete in
+// order.  Wave ballots gate the rare work (kill search / resolution, fix / sabotage) under uniform control flow.
 #pragma once
 
 #include <hip/hip_runtime.h>
