@@ -148,8 +148,8 @@ def cpu_baseline(spec, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
-    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=32768)
+    ap.add_argument("--warmup", type=int, default=1024)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="fused", choices=["fused", "step"])
     ap.add_argument("--obs", default="raw", choices=["none", "raw", "flat", "planes"])

@@ -403,16 +403,17 @@ __global__ void k_fill_cursor(Consts c, State s, uint64_t cursor) {
     if (b < c.B) s.rng[b] = cursor;
 }
 
-// one workgroup per lifetime row: wave shuffles, then one LDS hop across the 4 waves
+// lifetime row sums: grid = (chunks, rows); 64-lane shuffles, one LDS hop across the block's 4 waves, then ONE
+// atomic per block into the (pre-zeroed) 64-bit total
 __global__ __launch_bounds__(256) void k_reduce_lifetime(Consts c, State s, int64_t *out) {
     __shared__ unsigned long long part[4];
-    const int row = blockIdx.x;
+    const int row = blockIdx.y;
     unsigned long long acc = 0;
-    for (int64_t b = threadIdx.x; b < c.B; b += 256) acc += s.life[(size_t)row * c.Bp + b];
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < c.B; b += (int64_t)gridDim.x * 256) acc += s.life[(size_t)row * c.Bp + b];
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[row] = (int64_t)(part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(out) + row, part[0] + part[1] + part[2] + part[3]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -861,8 +862,10 @@ extern "C" int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get) 
 extern "C" int susnet_reduce_lifetime(susnet_env *env, int64_t *out_device, void *stream) {
     if (int rc = check_bound(env)) return rc;
     if (!out_device) return fail(SUSNET_E_INVALID, "null output");
-    hipLaunchKernelGGL(k_reduce_lifetime, dim3(SUSNET_N_LIFETIME), dim3(256), 0, static_cast<hipStream_t>(stream), env->c, env->s,
-                       out_device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(out_device, 0, sizeof(int64_t) * SUSNET_N_LIFETIME, st));
+    const unsigned chunks = (unsigned)((env->c.B + 4095) / 4096);
+    hipLaunchKernelGGL(k_reduce_lifetime, dim3(chunks < 64 ? chunks : 64, SUSNET_N_LIFETIME), dim3(256), 0, st, env->c, env->s, out_device);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }
