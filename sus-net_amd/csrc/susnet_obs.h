@@ -218,6 +218,7 @@ __device__ __forceinline__ void copy_bytes(const uint32_t *img, int total, uint8
 template <bool BITS>
 __device__ __forceinline__ void expand_f32(const uint32_t *img, int total, float *dst, bool is_signed, int lane) {
     const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+#pragma unroll 4
     for (int g = lane * 4; g < total; g += kWave * 4) {
         float v[4];
         if (BITS) {
