@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // compiled-in configurations write their raw uint8 row straight from registers (a few 4-byte stores per lane:
     // the 64 rows of a wave are contiguous, so every touched line is fully written within the tick); measured
     // faster than the LDS image + 16-byte copy-out, also when that copy-out was software-pipelined across ticks
-    constexpr bool kDirect = (OUT == OUT_TRAJ_RAW8) && !S::kGeneric;
+    constexpr bool kDirect = (OUT == OUT_TRAJ_RAW8) && S::kRawF > 0;
     uint8_t *obs_row = kDirect ? reinterpret_cast<uint8_t *>(o.out) + bb * kRawF : nullptr;
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         if (OUT == OUT_TRAJ_RAW8 && !kDirect) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
         if (kDirect) {
             if (active) {
-                uint8_t row[kRawF + 4];
+                uint8_t row[(kRawF > 0 ? kRawF : 1) + 4];
                 fill_raw<S>(c, st, e, row);
                 // 4-byte stores (naturally aligned when F % 4 == 0, otherwise the hardware's unaligned global
                 // access splits them), then a 2-byte and a 1-byte tail
@@ -305,6 +305,9 @@ using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0>;  // ImposterTrainingGround 1
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
 using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
 using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
+// agent count compiled in, everything else read at run time (any variant / order / up to 8 jobs): the packed-VGPR
+// tables without a full specialisation
+template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
 
 static int pick_spec(const Consts &c, bool float_exact) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
@@ -312,6 +315,7 @@ static int pick_spec(const Consts &c, bool float_exact) {
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
     if (c.A == 5 && c.J == 5 && c.variant == SUSNET_VARIANT_TAGGING && c.order_random) return 6;
+    if (c.A >= 2 && c.A <= 8 && c.J <= 8) return 10 + c.A; // SpecA<A>
     return 0;
 }
 
@@ -778,6 +782,9 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     else if (spec == 3) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 4) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
     else if (spec == 6) hipLaunchKernelGGL((k_step<PhiloxRng, SpecTag5>), g, blk, sh, st, env->c, env->s, a, o);
+#define STEP_A(N) else if (spec == 10 + N) hipLaunchKernelGGL((k_step<PhiloxRng, SpecA<N>>), g, blk, sh, st, env->c, env->s, a, o);
+    STEP_A(2) STEP_A(3) STEP_A(4) STEP_A(5) STEP_A(6) STEP_A(7) STEP_A(8)
+#undef STEP_A
     else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
     HIP_TRY(hipGetLastError());
     env->ticks += 1;
@@ -817,6 +824,9 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
     else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
     else if (spec == 6) LAUNCH_ROLLOUT(SpecTag5);
+#define ROLL_A(N) else if (spec == 10 + N) LAUNCH_ROLLOUT(SpecA<N>);
+    ROLL_A(2) ROLL_A(3) ROLL_A(4) ROLL_A(5) ROLL_A(6) ROLL_A(7) ROLL_A(8)
+#undef ROLL_A
     else LAUNCH_ROLLOUT(GenericSpec);
 #undef LAUNCH_ROLLOUT
     HIP_TRY(hipGetLastError());

@@ -99,7 +99,7 @@ struct Spec {
     static constexpr bool kGeneric = A_ < 0;
     static constexpr int kA = A_, kJ = J_;
     // flattened_state_size (base.py:230-232; tagging.py:42-60) when the configuration is compiled in
-    static constexpr int kRawF = A_ < 0 ? 1
+    static constexpr int kRawF = (A_ < 0 || J_ < 0 || VAR_ < 0) ? -1
                                  : 3 * A_ + ((J_ > 0 || VAR_ == SUSNET_VARIANT_TAGGING) ? 3 * (J_ > 0 ? J_ : 0) : 0) +
                                        (VAR_ == SUSNET_VARIANT_TAGGING ? 2 * A_ + 1 : 0);
     // reward arithmetic type: double reproduces the reference's float64 chain for ANY constants; the
@@ -293,8 +293,9 @@ struct RegStore {
     __device__ __forceinline__ void set_act(int i, uint32_t a) { actw.set(i, a); }
 };
 
+// compiled-in agent count: packed VGPR tables; a run-time job count gets the 8-slot table
 template <class S>
-struct StoreFor { using type = RegStore<S::kA, S::kJ>; };
+struct StoreFor { using type = RegStore<S::kA, (S::kJ >= 0 ? S::kJ : 8)>; };
 template <>
 struct StoreFor<GenericSpec> { using type = LdsStore; };
 
