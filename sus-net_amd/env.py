@@ -314,7 +314,8 @@ class BatchedFourRoomEnv:
         """
         if self.rng_kind == "philox":
             self.seed = int(seed)
-            L.check(self.lib.susnet_seed(self._h, self.seed & (2**64 - 1), 0, self._stream()))
+            with self._on_device():
+                L.check(self.lib.susnet_seed(self._h, self.seed & (2**64 - 1), 0, self._stream()))
         elif self.rng_kind == "numpy":
             seeds = [int(seed) + b for b in range(self.batch)] if np.isscalar(seed) else [int(s) for s in seed]
             tape = np.stack([np.random.RandomState(s).randint(0, 2**32, size=self.tape_words, dtype=np.uint32) for s in seeds])
@@ -407,6 +408,9 @@ class BatchedFourRoomEnv:
         with torch.cuda.device(self.device):
             if seed is not None:
                 self._reseed(seed)
+            elif self.rng_kind == "numpy" and self._tape is None:
+                # like the reference's unseeded global RandomState: fresh OS entropy
+                self._reseed(int(np.random.SeedSequence().generate_state(1)[0]) % (2**32 - self.batch))
             m = None
             if mask is not None:
                 m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
