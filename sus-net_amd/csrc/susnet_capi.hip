@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o
 }
 
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
-using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0>;  // ImposterTrainingGround 1v1, no jobs (any wall map)
+using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>; // ImposterTrainingGround 1v1, no jobs, fixed order, imposter = agent 0 (any wall map)
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
 using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
 using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
@@ -311,7 +311,7 @@ template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
 
 static int pick_spec(const Consts &c, bool float_exact) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
-    if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG) return 2;
+    if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG && !c.order_random && !c.shuffle_imp && c.n_imp == 1) return 2;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
     if (c.A == 5 && c.J == 5 && c.variant == SUSNET_VARIANT_TAGGING && c.order_random) return 6;

@@ -94,7 +94,7 @@ struct State {
 };
 
 // Compile-time specialisation of a configuration; -1 = read the value from Consts at run time.
-template <int A_, int J_, int VAR_, int ORD_>
+template <int A_, int J_, int VAR_, int ORD_, int SHUF_ = -1, int NI_ = -1>
 struct Spec {
     static constexpr bool kGeneric = A_ < 0;
     static constexpr int kA = A_, kJ = J_;
@@ -111,6 +111,9 @@ struct Spec {
     __device__ static __forceinline__ bool order_random(const Consts &c) { return ORD_ >= 0 ? (ORD_ != 0) : (c.order_random != 0); }
     __device__ static __forceinline__ bool tagging(const Consts &c) { return variant(c) == SUSNET_VARIANT_TAGGING; }
     __device__ static __forceinline__ uint32_t nr_imp(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 6u : 7u) : (uint32_t)c.nr_imp; }
+    // roles: with shuffle_imposter_index off the imposters are always agents [0, n_imp) (base.py:278)
+    __device__ static __forceinline__ int n_imp(const Consts &c) { return NI_ >= 0 ? NI_ : c.n_imp; }
+    __device__ static __forceinline__ uint32_t imp(const Consts &, uint32_t env_mask) { return (SHUF_ == 0 && NI_ >= 0) ? ((1u << (NI_ >= 0 ? NI_ : 0)) - 1u) : env_mask; }
     __device__ static __forceinline__ uint32_t nr_crew(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 5u : 6u) : (uint32_t)c.nr_crew; }
 };
 using GenericSpec = Spec<-1, -1, -1, -1>;
@@ -364,7 +367,7 @@ __device__ __forceinline__ void store_env(const Consts &c, const State &s, const
 #pragma unroll
     for (int i = 0; i < A; i++) {
         s.agent[(size_t)i * c.Bp + b] =
-            (uint16_t)pack_agent(st.xy(i), (e.alive >> i) & 1u, (e.imp >> i) & 1u, (e.used >> i) & 1u, st.cnt(i));
+            (uint16_t)pack_agent(st.xy(i), (e.alive >> i) & 1u, (S::imp(c, e.imp) >> i) & 1u, (e.used >> i) & 1u, st.cnt(i));
     }
     if (store_jobs) {
 #pragma unroll
@@ -496,7 +499,7 @@ __device__ __forceinline__ void zero_metrics(Env &e) {
 template <class S, class Store>
 __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, TapeRng &rng, ActionStream &, uint64_t) {
     const int A = S::A(c);
-    for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (e.imp >> i) & 1u)));
+    for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
 }
 // A tick owns W words of the action stream, W = 2 for A <= 2 and A rounded up to a multiple of 4 otherwise, so that
 // which word an agent reads is static: with A <= 2 one Philox block serves TWO ticks (even tick: words 0,1 and the
@@ -511,7 +514,7 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
 #pragma unroll
         for (int i = 0; i < A; i++) {
             const uint32_t w = odd ? (i == 0 ? as.w2 : as.w3) : (i == 0 ? as.w0 : as.w1);
-            st.set_act(i, __umulhi(w, n_actions<S>(c, (e.imp >> i) & 1u)));
+            st.set_act(i, __umulhi(w, n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
         }
     } else {
         const uint64_t blocks = (uint64_t)((A + 3) >> 2);
@@ -519,7 +522,7 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
         for (int i = 0; i < A; i++) {
             if ((i & 3) == 0) as.gen(rng, tick * blocks + (uint64_t)(i >> 2));
             const uint32_t w = (i & 3) == 0 ? as.w0 : (i & 3) == 1 ? as.w1 : (i & 3) == 2 ? as.w2 : as.w3;
-            st.set_act(i, __umulhi(w, n_actions<S>(c, (e.imp >> i) & 1u)));
+            st.set_act(i, __umulhi(w, n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
         }
     }
 }
@@ -597,7 +600,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         for (int i = 0; i < A; i++) {
             int32_t a = (int32_t)st.act(i);
             if (a >= (int32_t)space_n) bits |= SUSNET_ERRBIT_ASSERT;
-            else if (a < 0 || (uint32_t)a >= n_actions<S>(c, (e.imp >> i) & 1u)) bits |= SUSNET_ERRBIT_INDEX;
+            else if (a < 0 || (uint32_t)a >= n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)) bits |= SUSNET_ERRBIT_INDEX;
         }
         if (bits) {
             for (int i = 0; i < A; i++) sink.put(i, b, 0.0f);
@@ -644,7 +647,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     for (int k = 0; k < A; k++) {
         const int idx = shuffled ? (int)nibble(order, k) : k;
         const uint32_t a = st.act(idx);
-        const uint32_t is_imp = (e.imp >> idx) & 1u;
+        const uint32_t is_imp = (S::imp(c, e.imp) >> idx) & 1u;
         const uint32_t nr = n_role_actions<S>(c, is_imp);
         bool acts = (e.alive >> idx) & 1u; // base.py:477: dead agents do nothing
         if (tagging) {
@@ -678,7 +681,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         // agent attempts a kill this turn, the resolution only if some lane found a victim.
         if (__builtin_amdgcn_ballot_w64(is_kill) != 0ull) {
             uint32_t cm = 0;
-            const uint32_t crew = is_kill ? (e.alive & ~e.imp) : 0u;
+            const uint32_t crew = is_kill ? (e.alive & ~S::imp(c, e.imp)) : 0u;
 #pragma unroll
             for (int i = 0; i < A; i++) cm |= (((crew >> i) & 1u) && st.xy(i) == xy) ? (1u << i) : 0u;
             if (__builtin_amdgcn_ballot_w64(cm != 0u) != 0ull) {
@@ -735,7 +738,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             uint32_t quorum = ((uint32_t)__popc(e.alive) + 1u) / 2u;
             if (highest >= quorum) {
                 e.alive &= ~(1u << best);
-                bool vimp = (e.imp >> best) & 1u;
+                bool vimp = (S::imp(c, e.imp) >> best) & 1u;
                 team += rw<RT>(c, RW_VOTE) * (vimp ? (RT)-1 : (RT)1); // tagging.py:196, sign as coded
                 e.m_kv += vimp ? (1u << 16) : (1u << 24);
             }
@@ -748,7 +751,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     // check_win_condition: base.py:409-460 / pred_prey.py:78-99
     uint32_t wsel = 0; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
     {
-        const int alive_imp = __popc(e.alive & e.imp), alive_all = __popc(e.alive), done_jobs = __popc(e.jd);
+        const int alive_imp = __popc(e.alive & S::imp(c, e.imp)), alive_all = __popc(e.alive), done_jobs = __popc(e.jd);
         RT win = 0;
         const RT r_end = rw<RT>(c, RW_END);
         if (S::variant(c) == SUSNET_VARIANT_ITG) {
@@ -771,7 +774,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         for (int i = 0; i < A; i++) {
             const uint32_t code = (rc >> (2 * i)) & 3u;
             const uint32_t dead = ((e.alive >> i) & 1u) ? 0u : 4u;
-            const uint32_t neg = (i < c.n_imp) ? 8u : 0u;
+            const uint32_t neg = (i < S::n_imp(c)) ? 8u : 0u;
             const float r = T.rew[tsel + neg + dead + code];
             if (SINK_ON) rr[i] = r;
             else sink.put(i, b, r);
@@ -786,7 +789,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             else if (code == RC_FIX) r = rw<RT>(c, RW_FIX);
             else if (code == RC_SAB) r = (RT)-1 * rw<RT>(c, RW_SAB);
             r += team;
-            if (i < c.n_imp) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
+            if (i < S::n_imp(c)) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
             if (!((e.alive >> i) & 1u)) r = rw<RT>(c, RW_DEAD); // base.py:562
             if (!tagging && r == (RT)0) r = rw<RT>(c, RW_TSR);  // base.py:389-390 (tagging.py has no fill)
             if (SINK_ON) sink.put_bound(i, b, r);

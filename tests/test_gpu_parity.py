@@ -167,6 +167,9 @@ CONFIGS = {
                                               time_step_reward=0, include_walls=False), n=9),
     "itg_1v1_walls": dict(cls="itg", kw=dict(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
                                             time_step_reward=0), n=9),
+    # imposter slot drawn per episode: not the compiled-in 1v1 kernel (roles are data there)
+    "itg_1v1_shuffle": dict(cls="itg", kw=dict(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=2,
+                                              time_step_reward=0, shuffle_imposter_index=True), n=9),
     "base_1v2_j4_14": dict(cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14),
     "base_2v6_j4_14": dict(cls="base", kw=dict(n_imposters=2, n_crew=6, n_jobs=4), n=14),
     "base_3v9_j8_16": dict(cls="base", kw=dict(n_imposters=3, n_crew=9, n_jobs=8, max_time_steps=60), n=16),
@@ -278,7 +281,7 @@ def test_sharding_is_invisible(pkg, oracle_mod):
     np.testing.assert_array_equal(tot, np_(lo.lifetime_totals()) + np_(hi.lifetime_totals()))
 
 
-@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "itg_1v1_walls", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v5_j3"])
+@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "itg_1v1_walls", "itg_1v1_shuffle", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v5_j3"])
 def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
     B, T, seed = 1000, 120, 9
     env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
