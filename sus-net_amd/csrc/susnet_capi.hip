@@ -179,6 +179,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         load_env<S>(c, s, st, b, e);
         rng.cur = s.rng[b];
     }
+    // trajectory mode with register-direct observation rows has no cooperative (all-lane) work past this point:
+    // idle lanes of a ragged last wave leave, and the tick loop runs without per-block exec masking
+    if (OUT == OUT_TRAJ_RAW8 && S::kRawF > 0 && !active) return;
     LifeAcc life;
     life.clear();
     const int64_t AB = (int64_t)A * c.B;
@@ -194,6 +197,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // faster than the LDS image + 16-byte copy-out, also when that copy-out was software-pipelined across ticks
     constexpr bool kDirect = (OUT == OUT_TRAJ_RAW8) && S::kRawF > 0;
     uint8_t *obs_row = kDirect ? reinterpret_cast<uint8_t *>(o.out) + bb * kRawF : nullptr;
+    // OUT_TRAJ_RAW8: wave-uniform tick bases (scalar registers, bumped on the scalar unit) + a fixed 32-bit lane
+    // offset, i.e. the saddr + voffset form of the global stores; the host only selects this mode when a tick's
+    // slab of every output is below 4 GiB
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8;
+    const uint32_t lo_a = (uint32_t)(bb * A), lo_r = lo_a * 4u, lo_d = (uint32_t)bb, lo_o = (uint32_t)(bb * (kRawF > 0 ? kRawF : 0));
+    uint8_t *ua = a.actions, *ud = a.done, *ut = a.trunc, *uo = reinterpret_cast<uint8_t *>(o.out);
+    uint8_t *ur = reinterpret_cast<uint8_t *>(a.rewards);
+    if (kTraj) { pa = nullptr; pr = nullptr; pd = nullptr; pt = nullptr; obs_row = nullptr; }
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     unsigned long long seg2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -207,20 +218,21 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #endif
         STAMP(0);
         if (active) {
-            sample_actions_env<S>(c, st, e, rng, as, a.tick_base + (uint64_t)tick);
+            sample_actions_env<S>(c, st, e, rng, as, a.tick_base + (uint64_t)tick, tick == 0);
             STAMP(1);
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
                 if (!S::kGeneric) {
                     uint32_t av[S::kA > 0 ? S::kA : 1];
 #pragma unroll
                     for (int i = 0; i < A; i++) av[i] = st.act(i);
-                    store_row_u8<(S::kA > 0 ? S::kA : 1)>(pa, av);
+                    store_row_u8<(S::kA > 0 ? S::kA : 1)>(kTraj ? ua + lo_a : pa, av);
                 } else {
-                    for (int i = 0; i < A; i++) pa[i] = (uint8_t)st.act(i);
+                    uint8_t *const row = kTraj ? ua + lo_a : pa;
+                    for (int i = 0; i < A; i++) row[i] = (uint8_t)st.act(i);
                 }
             }
             STAMP(2);
-            RewardSink sink{(OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pr)) ? (void *)pr : nullptr, 1, 0, 0};
+            RewardSink sink{kTraj ? (void *)(ur + lo_r) : ((OUT == OUT_ANY && pr) ? (void *)pr : nullptr), 1, 0, 0};
             bool done, trunc;
 #ifdef SUSNET_STAMPS
             if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
@@ -230,8 +242,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             else step_env<S, false, false>(c, T, st, e, rng, sink, 0, done, trunc);
 #endif
             STAMP(3);
-            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pd != nullptr)) *pd = done ? 1 : 0;
-            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pt != nullptr)) *pt = trunc ? 1 : 0;
+            if (kTraj) {
+                ud[lo_d] = done ? 1 : 0;
+                ut[lo_d] = trunc ? 1 : 0;
+            } else if (OUT == OUT_ANY) {
+                if (pd != nullptr) *pd = done ? 1 : 0;
+                if (pt != nullptr) *pt = trunc ? 1 : 0;
+            }
             STAMP(4);
             if (__builtin_expect(done || trunc, 0)) {
                 life.add_episode(e, trunc);
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 e.flags |= FLAG_FRESH;
             }
             STAMP(5);
-            if (OUT != OUT_NONE) {
+            if (OUT == OUT_ANY) {
                 pa = pa ? pa + AB : pa;
                 pr = pr ? pr + AB : pr;
                 pd = pd ? pd + c.B : pd;
@@ -248,7 +265,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         }
         if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
         if (OUT == OUT_TRAJ_RAW8 && !kDirect) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (kTraj) { // uniform: next tick's slabs
+            ua += AB; ur += 4 * AB; ud += c.B; ut += c.B;
+        }
         if (kDirect) {
+            uint8_t *const obs_row = uo + lo_o;
             if (active) {
                 uint8_t row[(kRawF > 0 ? kRawF : 1) + 4];
                 fill_raw<S>(c, st, e, row);
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 }
                 if ((kRawF - kW) & 1) obs_row[kRawF - 1] = row[kRawF - 1];
             }
-            obs_row += o.tick_stride;
+            uo += o.tick_stride;
         }
         STAMP(6);
     }
@@ -812,7 +833,9 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool all_traj = a.actions && a.rewards && a.done && a.trunc;
     const bool none_traj = !a.actions && !a.rewards && !a.done && !a.trunc;
     const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
-                    : (all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0) ? OUT_TRAJ_RAW8 : OUT_ANY;
+                    : (all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0 &&
+                       env->c.B <= (1 << 24)) // 32-bit lane offsets inside one tick's slab (<= 129 bytes per env)
+                        ? OUT_TRAJ_RAW8 : OUT_ANY;
 #define LAUNCH_ROLLOUT(SPEC)                                                                                       \
     do {                                                                                                           \
         if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, env->c, env->s, a, o); \
