@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
         RNG rng = make_rng<RNG>(c, s, b);
         bool done, trunc;
-        uint32_t bits = step_env<S, true, false>(c, T, st, e, rng, a.rewards, b, done, trunc);
+        uint32_t bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc);
         if (bits) atomicOr(s.err, bits);
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
@@ -196,15 +196,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // the 64 rows of a wave are contiguous, so every touched line is fully written within the tick); measured
     // faster than the LDS image + 16-byte copy-out, also when that copy-out was software-pipelined across ticks
     constexpr bool kDirect = (OUT == OUT_TRAJ_RAW8) && S::kRawF > 0;
-    uint8_t *obs_row = kDirect ? reinterpret_cast<uint8_t *>(o.out) + bb * kRawF : nullptr;
-    // OUT_TRAJ_RAW8: wave-uniform tick bases (scalar registers, bumped on the scalar unit) + a fixed 32-bit lane
-    // offset, i.e. the saddr + voffset form of the global stores; the host only selects this mode when a tick's
-    // slab of every output is below 4 GiB
+    // OUT_TRAJ_RAW8: every output goes through a buffer descriptor (wave-uniform base and size, hardware range
+    // check) with a fixed per-lane byte offset and the tick's slab offset in a scalar register, so a store costs no
+    // vector address arithmetic and a tick advances five scalar offsets.  The host only selects this mode when
+    // every output array of the launch is below 2 GiB.
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8;
-    const uint32_t lo_a = (uint32_t)(bb * A), lo_r = lo_a * 4u, lo_d = (uint32_t)bb, lo_o = (uint32_t)(bb * (kRawF > 0 ? kRawF : 0));
-    uint8_t *ua = a.actions, *ud = a.done, *ut = a.trunc, *uo = reinterpret_cast<uint8_t *>(o.out);
-    uint8_t *ur = reinterpret_cast<uint8_t *>(a.rewards);
-    if (kTraj) { pa = nullptr; pr = nullptr; pd = nullptr; pt = nullptr; obs_row = nullptr; }
+    const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+    BufDst da = make_buf_dst(a.actions, nt * (uint64_t)AB, (uint32_t)(bb * A));
+    BufDst dr = make_buf_dst(a.rewards, nt * (uint64_t)AB * 4u, (uint32_t)(bb * A) * 4u);
+    BufDst dd = make_buf_dst(a.done, nt * (uint64_t)c.B, (uint32_t)bb);
+    BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
+    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * (kRawF > 0 ? kRawF : 0)));
+    const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    if (kTraj) { pa = nullptr; pr = nullptr; pd = nullptr; pt = nullptr; }
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     unsigned long long seg2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -225,26 +229,28 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                     uint32_t av[S::kA > 0 ? S::kA : 1];
 #pragma unroll
                     for (int i = 0; i < A; i++) av[i] = st.act(i);
-                    store_row_u8<(S::kA > 0 ? S::kA : 1)>(kTraj ? ua + lo_a : pa, av);
+                    if (kTraj) store_row_u8<(S::kA > 0 ? S::kA : 1)>(da, av);
+                    else store_row_u8<(S::kA > 0 ? S::kA : 1)>(PtrDst{pa}, av);
+                } else if (kTraj) {
+                    for (int i = 0; i < A; i++) da.st8((uint32_t)i, st.act(i));
                 } else {
-                    uint8_t *const row = kTraj ? ua + lo_a : pa;
-                    for (int i = 0; i < A; i++) row[i] = (uint8_t)st.act(i);
+                    for (int i = 0; i < A; i++) pa[i] = (uint8_t)st.act(i);
                 }
             }
             STAMP(2);
-            RewardSink sink{kTraj ? (void *)(ur + lo_r) : ((OUT == OUT_ANY && pr) ? (void *)pr : nullptr), 1, 0, 0};
+            RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr};
             bool done, trunc;
 #ifdef SUSNET_STAMPS
-            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
-            else step_env<S, false, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            else step_env<S, false, 0>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
 #else
-            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, true>(c, T, st, e, rng, sink, 0, done, trunc);
-            else step_env<S, false, false>(c, T, st, e, rng, sink, 0, done, trunc);
+            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2>(c, T, st, e, rng, sink, 0, done, trunc);
+            else step_env<S, false, 0>(c, T, st, e, rng, sink, 0, done, trunc);
 #endif
             STAMP(3);
             if (kTraj) {
-                ud[lo_d] = done ? 1 : 0;
-                ut[lo_d] = trunc ? 1 : 0;
+                dd.st8(0u, done ? 1u : 0u);
+                dt.st8(0u, trunc ? 1u : 0u);
             } else if (OUT == OUT_ANY) {
                 if (pd != nullptr) *pd = done ? 1 : 0;
                 if (pt != nullptr) *pt = trunc ? 1 : 0;
@@ -265,29 +271,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         }
         if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
         if (OUT == OUT_TRAJ_RAW8 && !kDirect) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        if (kTraj) { // uniform: next tick's slabs
-            ua += AB; ur += 4 * AB; ud += c.B; ut += c.B;
-        }
         if (kDirect) {
-            uint8_t *const obs_row = uo + lo_o;
             if (active) {
                 uint8_t row[(kRawF > 0 ? kRawF : 1) + 4];
                 fill_raw<S>(c, st, e, row);
-                // 4-byte stores (naturally aligned when F % 4 == 0, otherwise the hardware's unaligned global
+                // 4-byte stores (naturally aligned when F % 4 == 0, otherwise the hardware's unaligned
                 // access splits them), then a 2-byte and a 1-byte tail
-                constexpr int kW = kRawF / 4 * 4;
+                uint32_t rv[(kRawF > 0 ? kRawF : 1)];
 #pragma unroll
-                for (int k = 0; k < kW; k += 4) {
-                    const uint32_t w = (uint32_t)row[k] | ((uint32_t)row[k + 1] << 8) | ((uint32_t)row[k + 2] << 16) | ((uint32_t)row[k + 3] << 24);
-                    __builtin_memcpy(obs_row + k, &w, 4);
-                }
-                if (kRawF - kW >= 2) {
-                    const uint16_t h = (uint16_t)(row[kW] | (row[kW + 1] << 8));
-                    __builtin_memcpy(obs_row + kW, &h, 2);
-                }
-                if ((kRawF - kW) & 1) obs_row[kRawF - 1] = row[kRawF - 1];
+                for (int k = 0; k < kRawF; k++) rv[k] = row[k];
+                store_row_u8<(kRawF > 0 ? kRawF : 1)>(dobs, rv);
             }
-            uo += o.tick_stride;
+        }
+        if (kTraj) { // wave-uniform: next tick's slabs
+            da.so += slab_a; dr.so += 4u * slab_a; dd.so += slab_d; dt.so += slab_d; dobs.so += slab_o;
         }
         STAMP(6);
     }
@@ -834,7 +831,9 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool none_traj = !a.actions && !a.rewards && !a.done && !a.trunc;
     const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
                     : (all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0 &&
-                       env->c.B <= (1 << 24)) // 32-bit lane offsets inside one tick's slab (<= 129 bytes per env)
+                       // buffer descriptors with 32-bit offsets: every output array of the launch below 2 GiB
+                       (uint64_t)a.n_ticks * (uint64_t)env->c.B * (uint64_t)(4 * env->c.A) < (1ull << 31) &&
+                       (uint64_t)a.n_ticks * (uint64_t)o.tick_stride < (1ull << 31))
                         ? OUT_TRAJ_RAW8 : OUT_ANY;
 #define LAUNCH_ROLLOUT(SPEC)                                                                                       \
     do {                                                                                                           \

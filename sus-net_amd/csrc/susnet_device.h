@@ -532,14 +532,43 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
 // ---------------------------------------------------------------------------------------------------
 // step
 // ---------------------------------------------------------------------------------------------------
+// Destination of one lane's row of a per-tick output.  PtrDst = plain address.  BufDst = buffer descriptor
+// (wave-uniform base + size, hardware range check) + fixed per-lane byte offset + wave-uniform tick offset in an
+// SGPR: the store needs no address arithmetic on the vector unit, the tick offset advances on the scalar unit.
+struct PtrDst {
+    uint8_t *p;
+    __device__ __forceinline__ void st8(uint32_t off, uint32_t v) const { p[off] = (uint8_t)v; }
+    __device__ __forceinline__ void st16(uint32_t off, uint32_t v) const { const uint16_t h = (uint16_t)v; __builtin_memcpy(p + off, &h, 2); }
+    __device__ __forceinline__ void st32(uint32_t off, uint32_t v) const { __builtin_memcpy(p + off, &v, 4); }
+    __device__ __forceinline__ void st64(uint32_t off, uint32_t a, uint32_t b) const { const uint2 w = make_uint2(a, b); __builtin_memcpy(p + off, &w, 8); }
+    __device__ __forceinline__ void st128(uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
+        const uint4 w = make_uint4(a, b, c, d); __builtin_memcpy(p + off, &w, 16);
+    }
+};
+struct BufDst {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t r;
+    uint32_t vo, so;
+    __device__ __forceinline__ void st8(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, r, vo + off, so, 0); }
+    __device__ __forceinline__ void st16(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, r, vo + off, so, 0); }
+    __device__ __forceinline__ void st32(uint32_t off, uint32_t v) const { __builtin_amdgcn_raw_buffer_store_b32(v, r, vo + off, so, 0); }
+    __device__ __forceinline__ void st64(uint32_t off, uint32_t a, uint32_t b) const {
+        const u32x2 w = {a, b}; __builtin_amdgcn_raw_buffer_store_b64(w, r, vo + off, so, 0);
+    }
+    __device__ __forceinline__ void st128(uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
+        const u32x4 w = {a, b, c, d}; __builtin_amdgcn_raw_buffer_store_b128(w, r, vo + off, so, 0);
+    }
+};
+__device__ __forceinline__ BufDst make_buf_dst(void *base, uint64_t bytes, uint32_t lane_off) {
+    // raw buffer (stride 0): num_records = bytes; word 3 as in the CDNA4 guide's descriptor recipe
+    return BufDst{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(uint32_t)bytes, 0x00020000), lane_off, 0u};
+}
+
 struct RewardSink {
     void *ptr;       // NULL = drop
     int64_t sa, sb;  // element strides for (agent, env)
     int32_t f64;     // store double instead of float
-    template <class RT>
-    __device__ __forceinline__ void put_bound(int i, int64_t, RT r) const { // float32 env-major row at ptr
-        reinterpret_cast<float *>(ptr)[i] = (float)r;
-    }
     template <class RT>
     __device__ __forceinline__ void put(int i, int64_t b, RT r) const {
         if (__builtin_expect(ptr == nullptr, 0)) return;
@@ -549,41 +578,43 @@ struct RewardSink {
     }
 };
 
-// N consecutive values at p (p is naturally aligned to N * sizeof(T) when N is a power of two): widest stores
-template <int N>
-__device__ __forceinline__ void store_row_f32(float *p, const float *v) {
+struct RewardRowSink : RewardSink { // rollout flavour
+    BufDst buf;      // SINK_ON == 2: this env's float32 row of the current tick
+};
+
+// N consecutive 4-byte values / N consecutive bytes at a row destination that is naturally aligned to N's largest
+// power-of-two divisor times the element size: widest stores
+template <int N, class D>
+__device__ __forceinline__ void store_row_f32(const D &d, const float *v) {
     if (N % 4 == 0) {
 #pragma unroll
-        for (int k = 0; k < N; k += 4) *reinterpret_cast<float4 *>(p + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+        for (int k = 0; k < N; k += 4)
+            d.st128(4u * k, __float_as_uint(v[k]), __float_as_uint(v[k + 1]), __float_as_uint(v[k + 2]), __float_as_uint(v[k + 3]));
     } else if (N % 2 == 0) {
 #pragma unroll
-        for (int k = 0; k < N; k += 2) *reinterpret_cast<float2 *>(p + k) = make_float2(v[k], v[k + 1]);
+        for (int k = 0; k < N; k += 2) d.st64(4u * k, __float_as_uint(v[k]), __float_as_uint(v[k + 1]));
     } else {
 #pragma unroll
-        for (int k = 0; k < N; k++) p[k] = v[k];
+        for (int k = 0; k < N; k++) d.st32(4u * k, __float_as_uint(v[k]));
     }
 }
-template <int N>
-__device__ __forceinline__ void store_row_u8(uint8_t *p, const uint32_t *v) { // N bytes, p aligned like N's largest power-of-two divisor
+template <int N, class D>
+__device__ __forceinline__ void store_row_u8(const D &d, const uint32_t *v) {
     constexpr int kW = N / 4 * 4;
 #pragma unroll
-    for (int k = 0; k < kW; k += 4) {
-        const uint32_t w = (v[k] & 0xffu) | ((v[k + 1] & 0xffu) << 8) | ((v[k + 2] & 0xffu) << 16) | ((v[k + 3] & 0xffu) << 24);
-        __builtin_memcpy(p + k, &w, 4);
-    }
-    if (N - kW >= 2) {
-        const uint16_t h = (uint16_t)((v[kW] & 0xffu) | ((v[kW + 1] & 0xffu) << 8));
-        __builtin_memcpy(p + kW, &h, 2);
-    }
-    if ((N - kW) & 1) p[N - 1] = (uint8_t)v[N - 1];
+    for (int k = 0; k < kW; k += 4)
+        d.st32((uint32_t)k, (v[k] & 0xffu) | ((v[k + 1] & 0xffu) << 8) | ((v[k + 2] & 0xffu) << 16) | ((v[k + 3] & 0xffu) << 24));
+    if (N - kW >= 2) d.st16((uint32_t)kW, (v[kW] & 0xffu) | ((v[kW + 1] & 0xffu) << 8));
+    if ((N - kW) & 1) d.st8((uint32_t)(N - 1), v[N - 1]);
 }
 
 __device__ __forceinline__ void set_code(uint32_t &rc, int idx, uint32_t code) { rc = (rc & ~(3u << (2 * idx))) | (code << (2 * idx)); }
 
 // returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
-// SINK_ON: the reward sink is known to be bound to this env's float32 row (rollout trajectory, [T][B][A])
-template <class S, bool VALIDATE, bool SINK_ON, class RNG, class Store>
-__device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const RewardSink &sink,
+// SINK_ON: the reward sink is bound to this env's float32 row of the rollout trajectory [T][B][A]: 1 = by pointer
+// (sink.ptr), 2 = by buffer descriptor (sink.buf); 0 = generic strided put
+template <class S, bool VALIDATE, int SINK_ON, class RNG, class Store, class Sink>
+__device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const Sink &sink,
                                              int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr) {
 #ifdef SUSNET_STAMPS
     unsigned long long sprev = __builtin_readcyclecounter();
@@ -681,7 +712,10 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         SSTAMP(1);
         // KILL: base.py:490-515.  Two wave-uniform gates (ballots): the candidate search runs only if some lane's
         // agent attempts a kill this turn, the resolution only if some lane found a victim.
-        if (__builtin_amdgcn_ballot_w64(is_kill) != 0ull) {
+        // (no outer gate with a single crew member compiled in: the search is one compare, and an imposter picks
+        // KILL with probability 1/6, so some lane of a 64-env wave nearly always does)
+        constexpr bool kOneCrewGate = !S::kGeneric && S::kA == 2;
+        if (kOneCrewGate || __builtin_amdgcn_ballot_w64(is_kill) != 0ull) {
             uint32_t cm = 0;
             const uint32_t crew = is_kill ? (e.alive & ~S::imp(c, e.imp)) : 0u;
 #pragma unroll
@@ -781,7 +815,8 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             if (SINK_ON) rr[i] = r;
             else sink.put(i, b, r);
         }
-        if (SINK_ON) store_row_f32<(S::kA > 0 ? S::kA : 1)>(reinterpret_cast<float *>(sink.ptr), rr);
+        if constexpr (SINK_ON == 2) store_row_f32<(S::kA > 0 ? S::kA : 1)>(sink.buf, rr);
+        else if (SINK_ON == 1) store_row_f32<(S::kA > 0 ? S::kA : 1)>(PtrDst{reinterpret_cast<uint8_t *>(sink.ptr)}, rr);
     } else {
 #pragma unroll
         for (int i = 0; i < A; i++) {
@@ -794,7 +829,8 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             if (i < S::n_imp(c)) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
             if (!((e.alive >> i) & 1u)) r = rw<RT>(c, RW_DEAD); // base.py:562
             if (!tagging && r == (RT)0) r = rw<RT>(c, RW_TSR);  // base.py:389-390 (tagging.py has no fill)
-            if (SINK_ON) sink.put_bound(i, b, r);
+            if constexpr (SINK_ON == 2) sink.buf.st32(4u * (uint32_t)i, __float_as_uint((float)r));
+            else if (SINK_ON == 1) reinterpret_cast<float *>(sink.ptr)[i] = (float)r;
             else sink.put(i, b, r);
         }
     }
