@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "susnet_device.h"
 #include "susnet_obs.h"
@@ -216,13 +217,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #else
 #define STAMP(k) do {} while (0)
 #endif
-    for (int tick = 0; tick < a.n_ticks; tick++) {
+    // one tick; PAR = compile-time parity of the absolute tick (0 even, 1 odd) or -1 = decided at run time
+    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
 #ifdef SUSNET_STAMPS
         tprev = __builtin_readcyclecounter();
 #endif
         STAMP(0);
         if (active) {
-            sample_actions_env<S>(c, st, e, rng, as, a.tick_base + (uint64_t)tick, tick == 0);
+            sample_actions_env<S, PAR>(c, st, e, rng, as, a.tick_base + (uint64_t)tick, tick == 0);
             STAMP(1);
             if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
                 if (!S::kGeneric) {
@@ -287,7 +290,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             da.so += slab_a; dr.so += 4u * slab_a; dd.so += slab_d; dt.so += slab_d; dobs.so += slab_o;
         }
         STAMP(6);
+    };
+    int tick = 0;
+    // 1v1 trajectory kernels: a Philox block of the action stream serves an (even, odd) pair of ticks, so the loop
+    // runs pair-wise with the word selection static and one generation per pair; a launch that starts on an odd
+    // tick or ends on an even one runs that tick through the run-time flavour
+    constexpr bool kPairs = kTraj && !S::kGeneric && S::kA == 2;
+    if (kPairs) {
+        if ((a.tick_base & 1ull) && tick < a.n_ticks) tick_body(tick++, std::integral_constant<int, -1>{});
+        for (; tick + 1 < a.n_ticks; tick += 2) {
+            tick_body(tick, std::integral_constant<int, 0>{});
+            tick_body(tick + 1, std::integral_constant<int, 1>{});
+        }
     }
+    for (; tick < a.n_ticks; tick++) tick_body(tick, std::integral_constant<int, -1>{});
 #ifdef SUSNET_STAMPS
     if (blockIdx.x == 100 && tid == 0)
         for (int k = 0; k < 8; k++) {

@@ -496,7 +496,7 @@ __device__ __forceinline__ void zero_metrics(Env &e) {
 
 // base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order.
 // TAPE: numpy semantics on the env's own word stream.  PHILOX: word tick * A + i of the action stream.
-template <class S, class Store>
+template <class S, int PAR = -1, class Store>
 __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, TapeRng &rng, ActionStream &, uint64_t, bool = true) {
     const int A = S::A(c);
     for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
@@ -505,14 +505,15 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
 // which word an agent reads is static: with A <= 2 one Philox block serves TWO ticks (even tick: words 0,1 and the
 // generation, under a scalar branch on the tick's parity; odd tick: words 2,3), otherwise W/4 blocks per tick.
 // `first` = the stream holds no block yet (a launch that starts on an odd tick must generate too).
-template <class S, class Store>
+// PAR: the tick's parity when the caller knows it at compile time (-1 = run time).
+template <class S, int PAR = -1, class Store>
 __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, PhiloxRng &rng, ActionStream &as, uint64_t tick,
                                                    bool first = true) {
     const int A = S::A(c);
     if (A <= 2) {
-        const bool odd = (tick & 1ull) != 0ull;
+        const bool odd = PAR >= 0 ? (PAR == 1) : ((tick & 1ull) != 0ull);
         const uint64_t b = tick >> 1;
-        if (!odd || first) as.gen(rng, b);
+        if (PAR == 0 || (PAR < 0 && (!odd || first))) as.gen(rng, b); // PAR == 1: the even tick of the pair generated it
 #pragma unroll
         for (int i = 0; i < A; i++) {
             const uint32_t w = odd ? (i == 0 ? as.w2 : as.w3) : (i == 0 ? as.w0 : as.w1);

@@ -301,13 +301,22 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
         np.testing.assert_array_equal(obs[s], ob.obs_raw_u8(), err_msg=f"{name} raw obs tick {s}")
     env._export(full=True)
     compare_full_state(env, ob, f"{name} after rollout")
-    # a second launch continues the same streams
-    traj2 = env.rollout(7)
-    for s in range(7):
-        oa = ob.sample_actions()
-        np.testing.assert_array_equal(np_(traj2["actions"])[s], oa)
-        orew, odone, otrunc, _ = ob.step(oa)
-        ob.reset(mask=(odone | otrunc).astype(bool))
+    # further launches continue the same streams: odd lengths and odd starting ticks (the 1v1 kernels walk the
+    # action stream in (even, odd) tick pairs), with and without the trajectory-mode outputs
+    for n, with_obs in ((7, False), (5, True), (1, True), (2, True), (3, False), (4, True)):
+        traj2 = env.rollout(n, obs=pkg.ObsConfig("raw", dtype=torch.uint8) if with_obs else None)
+        torch.cuda.synchronize()
+        for s in range(n):
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(traj2["actions"])[s], oa, err_msg=f"{name} launch of {n}, tick {s}")
+            orew, odone, otrunc, _ = ob.step(oa)
+            assert np.array_equal(np_(traj2["rewards"])[s].astype(np.float64).view(np.uint64), orew.view(np.uint64))
+            np.testing.assert_array_equal(np_(traj2["done"])[s], odone.astype(bool))
+            ob.reset(mask=(odone | otrunc).astype(bool))
+            if with_obs:
+                np.testing.assert_array_equal(np_(traj2["obs"])[s], ob.obs_raw_u8())
+    env._export(full=True)
+    compare_full_state(env, ob, f"{name} after the short launches")
 
 
 @pytest.mark.parametrize("name,B", [("base_2v6_j4_14", 32768 + 96), ("itg_1v1_nowalls", 65536 + 32), ("base_1v2_j4_14", 40000),
