@@ -217,6 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #else
 #define STAMP(k) do {} while (0)
 #endif
+    if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
     // one tick; PAR = compile-time parity of the absolute tick (0 even, 1 odd) or -1 = decided at run time
     auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
@@ -244,11 +245,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr};
             bool done, trunc;
 #ifdef SUSNET_STAMPS
-            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
-            else step_env<S, false, 0>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
 #else
-            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2>(c, T, st, e, rng, sink, 0, done, trunc);
-            else step_env<S, false, 0>(c, T, st, e, rng, sink, 0, done, trunc);
+            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc);
+            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc);
 #endif
             STAMP(3);
             if (kTraj) {
@@ -262,7 +263,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             if (__builtin_expect(done || trunc, 0)) {
                 life.add_episode(e, trunc);
                 reset_env<S>(c, T, st, tid, e, rng);
-                e.flags |= FLAG_FRESH;
+                // info counters of a terminal step stay readable until the next step: only the launch's last
+                // tick can be observed, every other episode end zeroes them right away (wave-uniform branch)
+                if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+                else zero_metrics(e);
             }
             STAMP(5);
             if (OUT == OUT_ANY) {

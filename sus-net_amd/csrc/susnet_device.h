@@ -611,10 +611,23 @@ __device__ __forceinline__ void store_row_u8(const D &d, const uint32_t *v) {
 
 __device__ __forceinline__ void set_code(uint32_t &rc, int idx, uint32_t code) { rc = (rc & ~(3u << (2 * idx))) | (code << (2 * idx)); }
 
+// lazy metrics.reset() of an auto-reset episode: the terminal step's info counters stay readable until the next
+// step (select form: no branch on the stepping path)
+__device__ __forceinline__ void clear_info_if_fresh(Env &e) {
+    const bool fresh = (e.flags & FLAG_FRESH) != 0u;
+    e.m_steps = fresh ? 0u : e.m_steps;
+    e.m_fix = fresh ? 0u : e.m_fix;
+    e.m_sab = fresh ? 0u : e.m_sab;
+    e.m_kv = fresh ? 0u : e.m_kv;
+    e.flags = fresh ? (e.flags & ~(FLAG_FRESH | FLAG_CREW_WON | FLAG_IMP_WON)) : e.flags;
+}
+
 // returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
 // SINK_ON: the reward sink is bound to this env's float32 row of the rollout trajectory [T][B][A]: 1 = by pointer
 // (sink.ptr), 2 = by buffer descriptor (sink.buf); 0 = generic strided put
-template <class S, bool VALIDATE, int SINK_ON, class RNG, class Store, class Sink>
+// LAZY_INFO = false: the caller guarantees the env is not FRESH (the fused rollout clears once before its loop and
+// zeroes the counters itself at an episode end that is not the launch's last tick)
+template <class S, bool VALIDATE, int SINK_ON, bool LAZY_INFO = true, class RNG, class Store, class Sink>
 __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const Sink &sink,
                                              int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr) {
 #ifdef SUSNET_STAMPS
@@ -641,14 +654,7 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             return bits;
         }
     }
-    { // lazy metrics.reset() of an auto-reset episode (select form: no branch on the stepping path)
-        const bool fresh = (e.flags & FLAG_FRESH) != 0u;
-        e.m_steps = fresh ? 0u : e.m_steps;
-        e.m_fix = fresh ? 0u : e.m_fix;
-        e.m_sab = fresh ? 0u : e.m_sab;
-        e.m_kv = fresh ? 0u : e.m_kv;
-        e.flags = fresh ? (e.flags & ~(FLAG_FRESH | FLAG_CREW_WON | FLAG_IMP_WON)) : e.flags;
-    }
+    if (LAZY_INFO) clear_info_if_fresh(e);
     e.m_steps += 1; // base.py:366
     using RT = typename S::RT;
     uint32_t rc = 0; // 2-bit reward code per agent

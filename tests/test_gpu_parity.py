@@ -297,10 +297,14 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
         assert np.array_equal(rews[s].astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
         np.testing.assert_array_equal(dones[s], odone.astype(bool))
         np.testing.assert_array_equal(truncs[s], otrunc.astype(bool))
+        if s == T - 1:
+            last_info = ob.export()["metrics"].copy()  # info of the launch's last tick, before any reset
         ob.reset(mask=(odone | otrunc).astype(bool))
         np.testing.assert_array_equal(obs[s], ob.obs_raw_u8(), err_msg=f"{name} raw obs tick {s}")
     env._export(full=True)
     compare_full_state(env, ob, f"{name} after rollout")
+    # the info counters of the last tick stay readable (also for envs whose episode ended on it)
+    np.testing.assert_array_equal(np_(env._metrics), last_info, err_msg=f"{name} info after rollout")
     # further launches continue the same streams: odd lengths and odd starting ticks (the 1v1 kernels walk the
     # action stream in (even, odd) tick pairs), with and without the trajectory-mode outputs
     for n, with_obs in ((7, False), (5, True), (1, True), (2, True), (3, False), (4, True)):
