@@ -114,6 +114,8 @@ struct Spec {
     // roles: with shuffle_imposter_index off the imposters are always agents [0, n_imp) (base.py:278)
     __device__ static __forceinline__ int n_imp(const Consts &c) { return NI_ >= 0 ? NI_ : c.n_imp; }
     __device__ static __forceinline__ uint32_t imp(const Consts &, uint32_t env_mask) { return (SHUF_ == 0 && NI_ >= 0) ? ((1u << (NI_ >= 0 ? NI_ : 0)) - 1u) : env_mask; }
+    static constexpr bool kStaticRoles = SHUF_ == 0 && NI_ >= 0;
+    __device__ static __forceinline__ bool shuffle_imp(const Consts &c) { return SHUF_ >= 0 ? (SHUF_ != 0) : (c.shuffle_imp != 0); }
     __device__ static __forceinline__ uint32_t nr_crew(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 5u : 6u) : (uint32_t)c.nr_crew; }
 };
 using GenericSpec = Spec<-1, -1, -1, -1>;
@@ -435,7 +437,7 @@ template <class S, class RNG, class Store>
 __device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Store &st, int tid, Env &e, RNG &rng) {
     const int A = S::A(c), J = S::J(c);
     rng.align();
-    if (c.shuffle_imp) {
+    if (S::shuffle_imp(c)) {
         if (RNG::kNumpy) {
             uint64_t perm = 0xFEDCBA9876543210ull;
             shuffle_nibbles<false>(rng, perm, A); // choice(range(A), n_imp, replace=False) == permutation(A)[:n_imp]
@@ -450,11 +452,14 @@ __device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Stor
             }
         }
     } else {
-        e.imp = (1u << c.n_imp) - 1u; // np.arange(n_imposters), base.py:278
+        e.imp = (1u << S::n_imp(c)) - 1u; // np.arange(n_imposters), base.py:278
     }
+    // roles compiled in: the agent cells are draws 0..A-1 of the run that starts at the align() above, so the
+    // words are picked statically (no block-cache check, no select)
+    constexpr bool kStaticRun = !RNG::kNumpy && !S::kGeneric && S::kStaticRoles;
 #pragma unroll
     for (int i = 0; i < A; i++) { // base.py:288-291, with replacement
-        uint32_t cell = rng.bounded((uint32_t)c.n_valid);
+        uint32_t cell = kStaticRun ? rng.bounded_at((uint32_t)c.n_valid, i) : rng.bounded((uint32_t)c.n_valid);
         st.set_agent(i, T.valid[cell], 0u); // tagging.py:64: counts cleared
     }
     if (RNG::kNumpy) {
