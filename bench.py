@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="fused", choices=["fused", "step"])
     ap.add_argument("--obs", default="raw", choices=["none", "raw", "flat", "planes"])
-    ap.add_argument("--ticks", type=int, default=128, help="ticks per fused launch")
+    ap.add_argument("--ticks", type=int, default=512, help="ticks per fused launch")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -280,7 +280,7 @@ def main():
     b_stored = stored_bytes_per_step(A, J, N, args.obs)
     achieved = steps_per_launch * b_alg / avg_launch_s / 1e9
     traffic, traffic_src = (None, None)
-    if args.mode == "fused" and args.config == "cfg2" and B == 65536 and args.ticks == 128 and world == 1:
+    if args.mode == "fused" and args.config == "cfg2" and B == 65536 and args.ticks == 512 and world == 1:
         traffic, traffic_src = profiled_traffic("void k_rollout", args.obs)
     line = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -324,17 +324,18 @@ def main():
                 continue
             k3 = 512
             save_mode, save_ticks = args.mode, args.ticks
-            args.mode = "fused"
+            args.mode, args.ticks = "fused", min(args.ticks, 128)  # planes f32 at 128 ticks is already an 11 GB trajectory
             r3 = measure("fused", om, k3, 128)
-            args.mode = save_mode
+            sweep_ticks = args.ticks
+            args.mode, args.ticks = save_mode, save_ticks
             per_launch_s = (r3["per_launch_us"] / 1e6) if r3.get("per_launch_us") else (r3["device_ms"] / 1e3) / r3["launches"]
             bs = stored_bytes_per_step(A, J, N, om)
             ba = algorithmic_bytes_per_step(A, J, N, om)
             line["obs_modes"].append({
                 "obs": om + ("(onehot_pos)" if om == "flat" else "") + " f32", "value": B * k3 / r3["seconds"], "unit": "env-steps/s",
                 "algorithmic_bytes_per_env_step": ba, "stored_bytes_per_env_step": bs,
-                "achieved_GBs": B * args.ticks * ba / per_launch_s / 1e9, "frac": B * args.ticks * ba / per_launch_s / 1e9 / HBM_PEAK_GBS,
-                "avg_launch_us": per_launch_s * 1e6})
+                "achieved_GBs": B * sweep_ticks * ba / per_launch_s / 1e9, "frac": B * sweep_ticks * ba / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                "ticks_per_launch": sweep_ticks, "avg_launch_us": per_launch_s * 1e6})
             del r3
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(spec)

@@ -3,6 +3,7 @@
 // Build:  hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o libsusnet_hip.so susnet_capi.hip
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -849,12 +850,19 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const dim3 g((unsigned)((env->c.B + env->c.epw - 1) / env->c.epw)), blk(kBlock);
     const bool all_traj = a.actions && a.rewards && a.done && a.trunc;
     const bool none_traj = !a.actions && !a.rewards && !a.done && !a.trunc;
-    const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
-                    : (all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0 &&
-                       // buffer descriptors with 32-bit offsets: every output array of the launch below 2 GiB
-                       (uint64_t)a.n_ticks * (uint64_t)env->c.B * (uint64_t)(4 * env->c.A) < (1ull << 31) &&
-                       (uint64_t)a.n_ticks * (uint64_t)o.tick_stride < (1ull << 31))
-                        ? OUT_TRAJ_RAW8 : OUT_ANY;
+    // trajectory mode addresses every output through a buffer descriptor with 32-bit offsets: a launch covers at most
+    // as many ticks as keep every output array below 2 GiB; longer requests run as consecutive launches
+    const bool traj = all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0;
+    const uint64_t AB = (uint64_t)env->c.A * (uint64_t)env->c.B;
+    const uint64_t tick_bytes = std::max<uint64_t>(4u * AB, (uint64_t)o.tick_stride);
+    uint64_t limit = (1ull << 31) - 1u;
+    if (const char *ev = getenv("SUSNET_TRAJ_MAX_BYTES")) { // tests: exercise the chunking on small batches
+        const long long v = atoll(ev);
+        if (v > 0 && (uint64_t)v < limit) limit = (uint64_t)v;
+    }
+    const uint64_t fit = limit / tick_bytes;
+    const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE : (traj && fit >= 1) ? OUT_TRAJ_RAW8 : OUT_ANY;
+    const int chunk = out == OUT_TRAJ_RAW8 ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
 #define LAUNCH_ROLLOUT(SPEC)                                                                                       \
     do {                                                                                                           \
         if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, env->c, env->s, a, o); \
@@ -862,16 +870,27 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, env->c, env->s, a, o);            \
         else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, env->c, env->s, a, o);                 \
     } while (0)
-    if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
-    else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
-    else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
-    else if (spec == 6) LAUNCH_ROLLOUT(SpecTag5);
+    for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
+        a.n_ticks = std::min(chunk, io->n_ticks - t0);
+        a.tick_base = env->ticks + (uint64_t)t0;
+        if (t0 > 0) { // only reached in trajectory mode: all five outputs are bound, [T][B][...] slabs
+            a.actions += (uint64_t)chunk * AB;
+            a.rewards += (uint64_t)chunk * AB;
+            a.done += (uint64_t)chunk * (uint64_t)env->c.B;
+            a.trunc += (uint64_t)chunk * (uint64_t)env->c.B;
+            o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (uint64_t)o.tick_stride;
+        }
+        if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
+        else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
+        else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
+        else if (spec == 6) LAUNCH_ROLLOUT(SpecTag5);
 #define ROLL_A(N) else if (spec == 10 + N) LAUNCH_ROLLOUT(SpecA<N>);
-    ROLL_A(2) ROLL_A(3) ROLL_A(4) ROLL_A(5) ROLL_A(6) ROLL_A(7) ROLL_A(8)
+        ROLL_A(2) ROLL_A(3) ROLL_A(4) ROLL_A(5) ROLL_A(6) ROLL_A(7) ROLL_A(8)
 #undef ROLL_A
-    else LAUNCH_ROLLOUT(GenericSpec);
+        else LAUNCH_ROLLOUT(GenericSpec);
+        HIP_TRY(hipGetLastError());
+    }
 #undef LAUNCH_ROLLOUT
-    HIP_TRY(hipGetLastError());
     env->ticks += (uint64_t)io->n_ticks;
     return SUSNET_OK;
 }

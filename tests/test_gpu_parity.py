@@ -323,6 +323,30 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
     compare_full_state(env, ob, f"{name} after the short launches")
 
 
+def test_long_trajectory_launches_are_chunked(pkg, oracle_mod, monkeypatch):
+    """Trajectory-mode kernels address outputs with 32-bit offsets; requests whose arrays would pass 2 GiB run as
+    consecutive launches.  Forced here with a small limit: 7 ticks per launch, i.e. odd starts and a ragged tail."""
+    name, B, T, seed = "itg_1v1_nowalls", 1000, 45, 5
+    monkeypatch.setenv("SUSNET_TRAJ_MAX_BYTES", str(7 * 8 * B + 100))
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+    env.reset()
+    ob.reset()
+    traj = env.rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    torch.cuda.synchronize()
+    for s in range(T):
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(np_(traj["actions"])[s], oa, err_msg=f"actions tick {s}")
+        orew, odone, otrunc, _ = ob.step(oa)
+        assert np.array_equal(np_(traj["rewards"])[s].astype(np.float64).view(np.uint64), orew.view(np.uint64))
+        np.testing.assert_array_equal(np_(traj["done"])[s], odone.astype(bool))
+        np.testing.assert_array_equal(np_(traj["truncated"])[s], otrunc.astype(bool))
+        ob.reset(mask=(odone | otrunc).astype(bool))
+        np.testing.assert_array_equal(np_(traj["obs"])[s], ob.obs_raw_u8(), err_msg=f"raw obs tick {s}")
+    env._export(full=True)
+    compare_full_state(env, ob, "after chunked rollout")
+    assert int(env.tick) == T
+
+
 @pytest.mark.parametrize("name,B", [("base_2v6_j4_14", 32768 + 96), ("itg_1v1_nowalls", 65536 + 32), ("base_1v2_j4_14", 40000),
                                     ("tagging_1v4_j5", 4096), ("itg_1v5_j3", 2048)])
 def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B):
