@@ -164,7 +164,14 @@ template <class S, int OUT>
 __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
     const int tid = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * c.epw, b = b0 + tid;
+    // XCD-aware wave -> environment-block mapping: workgroup ids are dealt round-robin to the 8 XCDs, each with its
+    // own L2.  Consecutive env blocks write adjacent pieces of the same 128-byte lines (a wave's 64 done flags are
+    // half a line), so they are given to workgroups of the SAME XCD, dispatched back to back: the halves meet in one
+    // L2 instead of leaving two XCDs as partial-line write-backs.
+    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t per = nblk >> 3, rem = nblk & 7u;
+    const uint32_t wave_id = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    const int64_t b0 = (int64_t)wave_id * c.epw, b = b0 + tid;
     const bool active = tid < c.epw && b < c.B;
     const int nrows = (int)((c.B - b0) < c.epw ? (c.B - b0) : c.epw);
     const int A = S::A(c);
