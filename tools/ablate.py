@@ -11,8 +11,8 @@ import bench  # noqa: E402
 pkg = importlib.import_module("sus-net_amd")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 spec = bench.CONFIGS[cfg]
-B, T, reps = spec["batch"], 128, 16
-for obs in ("raw", "none", "flat", "planes"):
+B, T, reps = spec["batch"], int(sys.argv[2]) if len(sys.argv) > 2 else 512, 16
+for obs in (("raw", "none") if T > 128 else ("raw", "none", "flat", "planes")):  # float32 planes at 512 ticks would be a 44 GB buffer
     for store in (("actions", "rewards", "done", "truncated"), ()):
         env = bench.make_env(pkg, spec, B, 1234, 0, torch.device("cuda:0"))
         env.reset()
