@@ -115,6 +115,7 @@ struct Spec {
     __device__ static __forceinline__ int n_imp(const Consts &c) { return NI_ >= 0 ? NI_ : c.n_imp; }
     __device__ static __forceinline__ uint32_t imp(const Consts &, uint32_t env_mask) { return (SHUF_ == 0 && NI_ >= 0) ? ((1u << (NI_ >= 0 ? NI_ : 0)) - 1u) : env_mask; }
     static constexpr bool kStaticRoles = SHUF_ == 0 && NI_ >= 0;
+    static constexpr bool kFixedOrder = ORD_ == 0;
     __device__ static __forceinline__ bool shuffle_imp(const Consts &c) { return SHUF_ >= 0 ? (SHUF_ != 0) : (c.shuffle_imp != 0); }
     __device__ static __forceinline__ uint32_t nr_crew(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 5u : 6u) : (uint32_t)c.nr_crew; }
 };
@@ -727,7 +728,18 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
         // (no outer gate with a single crew member compiled in: the search is one compare, and an imposter picks
         // KILL with probability 1/6, so some lane of a 64-env wave nearly always does)
         constexpr bool kOneCrewGate = !S::kGeneric && S::kA == 2;
-        if (kOneCrewGate || __builtin_amdgcn_ballot_w64(is_kill) != 0ull) {
+        // 1v1 with roles and order compiled in (imposter = agent 0, its only possible victim = agent 1): the whole
+        // kill is a handful of selects, no gate, no branch
+        constexpr bool kDuel = !S::kGeneric && S::kA == 2 && S::kStaticRoles && S::kFixedOrder && !RNG::kNumpy;
+        if (kDuel) {
+            if (k == 0) {
+                const bool hit = is_kill && ((e.alive >> 1) & 1u) && st.xy(1) == xy;
+                rng.cur += hit ? 1ull : 0ull;            // production protocol: one (unused) word per kill
+                e.m_kv += hit ? 1u : 0u;                  // IMP_KILLED_CREW, base.py:508
+                e.alive &= hit ? ~2u : ~0u;               // base.py:511
+                rc = hit ? ((rc & ~15u) | (RC_KILL << 2) | RC_KILL) : rc; // base.py:514-515
+            }
+        } else if (kOneCrewGate || __builtin_amdgcn_ballot_w64(is_kill) != 0ull) {
             uint32_t cm = 0;
             const uint32_t crew = is_kill ? (e.alive & ~S::imp(c, e.imp)) : 0u;
 #pragma unroll
