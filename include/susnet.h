@@ -67,11 +67,13 @@ extern "C" {
 #define SUSNET_E_ACTION_ASSERT (-4) /* some env got action >= action_space.n (base.py:360-362) */
 #define SUSNET_E_ACTION_INDEX (-5)  /* some env got a role-invalid action index (base.py:379-382) */
 #define SUSNET_E_TAPE (-6)     /* random tape exhausted */
+#define SUSNET_E_ROW (-7)      /* susnet_featurize: a state row holds a coordinate outside the grid */
 
 /* bits of the device error word */
 #define SUSNET_ERRBIT_ASSERT 1u
 #define SUSNET_ERRBIT_INDEX 2u
 #define SUSNET_ERRBIT_TAPE 4u
+#define SUSNET_ERRBIT_ROW 8u
 
 /* dtypes of caller buffers */
 #define SUSNET_U8 0
@@ -227,6 +229,19 @@ int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
 int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);
 int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *size_out, int32_t *size2_out);
 
+/* Observation of n_rows FLATTENED states instead of the handle's own environments: what the reference's
+ * sequence featurizers do with a state window or a replay batch -- SequenceStateFeaturizer.fit(state_sequence
+ * [B, T, S]) un-flattens every state and featurises it (src/features/model_ready.py:41-57; FlatFeaturizer.fit
+ * 338-354, GlobalFeaturizer.fit 254-289; the trainer calls it on windows train.py:345-347 and on replay batches).
+ * rows: device pointer, [n_rows][S] contiguous, S = susnet_layout.obs_raw_size (flatten_state order, base.py:234:
+ * x0,y0,.. alive.. jobxy.. jobdone.. (, used, counts, timer_left)), rows_dtype one of SUSNET_U8 / I32 / I64 / F32 /
+ * F64 (integer-valued).  obs->out (/out2) receive [n_rows][obs_size] in the layouts of susnet_observe; obs->mode
+ * FLAT or PLANES.  A row with a coordinate outside the grid is written as all zeros and reported by
+ * susnet_poll_errors (SUSNET_E_ROW).  The handle supplies the configuration (A, J, N, wall map) only; its
+ * environments are not touched. */
+int susnet_featurize(susnet_env *env, const void *rows, int32_t rows_dtype, int64_t n_rows, const susnet_obs_spec *obs,
+                     void *stream);
+
 int susnet_export_state(susnet_env *env, const susnet_state_view *view, void *stream);
 int susnet_import_state(susnet_env *env, const susnet_state_view *view, void *stream);
 
@@ -235,7 +250,7 @@ int susnet_import_state(susnet_env *env, const susnet_state_view *view, void *st
 int susnet_reduce_lifetime(susnet_env *env, int64_t *out_device, void *stream);
 
 /* Synchronises `stream`, reads and clears the device error word. Returns 0 or the most severe
- * SUSNET_E_ACTION_* / SUSNET_E_TAPE code; *bits_out receives the raw bits. */
+ * SUSNET_E_ACTION_* / SUSNET_E_TAPE / SUSNET_E_ROW code; *bits_out receives the raw bits. */
 int susnet_poll_errors(susnet_env *env, uint32_t *bits_out, void *stream);
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@ RNG_TAPE, RNG_PHILOX = 1, 2
 U8, I32, I64, F32, F64 = 0, 1, 2, 3, 4
 LAYOUT_AB, LAYOUT_BA = 0, 1
 OBS_NONE, OBS_RAW, OBS_FLAT, OBS_PLANES = 0, 1, 2, 3
-E_INVALID, E_HIP, E_STATE, E_ACTION_ASSERT, E_ACTION_INDEX, E_TAPE = -1, -2, -3, -4, -5, -6
+E_INVALID, E_HIP, E_STATE, E_ACTION_ASSERT, E_ACTION_INDEX, E_TAPE, E_ROW = -1, -2, -3, -4, -5, -6, -7
 
 FLAT_COMPONENTS = {"onehot_pos": 0, "coord_pos": 1, "alive_crew": 2, "l1_crew": 3, "closest_crew": 4,
                    "walls3x3": 5, "dist_to_imp": 6, "room_loc": 7}
@@ -31,7 +31,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
     "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_step",
-    "susnet_rollout", "susnet_observe", "susnet_obs_size", "susnet_export_state", "susnet_import_state",
+    "susnet_rollout", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_poll_errors",
 ]
 
@@ -146,6 +146,7 @@ def lib():
     L.susnet_rollout.argtypes = [C.c_void_p, P(RolloutIO), C.c_void_p]
     L.susnet_observe.argtypes = [C.c_void_p, P(ObsSpec), C.c_void_p]
     L.susnet_obs_size.argtypes = [C.c_void_p, P(ObsSpec), P(C.c_int32), P(C.c_int32)]
+    L.susnet_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, P(ObsSpec), C.c_void_p]
     L.susnet_export_state.argtypes = [C.c_void_p, P(StateView), C.c_void_p]
     L.susnet_import_state.argtypes = [C.c_void_p, P(StateView), C.c_void_p]
     L.susnet_reduce_lifetime.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -346,6 +346,63 @@ __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
 
+// Observation of caller-supplied flattened states (flatten_state order) instead of the handle's environments:
+// lane r parses row b0 + r into the same per-lane storage the state loader fills, then the wave runs the same
+// cooperative writer.  A wave's 64 rows are contiguous in memory, so the per-lane element reads hit the same lines.
+__device__ __forceinline__ int row_value(const void *rows, int dtype, int64_t k) {
+    switch (dtype) {
+    case SUSNET_U8: return (int)static_cast<const uint8_t *>(rows)[k];
+    case SUSNET_I32: return static_cast<const int32_t *>(rows)[k];
+    case SUSNET_I64: return (int)static_cast<const int64_t *>(rows)[k];
+    case SUSNET_F32: return (int)static_cast<const float *>(rows)[k];
+    default: return (int)static_cast<const double *>(rows)[k];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_featurize(Consts c, const void *rows, int dtype, int64_t n_rows, int S_row, uint32_t *err, ObsArgs o) {
+    using S = GenericSpec;
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+    bool active = b < n_rows;
+    LdsStore st;
+    Tables T = setup_lds<S, false>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
+    Env e = {};
+    if (active) {
+        const int A = c.A, J = c.J, N = c.N;
+        const bool tagging = c.variant == SUSNET_VARIANT_TAGGING;
+        const int64_t base = b * S_row;
+        bool ok = true;
+        int k = 0;
+        for (int i = 0; i < A; i++, k += 2) {
+            const int x = row_value(rows, dtype, base + k), y = row_value(rows, dtype, base + k + 1);
+            ok = ok && (unsigned)x < (unsigned)N && (unsigned)y < (unsigned)N;
+            st.set_agent(i, (uint32_t)(x & 15) | ((uint32_t)(y & 15) << 4), 0u);
+        }
+        for (int i = 0; i < A; i++, k++) e.alive |= (row_value(rows, dtype, base + k) != 0 ? 1u : 0u) << i;
+        if (J > 0 || tagging) {
+            for (int j = 0; j < J; j++, k += 2) {
+                const int x = row_value(rows, dtype, base + k), y = row_value(rows, dtype, base + k + 1);
+                ok = ok && (unsigned)x < (unsigned)N && (unsigned)y < (unsigned)N;
+                st.set_job(j, (uint32_t)(x & 15) | ((uint32_t)(y & 15) << 4));
+            }
+            for (int j = 0; j < J; j++, k++) e.jd |= (row_value(rows, dtype, base + k) != 0 ? 1u : 0u) << j;
+        }
+        if (tagging) { // tagging.py:220-230: used[A], tag_counts[A], interval - timer
+            for (int i = 0; i < A; i++, k++) e.used |= (row_value(rows, dtype, base + k) != 0 ? 1u : 0u) << i;
+            for (int i = 0; i < A; i++, k++) st.set_cnt(i, (uint32_t)row_value(rows, dtype, base + k) & 15u);
+            e.timer = (uint32_t)(c.tag_interval - row_value(rows, dtype, base + k));
+        }
+        if (!ok) {
+            atomicOr(err, SUSNET_ERRBIT_ROW);
+            active = false; // the row stays all zeros
+        }
+    }
+    const int nrows = (int)((n_rows - b0) < kBlock ? (n_rows - b0) : kBlock);
+    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
+}
+
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
 using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>; // ImposterTrainingGround 1v1, no jobs, fixed order, imposter = agent 0 (any wall map)
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
@@ -914,6 +971,27 @@ extern "C" int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void 
     return SUSNET_OK;
 }
 
+extern "C" int susnet_featurize(susnet_env *env, const void *rows, int32_t rows_dtype, int64_t n_rows, const susnet_obs_spec *obs,
+                                void *stream) {
+    if (int rc = check_bound(env)) return rc; // the device error word lives in the bound state blob
+    if (!rows || n_rows < 0) return fail(SUSNET_E_INVALID, "rows is null / n_rows negative");
+    if (!obs || (obs->mode != SUSNET_OBS_FLAT && obs->mode != SUSNET_OBS_PLANES))
+        return fail(SUSNET_E_INVALID, "susnet_featurize: obs mode must be FLAT or PLANES");
+    if (rows_dtype != SUSNET_U8 && rows_dtype != SUSNET_I32 && rows_dtype != SUSNET_I64 && rows_dtype != SUSNET_F32 &&
+        rows_dtype != SUSNET_F64)
+        return fail(SUSNET_E_INVALID, "rows dtype must be U8 / I32 / I64 / F32 / F64");
+    if (n_rows == 0) return SUSNET_OK;
+    ObsArgs o;
+    if (int rc = build_obs(env, obs, o, n_rows)) return rc;
+    size_t sh = lds_bytes(env, o, false);
+    CHECK_LDS(sh);
+    const dim3 g((unsigned)((n_rows + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_featurize, g, dim3(kBlock), sh, static_cast<hipStream_t>(stream), env->c, rows, (int)rows_dtype, n_rows,
+                       (int)env->layout.obs_raw_size, env->s.err, o);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
 extern "C" int susnet_export_state(susnet_env *env, const susnet_state_view *view, void *stream) {
     if (int rc = check_bound(env)) return rc;
     if (!view) return fail(SUSNET_E_INVALID, "null view");
@@ -959,5 +1037,6 @@ extern "C" int susnet_poll_errors(susnet_env *env, uint32_t *bits_out, void *str
     if (bits & SUSNET_ERRBIT_ASSERT) return fail(SUSNET_E_ACTION_ASSERT, "Invalid action(s): action >= action_space.n");
     if (bits & SUSNET_ERRBIT_INDEX) return fail(SUSNET_E_ACTION_INDEX, "role-invalid action index");
     if (bits & SUSNET_ERRBIT_TAPE) return fail(SUSNET_E_TAPE, "random tape exhausted");
+    if (bits & SUSNET_ERRBIT_ROW) return fail(SUSNET_E_ROW, "susnet_featurize: a state row holds a coordinate outside the grid");
     return SUSNET_OK;
 }

@@ -99,8 +99,8 @@ __device__ __forceinline__ void fill_flat(const Consts &c, const ObsArgs &o, con
             for (int i = 0; i < A; i++)
                 if ((e.alive >> i) & 1u) {
                     uint32_t w = st.xy(i);
-                    put_b(row, k + i * 2 * N + (int)(w & 15u), 1);
-                    put_b(row, k + i * 2 * N + N + (int)((w >> 4) & 15u), 1);
+                    if ((int)(w & 15u) < N) put_b(row, k + i * 2 * N + (int)(w & 15u), 1); // (cells of imported states are
+                    if ((int)((w >> 4) & 15u) < N) put_b(row, k + i * 2 * N + N + (int)((w >> 4) & 15u), 1); //  not range-checked elsewhere)
                 }
             break;
         case SUSNET_F_COORD_POS: // component.py:389-399
@@ -183,12 +183,14 @@ __device__ __forceinline__ void fill_planes(const Consts &c, const Store &st, co
     for (int i = 0; i < A; i++) // component.py:90-100: channel i, [x][y], only if alive
         if ((e.alive >> i) & 1u) {
             uint32_t w = st.xy(i);
+            if ((int)(w & 15u) >= N || (int)((w >> 4) & 15u) >= N) continue; // never leave this row's bit range
             int g = rowbit0 + i * NN + (int)(w & 15u) * N + (int)((w >> 4) & 15u);
             atomicOr(&bits[g >> 5], 1u << (g & 31));
         }
 #pragma unroll
     for (int j = 0; j < J; j++) { // component.py:116-127: channel A + int(done)
         uint32_t w = st.job(j);
+        if ((int)(w & 15u) >= N || (int)((w >> 4) & 15u) >= N) continue;
         int g = rowbit0 + (A + (int)((e.jd >> j) & 1u)) * NN + (int)(w & 15u) * N + (int)((w >> 4) & 15u);
         atomicOr(&bits[g >> 5], 1u << (g & 31));
     }

@@ -278,7 +278,8 @@ class BatchedFourRoomEnv:
                 pass
             self._h = None
 
-    def _make_obs(self, oc: ObsConfig, ticks: int):
+    def _make_obs(self, oc: ObsConfig, ticks: int, rows: Optional[int] = None):
+        """Spec + output tensors for ``ticks`` x batch observations (or for ``rows`` free-standing rows)."""
         if oc.mode is None:
             return None, None, None
         spec = L.ObsSpec()
@@ -292,7 +293,7 @@ class BatchedFourRoomEnv:
         if rc == L.E_INVALID:
             raise ValueError(self.lib.susnet_last_error().decode())
         L.check(rc)
-        lead = (ticks, self.batch) if ticks > 1 else (self.batch,)
+        lead = (rows,) if rows is not None else ((ticks, self.batch) if ticks > 1 else (self.batch,))
         A, N = self.n_agents, self.n_rows
         shape1 = (*lead, A + 2, N, N) if oc.mode == "planes" else (*lead, f1.value)
         out = torch.zeros(shape1, dtype=oc.dtype, device=self.device)
@@ -528,6 +529,30 @@ class BatchedFourRoomEnv:
             torch.cuda.current_stream(self.device).synchronize()
         return (o1, o2) if o2 is not None else o1
 
+    _ROW_DTYPES = {torch.uint8: L.U8, torch.int32: L.I32, torch.int64: L.I64, torch.float32: L.F32, torch.float64: L.F64}
+
+    def featurize(self, states: torch.Tensor, obs: ObsConfig):
+        """Observation of caller-supplied FLATTENED states ``[..., S]`` (``flatten_state`` order, S =
+        ``flattened_state_size``) instead of the env's own state: the reference's
+        ``SequenceStateFeaturizer.fit(state_sequence[B, T, S])`` (src/features/model_ready.py:41-57) for a window
+        or a replay batch.  Returns tensors with the same leading dimensions as ``states``."""
+        assert obs.mode in ("flat", "planes"), "featurize() produces the flat / planes feature layouts"
+        assert states.shape[-1] == self.flattened_state_size, (
+            f"expected rows of {self.flattened_state_size} values, got {states.shape[-1]}")
+        assert states.dtype in self._ROW_DTYPES, f"unsupported state dtype {states.dtype}"
+        lead = tuple(states.shape[:-1])
+        rows = states.to(self.device).reshape(-1, states.shape[-1]).contiguous()
+        n = rows.shape[0]
+        spec, o1, o2 = self._make_obs(obs, 1, rows=n)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_featurize(self._h, rows.data_ptr(), self._ROW_DTYPES[rows.dtype], n, C.byref(spec), self._stream()))
+            if self.check_errors:
+                self.poll_errors()
+        o1 = o1.reshape(*lead, *o1.shape[1:])
+        if o2 is not None:
+            return o1, o2.reshape(*lead, *o2.shape[1:])
+        return o1
+
     def poll_errors(self):
         bits = C.c_uint32(0)
         rc = self.lib.susnet_poll_errors(self._h, C.byref(bits), self._stream())
@@ -535,6 +560,8 @@ class BatchedFourRoomEnv:
             raise AssertionError("Invalid action(s): some action >= action_space.n")  # base.py:360-362
         if rc == L.E_ACTION_INDEX:
             raise IndexError("list index out of range")  # base.py:379-382
+        if rc == L.E_ROW:
+            raise IndexError(self.lib.susnet_last_error().decode())  # the reference's planes would index out of bounds
         L.check(rc)
 
     def set_state(self, *, agent_positions=None, alive_agents=None, imposter_mask=None, job_positions=None,

@@ -1,11 +1,12 @@
 """Host-side mirror of the reference's sequence featurizers (src/features/model_ready.py) over the
 observations the HIP kernels write.
 
-The reference's ``fit(state_sequence[B, T, S])`` un-flattens every state in Python and loops over the batch;
-here the tensors come straight from the fused observation writers (``env.observe`` / the ``obs=`` argument of
-step / rollout), so ``fit`` takes no state argument: it observes the env's CURRENT state (T = 1).  What is
-kept is the OUTPUT contract of ``generate_featurized_states()``: one ``(spatial, non_spatial)`` pair per agent
-with the reference shapes and channel / column orders.
+The reference's ``fit(state_sequence[B, T, S])`` un-flattens every state in Python and loops over the batch
+(model_ready.py:41-57).  Here ``fit(state_sequence)`` hands the ``[B, T, S]`` tensor of flattened states (a
+window, a replay batch: any of uint8 / int32 / int64 / float32 / float64, on any device) to the HIP featurize
+kernel (``env.featurize`` -> ``susnet_featurize``); ``fit()`` with no argument observes the env's CURRENT state
+(T = 1) through the same writers.  The OUTPUT contract of ``generate_featurized_states()`` is the reference's:
+one ``(spatial, non_spatial)`` pair per agent with the reference shapes and channel / column orders.
 
 * ``FlatFeaturizer``        model_ready.py:309-370   -> ``(zeros[B, T, 1], feats[B, T, F])`` per agent
 * ``GlobalFeaturizer``      model_ready.py:219-306   -> ``(spatial[B, T, A+2, N, N], [alive, job_status, onehot(agent)])``
@@ -32,7 +33,11 @@ class FlatFeaturizer:
         return 1, torch.tensor([o1.shape[-1]], dtype=torch.int)
 
     def fit(self, state_sequence=None) -> None:
-        self.featurized_state = self.env.observe(self.config).unsqueeze(1)  # [B, T=1, F]
+        if state_sequence is None:
+            self.featurized_state = self.env.observe(self.config).unsqueeze(1)  # [B, T=1, F]
+        else:
+            assert state_sequence.dim() == 3, "state_sequence is [B, T, S] (model_ready.py:44)"
+            self.featurized_state = self.env.featurize(state_sequence, self.config)  # [B, T, F]
 
     def generate_featurized_states(self) -> List[Tuple[torch.Tensor, torch.Tensor]]:
         B, T = self.featurized_state.shape[:2]
@@ -47,8 +52,12 @@ class GlobalFeaturizer:
         self.spatial = self.non_spatial = None
 
     def fit(self, state_sequence=None) -> None:
-        sp, non = self.env.observe(self.config)
-        self.spatial, self.non_spatial = sp.unsqueeze(1), non.unsqueeze(1)  # [B, 1, C, N, N], [B, 1, A(+A)+J]
+        if state_sequence is None:
+            sp, non = self.env.observe(self.config)
+            self.spatial, self.non_spatial = sp.unsqueeze(1), non.unsqueeze(1)  # [B, 1, C, N, N], [B, 1, A(+A)+J]
+        else:
+            assert state_sequence.dim() == 3, "state_sequence is [B, T, S] (model_ready.py:44)"
+            self.spatial, self.non_spatial = self.env.featurize(state_sequence, self.config)  # [B, T, C, N, N], [B, T, .]
 
     def generate_featurized_states(self):
         A = self.env.n_agents

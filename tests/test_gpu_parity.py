@@ -446,6 +446,75 @@ def test_observations_match_reference_feature_fixtures(pkg):
         assert tuple(zs.shape) == (S, 1, 1) and np.array_equal(np_(fs)[:, 0], want)
 
 
+def test_featurize_flattened_state_windows_matches_reference_fixtures(pkg, oracle_mod):
+    """susnet_featurize: the reference's `featurizer.fit(state_sequence[B, T, S])` on flattened-state rows, fed the
+    fixture rows `env.flatten_state` produced (float64, as the trainer's window is) in a [B, T, S] shape and in every
+    accepted dtype; outputs vs the reference featurizers' golden vectors."""
+    import glob
+    import os
+
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "feat_*.npz"))):
+        g = load_golden(path)
+        meta = g["meta"]
+        n = len(g["raw"])
+        T = 4
+        B = n // T
+        env = env_from_meta(pkg, meta, 8, rng="philox")  # the handle only supplies the configuration
+        env.reset()
+        rows64 = torch.from_numpy(g["raw"][:B * T]).reshape(B, T, -1)  # host float64, like train.py:318
+        comps = [c for c in meta["flat"] if c != "scent"]
+        want = np.concatenate([g["flat_" + c] for c in comps], axis=1)[:B * T].reshape(B, T, -1)
+        for dt in (torch.float64, torch.float32, torch.uint8, torch.int32, torch.int64):
+            got = np_(env.featurize(rows64.to(dt), pkg.ObsConfig("flat", comps)))
+            assert got.shape == want.shape and got.view(np.uint32).tolist() == want.view(np.uint32).tolist(), (g["name"], dt)
+        ff = pkg.FlatFeaturizer(env, comps)
+        ff.fit(rows64)
+        zs, fs = ff.generate_featurized_states()[-1]
+        assert tuple(zs.shape) == (B, T, 1) and np.array_equal(np_(fs), want)
+        if "planes_spatial" in g:
+            sp, non = env.featurize(rows64.cuda(), pkg.ObsConfig("planes"))
+            np.testing.assert_array_equal(np_(sp), g["planes_spatial"][:B * T].reshape(B, T, *g["planes_spatial"].shape[1:]))
+            np.testing.assert_array_equal(np_(non), g["planes_non_spatial"][:B * T].reshape(B, T, -1))
+            pf = pkg.PerspectiveFeaturizer(env)
+            pf.fit(rows64)
+            for i, (psp, pns) in enumerate(pf.generate_featurized_states()):
+                np.testing.assert_array_equal(np_(psp).reshape(B * T, *psp.shape[2:]), g["persp_spatial"][:B * T, i])
+                np.testing.assert_array_equal(np_(pns).reshape(B * T, -1), g["persp_non_spatial"][:B * T, i])
+        # ragged tail (not a multiple of the 64-row wave) and a bad row
+        tail = torch.from_numpy(g["raw"][:70]).reshape(1, 70, -1)
+        got = np_(env.featurize(tail, pkg.ObsConfig("flat", comps)))
+        assert np.array_equal(got[0], np.concatenate([g["flat_" + c] for c in comps], axis=1)[:70])
+        bad = tail.clone()
+        bad[0, 5, 0] = 99.0  # x far outside the grid
+        with pytest.raises(IndexError):
+            env.featurize(bad, pkg.ObsConfig("flat", comps))
+        env.check_errors = False
+        got = np_(env.featurize(bad, pkg.ObsConfig("flat", comps)))
+        assert not got[0, 5].any() and np.array_equal(got[0, 6], want.reshape(B * T, -1)[6])
+        with pytest.raises(IndexError):
+            env.poll_errors()
+
+
+def test_featurize_matches_oracle_on_tagging_rows(pkg, oracle_mod):
+    """Rows with the tagging fields (used, tag_counts, timer_left): raw rows written by the fused rollout of a
+    tagging game go back through susnet_featurize and must give the fused planes observation of the same states."""
+    name, B, T = "tagging_1v4_j5", 300, 40
+    env, ob = make_pair(pkg, oracle_mod, name, B, 11, auto_reset=True, check_errors=True)
+    env.reset()
+    traj = env.rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    rows = traj["obs"]  # [T, B, S] uint8
+    env2, _ = make_pair(pkg, oracle_mod, name, B, 11, auto_reset=True, check_errors=True)
+    env2.reset()
+    traj2 = env2.rollout(T, obs=pkg.ObsConfig("planes"))
+    sp, non = env.featurize(rows, pkg.ObsConfig("planes"))
+    assert torch.equal(sp, traj2["obs"]) and torch.equal(non, traj2["obs_non_spatial"])
+    flat = env.featurize(rows, pkg.ObsConfig("flat", ["onehot_pos", "alive_crew", "dist_to_imp"]))
+    env3, _ = make_pair(pkg, oracle_mod, name, B, 11, auto_reset=True, check_errors=True)
+    env3.reset()
+    traj3 = env3.rollout(T, obs=pkg.ObsConfig("flat", ["onehot_pos", "alive_crew", "dist_to_imp"]))
+    assert torch.equal(flat, traj3["obs"])
+
+
 # ------------------------------------------------------------------------------------------------
 # error behaviour (reference: AssertionError base.py:357-362, IndexError base.py:379-382)
 # ------------------------------------------------------------------------------------------------
