@@ -10,7 +10,7 @@ from .env import (  # noqa: F401
 )
 from . import _lib, build_hip, dist, features, policy, replay  # noqa: F401
 from .replay import Batch, DeviceReplayBuffer  # noqa: F401
-from .policy import MLP, PolicyRollout, RandomEquiprobable  # noqa: F401
+from .policy import MLP, PolicyRollout, RandomEquiprobable, SpatialDQN, WindowedPolicyRollout  # noqa: F401
 from .features import FlatFeaturizer, GlobalFeaturizer, PerspectiveFeaturizer  # noqa: F401
 
 # reference names (src/environment/__init__.py:1-3)

@@ -11,6 +11,15 @@ fused flat observation -> model -> argmax -> `step`, greedy as in the reference'
   seeded random initialisation of the same architecture (layer dims of notebooks/experiment_1v1.ipynb cell 1).
 * ``RandomEquiprobable`` mirrors dqn.py:111-138; in the loop a random crew is sampled by the environment's own
   `sample_actions` kernel (uniform over the role-valid indices, base.py:326-330).
+* ``SpatialDQN`` mirrors dqn.py:205-314 (CNN over the plane features of every window step -> concat with the
+  non-spatial features -> RNN over the window -> PReLU MLP head on the last hidden state), again with the reference's
+  module names and its layer-list quirks, so reference checkpoints load; ``tests/golden/model_spatialdqn.npz`` pins it
+  against the reference module's own forward pass.
+* ``WindowedPolicyRollout`` is the batched form of the reference's acting loop with a state window
+  (train.py:316-389, visualize.py:502-585): a ``[B, T, S]`` window of flattened states lives on the device, every
+  tick it goes through ``susnet_featurize`` (Perspective / Global / Flat featurizer), each agent's view feeds the
+  imposter or the crew network by the env's role mask, argmax (optionally epsilon-greedy, train.py:355-381), step,
+  window roll (np.roll, train.py:388-389) or refill with the fresh first state where an episode ended.
 """
 from __future__ import annotations
 
@@ -71,6 +80,77 @@ class RandomEquiprobable(nn.Module):  # dqn.py:111-138
         return out
 
 
+def calculate_cnn_output_dim(input_size, kernel_size, strides, paddings, dilations):  # src/utils.py:5-11
+    size = input_size
+    for stride, padding, dilation in zip(strides, paddings, dilations):
+        size = (size + 2 * padding - dilation * (kernel_size[0] - 1) - 1) // stride + 1
+    return size
+
+
+class _CNN(nn.Module):  # dqn.py:141-181; attribute name `model` = the checkpoint key prefix "cnn.model."
+    def __init__(self, n_channels, strides, paddings, kernel_size, dilations):
+        super().__init__()
+        # the reference repeats the LAST entry of every list once more and zips them: with len(n_channels) ==
+        # len(strides) + 1 that appends one extra same-width convolution (dqn.py:155-159)
+        chans = list(n_channels) + [n_channels[-1]]
+        strides, paddings, dilations = (list(v) + [v[-1]] for v in (strides, paddings, dilations))
+        layers: List[nn.Module] = []
+        for idx, (c_in, stride, padding, dilation) in enumerate(zip(chans[:-1], strides, paddings, dilations)):
+            layers += [nn.Conv2d(c_in, chans[idx + 1], kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation),
+                       nn.ReLU()]
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _RNN(nn.Module):  # dqn.py:184-202
+    def __init__(self, input_dim, n_layers, hidden_dim, dropout):
+        super().__init__()
+        self.model = nn.RNN(input_size=input_dim, hidden_size=hidden_dim, num_layers=n_layers, dropout=dropout, batch_first=True)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class SpatialDQN(nn.Module):
+    def __init__(self, input_image_size, non_spatial_input_size, n_channels, strides, paddings, kernel_size, dilations,
+                 rnn_layers, rnn_hidden_dim, rnn_dropout, mlp_hidden_layer_dims, n_actions):
+        super().__init__()
+        self.config = dict(input_image_size=input_image_size, non_spatial_input_size=non_spatial_input_size,
+                           n_channels=list(n_channels), strides=list(strides), paddings=list(paddings), dilations=list(dilations),
+                           kernel_size=kernel_size, rnn_layers=rnn_layers, rnn_hidden_dim=rnn_hidden_dim, rnn_dropout=rnn_dropout,
+                           mlp_hidden_layer_dims=list(mlp_hidden_layer_dims), n_actions=n_actions)
+        self.cnn_ouput_dim = calculate_cnn_output_dim(input_image_size, kernel_size, strides, paddings, dilations)  # (sic)
+        self.cnn = _CNN(n_channels, strides, paddings, kernel_size, dilations)
+        self.rnn_in_dim = self.cnn_ouput_dim ** 2 * n_channels[-1] + non_spatial_input_size
+        self.rnn = _RNN(self.rnn_in_dim, rnn_layers, rnn_hidden_dim, rnn_dropout)
+        self.n_actions = n_actions
+        self.mlp_dims = [rnn_hidden_dim] + list(mlp_hidden_layer_dims) + [n_actions]
+        self.prediction_head = make_mlp(self.mlp_dims)
+
+    def forward(self, spatial_x, non_spatial_x):  # dqn.py:275-293
+        batch, steps, C, H, W = spatial_x.shape
+        feats = self.cnn(spatial_x.reshape(batch * steps, C, H, W)).reshape(batch, steps, -1)
+        out, _ = self.rnn(torch.cat((feats, non_spatial_x), dim=2))
+        return self.prediction_head(out[:, -1, :])
+
+    def dump_to_checkpoint(self, filepath):  # dqn.py:295-298
+        torch.save({"state_dict": self.state_dict(), "config": self.config}, filepath)
+
+    @staticmethod
+    def load_from_checkpoint(filepath, map_location=None):  # dqn.py:300-306
+        checkpoint = torch.load(filepath, map_location=map_location)
+        model = SpatialDQN(**checkpoint["config"])
+        model.load_state_dict(checkpoint["state_dict"])
+        return model
+
+    def create_copy(self):
+        new = SpatialDQN(**self.config)
+        new.load_state_dict(self.state_dict())
+        return new
+
+
 def reference_imposter_mlp(env, components: Sequence[str], seed: int = 0) -> MLP:
     """`[F, 256, 128, 64, 16, n_imposter_actions]` (notebooks/experiment_1v1.ipynb cell 1), seeded init."""
     spec, o1, _ = env._make_obs(ObsConfig("flat", list(components)), 1)
@@ -124,4 +204,81 @@ class PolicyRollout:
                 out["rewards"].append(rew.clone())
                 out["done"].append(done.clone())
                 out["truncated"].append(trunc.clone())
+        return {k: torch.stack(v) for k, v in out.items()} if record else {}
+
+
+class WindowedPolicyRollout:
+    """Acting loop over a device-resident window of the last ``sequence_length`` flattened states per env.
+
+    ``env`` must fuse the raw uint8 observation into step/reset (``obs=ObsConfig('raw', dtype=torch.uint8)``) and
+    auto-reset.  ``featurizer`` is one of ``features.PerspectiveFeaturizer / GlobalFeaturizer / FlatFeaturizer`` built on
+    the same env.  Per tick (train.py:345-383): ``featurizer.fit(window)``; agent *i* of env *b* acts by the imposter
+    network if it is an imposter there, else by the crew network, on ITS view; dead agents get index 0 when
+    ``mask_dead`` (train.py) and act like everybody else otherwise (visualize.py:547-560); with ``epsilon`` > 0 a
+    uniformly random role-valid index replaces the greedy one with that probability (the env's sample_actions kernel
+    supplies it).
+    """
+
+    def __init__(self, env, featurizer, imposter_model: nn.Module, crew_model: nn.Module, sequence_length: int = 2,
+                 epsilon: float = 0.0, mask_dead: bool = True, seed: int = 0):
+        assert env.obs_config.mode == "raw" and env.obs_config.dtype == torch.uint8 and env.auto_reset, (
+            "construct the env with obs=ObsConfig('raw', dtype=torch.uint8), auto_reset=True")
+        self.env, self.featurizer = env, featurizer
+        self.imposter_model, self.crew_model = imposter_model, crew_model
+        self.T, self.epsilon, self.mask_dead = int(sequence_length), float(epsilon), mask_dead
+        self._gen = torch.Generator(device=env.device)
+        self._gen.manual_seed(seed)
+        self.window = None
+        self._actions = torch.zeros(env.batch, env.n_agents, dtype=torch.int64, device=env.device)
+
+    def reset(self):
+        self.env.reset()
+        self.window = self.env.obs.unsqueeze(1).repeat(1, self.T, 1)  # train.py:318-322: the first state T times
+        return self.window
+
+    @torch.no_grad()
+    def act(self) -> torch.Tensor:
+        env = self.env
+        if self.window is None:
+            self.reset()
+        if not env.export_state:
+            env.refresh_roles()
+        self.featurizer.fit(self.window)
+        imp_mask = env.imposter_mask  # [B, A]
+        for i, (spatial, non_spatial) in enumerate(self.featurizer.generate_featurized_states()):
+            q_imp = self.imposter_model(spatial, non_spatial).argmax(dim=1)
+            q_crew = self.crew_model(spatial, non_spatial).argmax(dim=1)
+            self._actions[:, i] = torch.where(imp_mask[:, i], q_imp, q_crew)
+        if self.epsilon > 0.0:
+            explore = torch.rand(self._actions.shape, device=env.device, generator=self._gen) <= self.epsilon  # train.py:359,371
+            self._actions.copy_(torch.where(explore, env.sample_actions().to(torch.int64), self._actions))
+        if self.mask_dead:
+            self._actions.mul_(env.alive_agents.to(torch.int64) if env.export_state else self._alive_from_window())
+        return self._actions
+
+    def _alive_from_window(self) -> torch.Tensor:
+        A = self.env.n_agents
+        return self.window[:, -1, 2 * A:3 * A].to(torch.int64)  # flatten_state: alive flags follow the A (x, y) pairs
+
+    @torch.no_grad()
+    def step(self):
+        """One tick: act, env.step, window update.  Returns (actions, rewards, done, truncated)."""
+        env = self.env
+        a = self.act()
+        _, rew, done, trunc, _ = env.step(a)
+        ended = (done | trunc).view(-1, 1, 1)
+        nxt = torch.roll(self.window, shifts=-1, dims=1)  # train.py:388-389
+        nxt[:, -1] = env.obs
+        # an ended env was auto-reset inside the step: its window restarts from the fresh first state (train.py:452-457)
+        self.window = torch.where(ended, env.obs.unsqueeze(1).expand(-1, self.T, -1), nxt)
+        return a, rew, done, trunc
+
+    @torch.no_grad()
+    def run(self, n_steps: int, record: bool = False) -> Dict[str, torch.Tensor]:
+        out: Dict[str, List[torch.Tensor]] = {"actions": [], "rewards": [], "done": [], "truncated": []}
+        for _ in range(n_steps):
+            a, rew, done, trunc = self.step()
+            if record:
+                for k, v in zip(out, (a, rew, done, trunc)):
+                    out[k].append(v.clone())
         return {k: torch.stack(v) for k, v in out.items()} if record else {}

@@ -625,6 +625,58 @@ def test_policy_rollout_matches_oracle_on_recorded_actions(pkg, oracle_mod):
         ob.reset(mask=(odone | otrunc).astype(bool))
 
 
+def test_windowed_spatialdqn_policy_rollout(pkg, oracle_mod):
+    """SpatialDQN (CNN + RNN over a T = 3 window of flattened states) acting for every agent through the Perspective
+    featurizer, epsilon-greedy: the window follows np.roll / refill-on-reset (train.py:318-322, 388-389, 452-457) with
+    the oracle supplying the expected raw rows, the greedy indices are recomputed from the window, and the env's
+    rewards / dones for the recorded actions equal the oracle's."""
+    B, steps, seed, T = 384, 70, 13, 3
+    name = "base_1v2_j4_14"
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=True,
+                        obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    A, J, N = env.n_agents, env.n_jobs, env.n_rows
+    torch.manual_seed(5)
+    mk = lambda n_act: pkg.SpatialDQN(input_image_size=N, non_spatial_input_size=A + J, n_channels=[A + 2, 6, 8], strides=[1, 1],
+                                      paddings=[1, 1], kernel_size=[3, 3], dilations=[1, 1], rnn_layers=1, rnn_hidden_dim=16,
+                                      rnn_dropout=0.0, mlp_hidden_layer_dims=[12], n_actions=n_act).to(env.device).eval()
+    imp_net, crew_net = mk(env.n_imposter_actions), mk(env.n_crew_actions)
+    feat = pkg.PerspectiveFeaturizer(env)
+    runner = pkg.WindowedPolicyRollout(env, feat, imp_net, crew_net, sequence_length=T, epsilon=0.25, mask_dead=True, seed=1)
+    win = runner.reset()
+    ob.reset()
+    first = ob.obs_raw_u8()
+    want_win = np.repeat(first[:, None, :], T, axis=1)
+    np.testing.assert_array_equal(np_(win), want_win)
+    explored = 0
+    for s in range(steps):
+        # greedy indices recomputed from the window the runner holds
+        feat.fit(runner.window)
+        imp = env.imposter_mask.clone()  # (a live view: refreshed in place by the next step)
+        greedy = torch.stack([torch.where(imp[:, i], imp_net(sp, ns).argmax(1), crew_net(sp, ns).argmax(1))
+                              for i, (sp, ns) in enumerate(feat.generate_featurized_states())], dim=1)
+        alive = torch.from_numpy(ob.export()["alive"].astype(np.int64)).to(env.device)
+        a, rew, done, trunc = runner.step()
+        a = a.clone()
+        assert bool(((a == 0) | (alive == 1)).all()), "dead agents get index 0 (train.py:353-357)"
+        limit = torch.where(imp, env.n_imposter_actions, env.n_crew_actions)
+        assert bool((a < limit).all()), "role-valid indices"
+        same = (a == greedy * alive)
+        explored += int((~same).sum())
+        assert float(same.float().mean()) > 0.6, "mostly greedy at epsilon 0.25"
+        orew, odone, otrunc, rc = ob.step(np_(a).astype(np.int64))
+        assert rc == 0
+        assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"rewards step {s}"
+        np.testing.assert_array_equal(np_(done), odone.astype(bool))
+        ended = (odone | otrunc).astype(bool)
+        ob.reset(mask=ended)
+        nxt = ob.obs_raw_u8()
+        want_win = np.roll(want_win, -1, axis=1)
+        want_win[:, -1] = nxt
+        want_win[ended] = nxt[ended][:, None, :]
+        np.testing.assert_array_equal(np_(runner.window), want_win, err_msg=f"window step {s}")
+    assert explored > 0
+
+
 def test_device_replay_populate(pkg):
     """Batched ReplayBuffer.populate (src/replay_memory.py:96-143): window roll, ring layout, episode boundaries."""
     B, T = 256, 3

@@ -1,6 +1,7 @@
 """CPU-only tests of the Python host side (no kernels): grids, names, sharding arithmetic."""
 import importlib
 import json
+import os
 
 import numpy as np
 import pytest
@@ -108,3 +109,39 @@ def test_replay_ring_equals_sequential_reference_adds(pkg):
         assert torch.equal(buf.states, ref["states"]) and torch.equal(buf.actions, ref["actions"])
     b = buf.sample(11)
     assert b.states.shape == (11, T, S) and b.dones.shape == (11, 1) and b.imposters.dtype == torch.int16
+
+
+# ------------------------------------------------------------------------------------------------
+# Q-network mirrors vs the reference modules' own parameters / forward pass (tests/golden/model_*.npz)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["spatialdqn", "mlp"])
+def test_q_network_mirrors_load_reference_parameters_and_reproduce_forward(name):
+    import importlib
+    import json
+
+    import torch
+
+    policy = importlib.import_module("sus-net_amd.policy")
+    z = np.load(os.path.join(GOLDEN_DIR, f"model_{name}.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    cls = policy.SpatialDQN if name.startswith("spatialdqn") else policy.MLP
+    model = cls(**meta["config"])
+    sd = {k: torch.from_numpy(z["param::" + k]) for k in meta["keys"]}
+    assert list(model.state_dict().keys()) == meta["keys"], "state_dict keys differ from the reference module's"
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    with torch.no_grad():
+        out = model(torch.from_numpy(z["input0"]), torch.from_numpy(z["input1"]))
+    np.testing.assert_allclose(out.numpy(), z["output"], rtol=1e-5, atol=1e-6)
+    # checkpoint round trip in the reference's {"state_dict", "config"} format (dqn.py:92-103, 295-306)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.pt")
+        model.dump_to_checkpoint(path)
+        again = cls.load_from_checkpoint(path)
+        with torch.no_grad():
+            out2 = again(torch.from_numpy(z["input0"]), torch.from_numpy(z["input1"]))
+        assert torch.equal(out, out2)
+        copy = model.create_copy()
+        assert all(torch.equal(a, b) for a, b in zip(copy.state_dict().values(), model.state_dict().values()))
