@@ -70,8 +70,16 @@ class DeviceReplayBuffer:
     @torch.no_grad()
     def populate(self, env, num_steps: int) -> int:
         """Random-policy rollout into the ring: ``num_steps`` lockstep ticks of ``env`` (B transitions each).
-        ``env`` must be built with ``obs=ObsConfig('raw')`` (float32) and ``auto_reset=True``."""
-        assert env.obs_config.mode == "raw" and env.auto_reset, "populate needs the fused raw observation and auto-reset"
+        ``env`` must fuse the float32 raw observation (``obs=ObsConfig('raw')``).
+
+        * ``auto_reset=False`` env: EXACT reference semantics -- the stored ``next_states`` window ends with the true
+          post-step state (also for terminal and truncated transitions, replay_memory.py:120-136); ended envs are then
+          reset with a masked ``env.reset`` (one more small launch per tick).
+        * ``auto_reset=True`` env: one launch per tick; for a transition that ENDS an episode the last row of
+          ``next_states`` is already the new episode's first state.  ``done`` is stored, so a learner never bootstraps
+          across a terminal boundary; a truncated transition (done = False) does bootstrap from the fresh state.
+        """
+        assert env.obs_config.mode == "raw", "populate needs the fused raw observation"
         assert env.obs.shape[-1] == self.state_size
         T = self.trajectory_size
         env.reset()
@@ -86,9 +94,9 @@ class DeviceReplayBuffer:
             ended = done | trunc
             nxt = torch.roll(window, shifts=-1, dims=1)  # replay_memory.py:122-127 / train.py:388-389
             nxt[:, -1] = env.obs
-            # NOTE: with same-step auto-reset env.obs of an ended env is already the NEW episode's first state;
-            # the stored transition keeps `done` so a learner never bootstraps across the boundary.
             self.add_batch(window, a, rew, nxt, done, imposters)
+            if not env.auto_reset:
+                env.reset(mask=ended)  # fuses the fresh states of the ended envs into env.obs
             window = torch.where(ended.view(-1, 1, 1), env.obs.unsqueeze(1).expand(-1, T, -1), nxt)
             added += env.batch
         return added

@@ -699,3 +699,28 @@ def test_device_replay_populate(pkg):
     fresh = st[1:][rew_done]
     assert bool((fresh == fresh[:, :1]).all())
     assert buf.actions[:n].max() < 7 and buf.imposters[:n].min() >= 0 and buf.imposters[:n].max() < env.n_agents
+
+
+def test_device_replay_populate_exact_terminal_states(pkg):
+    """With auto_reset=False populate() keeps the reference's terminal semantics (replay_memory.py:120-136): the
+    next_states window of a transition that ended its episode ends with the TRUE terminal state (here: 1v1, `done`
+    means the crew member was killed, so its alive flag is 0 there), and the following transition of that env starts
+    from T copies of a fresh state (everybody alive)."""
+    B, T, steps = 512, 2, 120
+    env = pkg.BatchedImposterTrainingGround(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
+                                            time_step_reward=0, include_walls=False, batch=B, auto_reset=False, seed=4,
+                                            obs=pkg.ObsConfig("raw"), max_time_steps=40)
+    S = env.flattened_state_size
+    buf = pkg.DeviceReplayBuffer(B * steps, S, T, 2, 1, device=env.device)
+    assert buf.populate(env, steps) == B * steps
+    st = buf.states.view(steps, B, T, S)
+    nx = buf.next_states.view(steps, B, T, S)
+    dn = buf.dones.view(steps, B)
+    assert int(dn.sum()) > 50
+    crew_alive_after = nx[:, :, -1, 5]  # flatten_state: x0 y0 x1 y1 alive0 alive1
+    assert bool((crew_alive_after[dn] == 0).all()) and bool((crew_alive_after[~dn] == 1).all())
+    after_end = st[1:][dn[:-1]]
+    assert bool((after_end[:, :, 4:6] == 1).all()) and bool((after_end == after_end[:, :1]).all())
+    # truncation (t reaches max_time_steps - 1 = 39): episode restarts although done is False
+    fresh = (st[1:] == st[1:, :, :1]).flatten(2).all(-1) & (st[1:] != nx[:-1]).flatten(2).any(-1)
+    assert int((fresh & ~dn[:-1]).sum()) > 0
