@@ -173,6 +173,8 @@ CONFIGS = {
     "base_1v2_j4_14": dict(cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14),
     "base_2v6_j4_14": dict(cls="base", kw=dict(n_imposters=2, n_crew=6, n_jobs=4), n=14),
     "base_3v9_j8_16": dict(cls="base", kw=dict(n_imposters=3, n_crew=9, n_jobs=8, max_time_steps=60), n=16),
+    # the ABI's maximum sizes: 16 agents, 16 jobs, 16x16 grid (generic LDS-table kernels)
+    "base_7v9_j16_16": dict(cls="base", kw=dict(n_imposters=7, n_crew=9, n_jobs=16, max_time_steps=40), n=16),
     "tagging_1v4_j5": dict(cls="tagging", kw=dict(n_imposters=1, n_crew=4, n_jobs=5, tag_reset_interval=6), n=9),
     "tagging_2v6_j4_14": dict(cls="tagging", kw=dict(n_imposters=2, n_crew=6, n_jobs=4, tag_reset_interval=11, time_step_reward=-1), n=14),
     "itg_1v5_j3": dict(cls="itg", kw=dict(n_crew=5, n_jobs=3, kill_reward=-3, sabotage_reward=1, end_of_game_reward=7,
@@ -259,6 +261,33 @@ def test_hip_matches_oracle_without_reset_after_done(pkg, oracle_mod, name):
         np.testing.assert_array_equal(np_(done), odone.astype(bool))
         np.testing.assert_array_equal(np_(env._metrics), ob.export()["metrics"])
     compare_full_state(env, ob, f"{name} coasting")
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65])
+def test_tiny_and_ragged_batches(pkg, oracle_mod, B):
+    """One env, one lane short of a wave, exactly one wave, one lane over: step API and fused rollout."""
+    for name in ("itg_1v1_nowalls", "base_2v6_j4_14", "base_7v9_j16_16"):
+        env, ob = make_pair(pkg, oracle_mod, name, B, 3, auto_reset=True, check_errors=True)
+        env.reset()
+        ob.reset()
+        for s in range(12):
+            a = env.sample_actions().clone()
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(a), oa)
+            _, rew, done, trunc, _ = env.step(a)
+            orew, odone, otrunc, _ = ob.step(oa)
+            assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64))
+            ob.reset(mask=(odone | otrunc).astype(bool))
+        traj = env.rollout(9, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+        for s in range(9):
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(traj["actions"])[s], oa)
+            orew, odone, otrunc, _ = ob.step(oa)
+            assert np.array_equal(np_(traj["rewards"])[s].astype(np.float64).view(np.uint64), orew.view(np.uint64))
+            ob.reset(mask=(odone | otrunc).astype(bool))
+            np.testing.assert_array_equal(np_(traj["obs"])[s], ob.obs_raw_u8())
+        env._export(full=True)
+        compare_full_state(env, ob, f"{name} B={B}")
 
 
 def test_sharding_is_invisible(pkg, oracle_mod):
