@@ -345,8 +345,16 @@ void so_sample_actions(so_env *e, int32_t *actions) {
     if (e->rng.kind == SO_RNG_PHILOX) {
         /* production protocol: agent i's action at step `tick` is word tick * W + i of the action stream; sampling
          * does not advance anything (the step does), so repeated calls before a step return the same actions */
-        /* a tick owns W words: 2 when A <= 2, A rounded up to a multiple of 4 otherwise (static word assignment) */
-        const uint64_t W = e->A <= 2 ? 2u : (uint64_t)((e->A + 3) & ~3);
+        /* a tick owns W words.  A > 2: W = A rounded up to a multiple of 4, agent i reads word i.  A <= 2: W = 1, one
+         * word serves both agents by nested multiply-shift (p = w * n0: agent 0 = hi32(p), agent 1 = hi32(lo32(p) * n1)) */
+        if (e->A <= 2) {
+            uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick, SO_ACTION_STREAM_TAG);
+            uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, 0);
+            actions[0] = (int)(p >> 32);
+            if (e->A == 2) actions[1] = (int)(((uint64_t)(uint32_t)p * (uint64_t)(uint32_t)so_n_actions(e, 1)) >> 32);
+            return;
+        }
+        const uint64_t W = (uint64_t)((e->A + 3) & ~3);
         for (int i = 0; i < e->A; i++) {
             uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * W + (uint64_t)i, SO_ACTION_STREAM_TAG);
             actions[i] = (int)(((uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i)) >> 32);

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #define STAMP(k) do {} while (0)
 #endif
     if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
-    // one tick; PAR = compile-time parity of the absolute tick (0 even, 1 odd) or -1 = decided at run time
+    // one tick; PAR = compile-time position of the absolute tick in its 4-tick action-stream block, or -1 = run time
     auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
 #ifdef SUSNET_STAMPS
@@ -303,19 +303,23 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         }
         STAMP(6);
     };
+    // 1v1 trajectory kernels: a Philox block of the action stream serves four consecutive ticks (one word each), so
+    // the loop runs block-wise with the word selection static and one generation per block; ticks before the first
+    // block boundary of a launch and after its last full block run through the run-time flavour
+    constexpr bool kQuads = kTraj && !S::kGeneric && S::kA == 2;
     int tick = 0;
-    // 1v1 trajectory kernels: a Philox block of the action stream serves an (even, odd) pair of ticks, so the loop
-    // runs pair-wise with the word selection static and one generation per pair; a launch that starts on an odd
-    // tick or ends on an even one runs that tick through the run-time flavour
-    constexpr bool kPairs = kTraj && !S::kGeneric && S::kA == 2;
-    if (kPairs) {
-        if ((a.tick_base & 1ull) && tick < a.n_ticks) tick_body(tick++, std::integral_constant<int, -1>{});
-        for (; tick + 1 < a.n_ticks; tick += 2) {
+    while (tick < a.n_ticks) {
+        if (kQuads && ((a.tick_base + (uint64_t)tick) & 3ull) == 0ull && tick + 3 < a.n_ticks) {
             tick_body(tick, std::integral_constant<int, 0>{});
             tick_body(tick + 1, std::integral_constant<int, 1>{});
+            tick_body(tick + 2, std::integral_constant<int, 2>{});
+            tick_body(tick + 3, std::integral_constant<int, 3>{});
+            tick += 4;
+        } else {
+            tick_body(tick, std::integral_constant<int, -1>{});
+            tick++;
         }
     }
-    for (; tick < a.n_ticks; tick++) tick_body(tick, std::integral_constant<int, -1>{});
 #ifdef SUSNET_STAMPS
     if (blockIdx.x == 100 && tid == 0)
         for (int k = 0; k < 8; k++) {

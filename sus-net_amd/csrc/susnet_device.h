@@ -175,7 +175,7 @@ struct PhiloxRng {
 
 // ACTION stream of the production protocol (counter word 1 tagged with bit 31), indexed by `tick` = steps taken so
 // far: the same for every env stepped in lockstep, so blocks are generated under wave-uniform control flow
-// (see sample_actions_env for the word assignment; 1v1: one Philox block per TWO ticks).
+// (see sample_actions_env for the word assignment; 1v1: one Philox block per FOUR ticks).
 constexpr uint32_t kActionStreamTag = 0x80000000u;
 struct ActionStream {
     uint64_t blk;          // block currently held (uniform across the wave)
@@ -507,24 +507,23 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
     const int A = S::A(c);
     for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
 }
-// A tick owns W words of the action stream, W = 2 for A <= 2 and A rounded up to a multiple of 4 otherwise, so that
-// which word an agent reads is static: with A <= 2 one Philox block serves TWO ticks (even tick: words 0,1 and the
-// generation, under a scalar branch on the tick's parity; odd tick: words 2,3), otherwise W/4 blocks per tick.
-// `first` = the stream holds no block yet (a launch that starts on an odd tick must generate too).
-// PAR: the tick's parity when the caller knows it at compile time (-1 = run time).
-template <class S, int PAR = -1, class Store>
+// A tick owns W words of the action stream.  A > 2: W = A rounded up to a multiple of 4 (W/4 blocks per tick, agent i
+// reads word i: static word assignment).  A <= 2 (the 1v1 game): W = 1 -- ONE word serves both agents by nested
+// multiply-shift (p = w * n0: agent 0 takes the high word of p, agent 1 the high word of lo32(p) * n1, i.e. the two
+// mixed-radix digits of w * n0 * n1 / 2^32; joint bias <= n0 * n1 * 2^-32), so one Philox block serves FOUR ticks.
+// Q: the tick's position in its block when the caller knows it at compile time (the fused rollout's 4-tick loop
+// generates at Q == 0), -1 = run time.  `first` = the stream holds no block yet (a launch may start mid-block).
+template <class S, int Q = -1, class Store>
 __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, PhiloxRng &rng, ActionStream &as, uint64_t tick,
                                                    bool first = true) {
     const int A = S::A(c);
     if (A <= 2) {
-        const bool odd = PAR >= 0 ? (PAR == 1) : ((tick & 1ull) != 0ull);
-        const uint64_t b = tick >> 1;
-        if (PAR == 0 || (PAR < 0 && (!odd || first))) as.gen(rng, b); // PAR == 1: the even tick of the pair generated it
-#pragma unroll
-        for (int i = 0; i < A; i++) {
-            const uint32_t w = odd ? (i == 0 ? as.w2 : as.w3) : (i == 0 ? as.w0 : as.w1);
-            st.set_act(i, __umulhi(w, n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
-        }
+        const uint32_t q = Q >= 0 ? (uint32_t)Q : ((uint32_t)tick & 3u);
+        if (Q == 0 || (Q < 0 && (q == 0u || first))) as.gen(rng, tick >> 2);
+        const uint32_t w = q == 0u ? as.w0 : q == 1u ? as.w1 : q == 2u ? as.w2 : as.w3;
+        const uint64_t p = (uint64_t)w * (uint64_t)n_actions<S>(c, S::imp(c, e.imp) & 1u);
+        st.set_act(0, (uint32_t)(p >> 32));
+        if (A == 2) st.set_act(1, __umulhi((uint32_t)p, n_actions<S>(c, (S::imp(c, e.imp) >> 1) & 1u)));
     } else {
         const uint64_t blocks = (uint64_t)((A + 3) >> 2);
 #pragma unroll

@@ -92,3 +92,32 @@ def test_philox_protocol_draws_are_uniform(oracle_mod):
     ob2.set_philox(2025, 0, 0)
     ob2.reset()
     assert not np.array_equal(ob2.export()["pos"], e["pos"][:4])
+
+
+def test_one_word_serves_both_1v1_agents_jointly_uniform(oracle_mod):
+    """1v1 production protocol: ONE action-stream word per tick gives both agents' actions by nested multiply-shift.
+    The pair (imposter action in 0..5, crew action in 0..4) must be jointly uniform over its 30 cells, and consecutive
+    ticks independent (df = 29: 99.9 % quantile ~ 58; df = 35 for the lag pairs: ~ 66)."""
+    om = oracle_mod
+    B, ticks = 3000, 40
+    cfg = om.make_config("itg", n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
+                         time_step_reward=0, include_walls=False, shuffle_imposter_index=False)
+    ob = om.OracleBatch(cfg, B)
+    ob.set_philox(77, 0, 0)
+    ob.reset()
+    joint = np.zeros((6, 5))
+    lag = np.zeros((6, 6))
+    prev = None
+    for t in range(ticks):
+        a = ob.sample_actions()
+        assert a[:, 0].max() == 5 and a[:, 1].max() == 4 and a.min() == 0
+        np.add.at(joint, (a[:, 0], a[:, 1]), 1)
+        if prev is not None:
+            np.add.at(lag, (prev[:, 0], a[:, 0]), 1)
+        prev = a
+        _, done, trunc, _ = ob.step(a)
+        ob.reset(mask=(done | trunc).astype(bool))
+    assert _chi2(joint.ravel(), B * ticks / 30) < 58
+    assert _chi2(lag.ravel(), B * (ticks - 1) / 36) < 66
+    # sampling twice before a step returns the same actions (the step advances the tick, sampling does not)
+    np.testing.assert_array_equal(ob.sample_actions(), ob.sample_actions())
