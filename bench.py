@@ -27,6 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# kernel arguments in device memory (see sus-net_amd/__init__.py); must be in the environment before HIP initialises
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
