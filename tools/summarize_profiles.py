@@ -35,3 +35,18 @@ for d in sorted(glob.glob(f"{src}/pmc_*")):
     summary[name] = out
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
+
+# bench.py reads `roofline.traffic` from the summary that was committed BEFORE the profiled run; the bench lines kept
+# next to this summary get the traffic of the SAME run (WRITE_SIZE + 2 x FETCH_SIZE, KiB -> bytes)
+try:
+    ksel = lambda grp, ctr: next(v[ctr]["mean_per_launch"] for k, v in summary[grp].items() if k.startswith("void k_rollout") and ", 2>" in k)
+    traffic = (ksel("pmc_WRITE_SIZE", "WRITE_SIZE") + 2.0 * ksel("pmc_FETCH_SIZE", "FETCH_SIZE")) * 1024.0
+    for name in (f"profiles/{tag}_bench_under_rocprofv3.json", f"profiles/{tag}_bench_unprofiled.json"):
+        if os.path.exists(name):
+            line = json.load(open(name))
+            line["roofline"]["traffic"] = traffic
+            line["roofline"]["traffic_source"] = f"{tag}_pmc_summary.json"
+            json.dump(line, open(name, "w"))
+    print("traffic per launch:", traffic)
+except (KeyError, StopIteration) as exc:
+    print("traffic not refreshed:", exc)
