@@ -520,7 +520,9 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
     if (A <= 2) {
         const uint32_t q = Q >= 0 ? (uint32_t)Q : ((uint32_t)tick & 3u);
         if (Q == 0 || (Q < 0 && (q == 0u || first))) as.gen(rng, tick >> 2);
-        const uint32_t w = q == 0u ? as.w0 : q == 1u ? as.w1 : q == 2u ? as.w2 : as.w3;
+        // (two-level select: a 4-way chain on a run-time q is turned into an indexed stack array, i.e. scratch memory)
+        const uint32_t lo = (q & 1u) ? as.w1 : as.w0, hi = (q & 1u) ? as.w3 : as.w2;
+        const uint32_t w = (q & 2u) ? hi : lo;
         const uint64_t p = (uint64_t)w * (uint64_t)n_actions<S>(c, S::imp(c, e.imp) & 1u);
         st.set_act(0, (uint32_t)(p >> 32));
         if (A == 2) st.set_act(1, __umulhi((uint32_t)p, n_actions<S>(c, (S::imp(c, e.imp) >> 1) & 1u)));
