@@ -127,3 +127,23 @@ def test_obs_sizes_follow_the_reference_featurizers(pkg):
     spec.components[0] = L.FLAT_COMPONENTS["room_loc"]  # 9x9 only (component.py:8-17)
     assert lib.susnet_obs_size(h, C.byref(spec), C.byref(f1), C.byref(f2)) == L.E_INVALID
     lib.susnet_destroy(h)
+
+
+def test_device_code_has_no_scratch_memory_traffic(pkg, tmp_path):
+    """Per-lane arrays indexed at run time get demoted to scratch (private) memory: slow, and every scratch load
+    carries an `s_waitcnt vmcnt(0)` that also waits for all outstanding trajectory stores.  The hot kernels keep
+    such tables in packed VGPR words or LDS instead; this pins it on the shipped gfx950 code object."""
+    import shutil
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = tmp_path / "libsusnet_hip.so"
+    shutil.copy(pkg._lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert len(objs) == 1, "expected exactly one gfx950 code object in the library"
+    asm = subprocess.run([objdump, "-d", str(objs[0])], check=True, capture_output=True, text=True).stdout
+    assert asm.count("v_mad_u64_u32") > 1000, "disassembly looks empty"
+    scratch = [ln for ln in asm.splitlines() if "scratch_" in ln]
+    assert not scratch, f"{len(scratch)} scratch instructions, e.g. {scratch[:3]}"
