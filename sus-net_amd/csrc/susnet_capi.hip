@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
 // that is instruction-fetch bound): OUT_ANY = whatever pointers are non-null / any observation mode;
 // OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
 // uint8 observation (the populate()-shaped record)
-enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2 };
+enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3 }; // OUT_TRAJ = the same record without an observation
 template <class S, int OUT>
 __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     }
     // trajectory mode with register-direct observation rows has no cooperative (all-lane) work past this point:
     // idle lanes of a ragged last wave leave, and the tick loop runs without per-block exec masking
-    if (OUT == OUT_TRAJ_RAW8 && S::kRawF > 0 && !active) return;
+    if (((OUT == OUT_TRAJ_RAW8 && S::kRawF > 0) || OUT == OUT_TRAJ) && !active) return;
     LifeAcc life;
     life.clear();
     const int64_t AB = (int64_t)A * c.B;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // check) with a fixed per-lane byte offset and the tick's slab offset in a scalar register, so a store costs no
     // vector address arithmetic and a tick advances five scalar offsets.  The host only selects this mode when
     // every output array of the launch is below 2 GiB.
-    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8;
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
     const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     BufDst da = make_buf_dst(a.actions, nt * (uint64_t)AB, (uint32_t)(bb * A));
     BufDst dr = make_buf_dst(a.rewards, nt * (uint64_t)AB * 4u, (uint32_t)(bb * A) * 4u);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         if (active) {
             sample_actions_env<S, PAR>(c, st, e, rng, as, a.tick_base + (uint64_t)tick, tick == 0);
             STAMP(1);
-            if (OUT == OUT_TRAJ_RAW8 || (OUT == OUT_ANY && pa != nullptr)) {
+            if (kTraj || (OUT == OUT_ANY && pa != nullptr)) {
                 if (!S::kGeneric) {
                     uint32_t av[S::kA > 0 ? S::kA : 1];
 #pragma unroll
@@ -253,10 +253,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr};
             bool done, trunc;
 #ifdef SUSNET_STAMPS
-            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
             else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
 #else
-            if (OUT == OUT_TRAJ_RAW8) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc);
+            if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc);
             else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc);
 #endif
             STAMP(3);
@@ -921,6 +921,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     // trajectory mode addresses every output through a buffer descriptor with 32-bit offsets: a launch covers at most
     // as many ticks as keep every output array below 2 GiB; longer requests run as consecutive launches
     const bool traj = all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0;
+    const bool traj_noobs = all_traj && o.mode == SUSNET_OBS_NONE;
     const uint64_t AB = (uint64_t)env->c.A * (uint64_t)env->c.B;
     const uint64_t tick_bytes = std::max<uint64_t>(4u * AB, (uint64_t)o.tick_stride);
     uint64_t limit = (1ull << 31) - 1u;
@@ -929,24 +930,29 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         if (v > 0 && (uint64_t)v < limit) limit = (uint64_t)v;
     }
     const uint64_t fit = limit / tick_bytes;
-    const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE : (traj && fit >= 1) ? OUT_TRAJ_RAW8 : OUT_ANY;
-    const int chunk = out == OUT_TRAJ_RAW8 ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
+    const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
+                    : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8
+                    : (traj_noobs && fit >= 1)              ? OUT_TRAJ
+                                                            : OUT_ANY;
+    const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
 #define LAUNCH_ROLLOUT(SPEC)                                                                                       \
     do {                                                                                                           \
         if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, env->c, env->s, a, o); \
         else if (out == OUT_TRAJ_RAW8)                                                                             \
             hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, env->c, env->s, a, o);            \
+        else if (out == OUT_TRAJ)                                                                                  \
+            hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, env->c, env->s, a, o);                 \
         else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, env->c, env->s, a, o);                 \
     } while (0)
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);
         a.tick_base = env->ticks + (uint64_t)t0;
-        if (t0 > 0) { // only reached in trajectory mode: all five outputs are bound, [T][B][...] slabs
+        if (t0 > 0) { // only reached in the trajectory modes: the four trajectory outputs are bound, [T][B][...] slabs
             a.actions += (uint64_t)chunk * AB;
             a.rewards += (uint64_t)chunk * AB;
             a.done += (uint64_t)chunk * (uint64_t)env->c.B;
             a.trunc += (uint64_t)chunk * (uint64_t)env->c.B;
-            o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (uint64_t)o.tick_stride;
+            if (o.out) o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (uint64_t)o.tick_stride;
         }
         if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
         else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
