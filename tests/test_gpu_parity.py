@@ -244,6 +244,32 @@ def test_hip_matches_oracle_philox_autoreset(pkg, oracle_mod, name):
     assert life[0] == episodes, "lifetime episode count"
 
 
+def test_imported_dead_agents_in_the_compiled_1v1_kernel(pkg, oracle_mod):
+    """The 1v1 kernel takes its rewards from a few table constants selected by {kill landed, crew dead, agent dead}; states a
+    caller assigns (dead imposter, dead crew, both) must behave like the reference's general reward chain (oracle)."""
+    name, B = "itg_1v1_nowalls", 256
+    env, ob = make_pair(pkg, oracle_mod, name, B, 19, auto_reset=False, check_errors=True)
+    env.reset()
+    ob.reset()
+    alive = np.ones((B, 2), dtype=bool)
+    alive[0::4, 0] = False            # dead imposter
+    alive[1::4, 1] = False            # dead crew member (a finished episode)
+    alive[2::4] = False               # both
+    env.set_state(alive_agents=alive)
+    for b in range(B):
+        ob.set_state(b, alive=alive[b].astype(np.uint8))
+    for s in range(25):
+        a = env.sample_actions().clone()
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(np_(a), oa)
+        _, rew, done, trunc, _ = env.step(a)
+        orew, odone, otrunc, _ = ob.step(oa)
+        assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"rewards step {s}"
+        np.testing.assert_array_equal(np_(done), odone.astype(bool))
+        np.testing.assert_array_equal(np_(trunc), otrunc.astype(bool))
+    compare_full_state(env, ob, "after stepping imported states")
+
+
 @pytest.mark.parametrize("name", ["itg_1v1_nowalls", "base_1v2_j4_14", "base_2v6_j4_14"])
 def test_hip_matches_oracle_without_reset_after_done(pkg, oracle_mod, name):
     """Callers may keep stepping a finished episode (the reference allows it): compiled-in kernels included."""
