@@ -526,6 +526,17 @@ def test_featurize_flattened_state_windows_matches_reference_fixtures(pkg, oracl
         ff.fit(rows64)
         zs, fs = ff.generate_featurized_states()[-1]
         assert tuple(zs.shape) == (B, T, 1) and np.array_equal(np_(fs), want)
+        if "scent" in meta["flat"]:  # the real-valued component (torch arithmetic), alone and inside a composite
+            sc = g["flat_scent"][:B * T].reshape(B, T, 4)
+            f2 = pkg.FlatFeaturizer(env, ["scent"])
+            f2.fit(rows64)
+            assert np_(f2.generate_featurized_states()[0][1]).view(np.uint32).tolist() == sc.view(np.uint32).tolist(), g["name"]
+            mix = [comps[0], "scent"] + comps[1:2]
+            f3 = pkg.FlatFeaturizer(env, mix)
+            f3.fit(rows64)
+            want3 = np.concatenate([(sc if c == "scent" else g["flat_" + c][:B * T].reshape(B, T, -1)) for c in mix], axis=2)
+            assert np.array_equal(np_(f3.generate_featurized_states()[0][1]), want3)
+            assert int(f3.featurized_shape[1][0]) == want3.shape[-1]
         if "planes_spatial" in g:
             sp, non = env.featurize(rows64.cuda(), pkg.ObsConfig("planes"))
             np.testing.assert_array_equal(np_(sp), g["planes_spatial"][:B * T].reshape(B, T, *g["planes_spatial"].shape[1:]))
