@@ -1,7 +1,6 @@
 """Time the fused rollout under output ablations (which part of a tick costs what). GPU box only."""
 import importlib
 import sys
-import time
 
 import torch
 
