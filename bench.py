@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--obs", default="raw", choices=["none", "raw", "flat", "planes"])
     ap.add_argument("--ticks", type=int, default=512, help="ticks per fused launch")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--packed", type=int, default=0, help="fused + raw obs: 1 = one packed record per env-step (compiled-in "
+                    "configurations), 0 = separate trajectory tensors (default; faster on cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -218,6 +220,8 @@ def main():
             env.step(a)
         return 2 * n_ticks
 
+    used_packed = [False]
+
     def measure(mode, obs_mode, K, W):
         oc = obs_config(obs_mode) if mode == "fused" else None
         step_obs = obs_config(obs_mode) if mode == "step" else None
@@ -225,7 +229,11 @@ def main():
             step_obs = pkg.ObsConfig("flat", POLICY_COMPONENTS)
         env = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=step_obs)
         env.reset()
-        bufs = env.alloc_rollout(args.ticks, obs=oc) if mode == "fused" else None
+        packed = (mode == "fused" and obs_mode == "raw" and args.packed == 1 and env.record_layout() is not None)
+        if args.packed == 1 and mode == "fused" and obs_mode == "raw":
+            assert packed, "this configuration has no packed record mode"
+        used_packed[0] = packed if mode == "fused" and obs_mode == args.obs else used_packed[0]
+        bufs = env.alloc_rollout(args.ticks, obs=oc, packed=packed) if mode == "fused" else None
         if mode == "policy":
             model = pkg.policy.reference_imposter_mlp(env, POLICY_COMPONENTS, seed=0)
             pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS)
@@ -280,6 +288,8 @@ def main():
         avg_launch_s = (res["device_ms"] / 1e3) / K  # one k_step per tick; the tick also holds 5 GEMMs + glue
     b_alg = algorithmic_bytes_per_step(A, J, N, args.obs)
     b_stored = stored_bytes_per_step(A, J, N, args.obs)
+    if used_packed[0]:
+        b_stored = (b_stored + 3) // 4 * 4  # the packed record is padded to a multiple of 4 bytes
     achieved = steps_per_launch * b_alg / avg_launch_s / 1e9
     traffic, traffic_src = (None, None)
     if args.mode == "fused" and args.config == "cfg2" and B == 65536 and args.ticks == 512 and world == 1:
@@ -290,6 +300,7 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": spec["workload"], "mode": args.mode, "obs": args.obs, "batch_per_gpu": B,
                    "global_batch": B * world, "ticks_per_launch": args.ticks if args.mode == "fused" else 1,
+                   "trajectory_layout": "packed record per env-step" if used_packed[0] else "separate tensors",
                    "rng": "philox4x32-10 in-kernel", "auto_reset": True, "parallelism": f"dp{world}",
                    "agent_steps_per_s": value * A},
         "roofline": {

@@ -185,7 +185,19 @@ typedef struct susnet_rollout_io {
     uint8_t *done;      /* out [T][B] */
     uint8_t *truncated; /* out [T][B] */
     const susnet_obs_spec *obs; /* out pointer is [T][B][obs_size]; observation AFTER each tick */
+    void *record;       /* alternative to ALL of the above (which must then be NULL): one packed record per env-step,
+                         * [T][B][record_bytes] -- the same fields, laid out for one wide store per lane
+                         * (susnet_record_layout); only for the compiled-in configurations */
 } susnet_rollout_io;
+
+/* Packed trajectory record of susnet_rollout_io.record: rewards f32[A] at byte 0, then actions u8[A], done u8,
+ * truncated u8, raw observation u8[obs_raw_size] (flatten_state order), zero-padded to a multiple of 4 bytes.
+ * *record_bytes = 0 when the handle's configuration has no packed mode (not one of the compiled-in games). */
+typedef struct susnet_record_layout_t {
+    int32_t record_bytes;
+    int32_t off_rewards, off_actions, off_done, off_truncated, off_obs;
+} susnet_record_layout_t;
+int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out);
 
 /* Reference-layout views of the state (export / import). NULL pointers are skipped. */
 typedef struct susnet_state_view {

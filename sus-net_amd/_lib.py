@@ -31,7 +31,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
     "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_step",
-    "susnet_rollout", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
+    "susnet_rollout", "susnet_record_layout", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_poll_errors",
 ]
 
@@ -76,8 +76,13 @@ class StepIO(C.Structure):
 class RolloutIO(C.Structure):
     _fields_ = [
         ("n_ticks", C.c_int32), ("actions", C.c_void_p), ("rewards", C.c_void_p), ("done", C.c_void_p),
-        ("truncated", C.c_void_p), ("obs", C.POINTER(ObsSpec)),
+        ("truncated", C.c_void_p), ("obs", C.POINTER(ObsSpec)), ("record", C.c_void_p),
     ]
+
+
+class RecordLayout(C.Structure):
+    _fields_ = [("record_bytes", C.c_int32), ("off_rewards", C.c_int32), ("off_actions", C.c_int32), ("off_done", C.c_int32),
+                ("off_truncated", C.c_int32), ("off_obs", C.c_int32)]
 
 
 class StateView(C.Structure):
@@ -144,6 +149,7 @@ def lib():
     L.susnet_sample_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.susnet_step.argtypes = [C.c_void_p, P(StepIO), C.c_void_p]
     L.susnet_rollout.argtypes = [C.c_void_p, P(RolloutIO), C.c_void_p]
+    L.susnet_record_layout.argtypes = [C.c_void_p, P(RecordLayout)]
     L.susnet_observe.argtypes = [C.c_void_p, P(ObsSpec), C.c_void_p]
     L.susnet_obs_size.argtypes = [C.c_void_p, P(ObsSpec), P(C.c_int32), P(C.c_int32)]
     L.susnet_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, P(ObsSpec), C.c_void_p]

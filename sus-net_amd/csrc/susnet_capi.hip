@@ -33,6 +33,8 @@ struct RolloutArgs {
     uint8_t *actions; // [T][B][A]
     float *rewards;   // [T][B][A]
     uint8_t *done, *trunc; // [T][B]
+    uint8_t *record;       // packed mode: [T][B][record_bytes]
+    int32_t record_bytes;
 };
 
 template <class RNG>
@@ -159,7 +161,15 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
 // that is instruction-fetch bound): OUT_ANY = whatever pointers are non-null / any observation mode;
 // OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
 // uint8 observation (the populate()-shaped record)
-enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3 }; // OUT_TRAJ = the same record without an observation
+enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4 };
+// OUT_TRAJ = OUT_TRAJ_RAW8 without an observation; OUT_RECORD = the OUT_TRAJ_RAW8 fields packed into ONE record per
+// env-step (rewards f32[A] | actions u8[A] | done | truncated | raw obs u8[F], padded to a dword): a lane stores its
+// record with one or two wide stores through a single buffer descriptor instead of six stores through five
+template <class S>
+struct RecordLayout {
+    static constexpr int kBytesTail = (S::kA > 0 ? S::kA : 0) + 2 + (S::kRawF > 0 ? S::kRawF : 0);
+    static constexpr int kDwords = (S::kA > 0 ? S::kA : 0) + (kBytesTail + 3) / 4;
+};
 template <class S, int OUT>
 __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     }
     // trajectory mode with register-direct observation rows has no cooperative (all-lane) work past this point:
     // idle lanes of a ragged last wave leave, and the tick loop runs without per-block exec masking
-    if (((OUT == OUT_TRAJ_RAW8 && S::kRawF > 0) || OUT == OUT_TRAJ) && !active) return;
+    if (((OUT == OUT_TRAJ_RAW8 && S::kRawF > 0) || OUT == OUT_TRAJ || OUT == OUT_RECORD) && !active) return;
     LifeAcc life;
     life.clear();
     const int64_t AB = (int64_t)A * c.B;
@@ -217,6 +227,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
     BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * (kRawF > 0 ? kRawF : 0)));
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    constexpr bool kRec = OUT == OUT_RECORD; // (host: compiled-in configurations with a static raw row only)
+    constexpr int kRecDwords = RecordLayout<S>::kDwords > 0 ? RecordLayout<S>::kDwords : 1;
+    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
+    const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
     if (kTraj) { pa = nullptr; pr = nullptr; pd = nullptr; pt = nullptr; }
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -236,9 +250,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         if (active) {
             sample_actions_env<S, PAR>(c, st, e, rng, as, a.tick_base + (uint64_t)tick, tick == 0);
             STAMP(1);
-            if (kTraj || (OUT == OUT_ANY && pa != nullptr)) {
+            uint32_t av[S::kA > 0 ? S::kA : 1];
+            float rr[S::kA > 0 ? S::kA : 1];
+            if (kRec) {
+#pragma unroll
+                for (int i = 0; i < (S::kA > 0 ? S::kA : 0); i++) av[i] = st.act(i);
+            } else if (kTraj || (OUT == OUT_ANY && pa != nullptr)) {
                 if (!S::kGeneric) {
-                    uint32_t av[S::kA > 0 ? S::kA : 1];
 #pragma unroll
                     for (int i = 0; i < A; i++) av[i] = st.act(i);
                     if (kTraj) store_row_u8<(S::kA > 0 ? S::kA : 1)>(da, av);
@@ -250,13 +268,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 }
             }
             STAMP(2);
-            RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr};
+            RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr, rr};
             bool done, trunc;
 #ifdef SUSNET_STAMPS
-            if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
             else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
 #else
-            if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc);
+            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc);
+            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc);
             else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc);
 #endif
             STAMP(3);
@@ -277,6 +297,27 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 else zero_metrics(e);
             }
             STAMP(5);
+            if (kRec) { // one packed record per env-step: rewards | actions | done | truncated | raw observation
+                constexpr int kA = S::kA > 0 ? S::kA : 0, kF = kRawF > 0 ? kRawF : 0, kNB = kA + 2 + kF;
+                uint8_t row[kF + 4];
+                fill_raw<S>(c, st, e, row);
+                uint32_t by[(kNB + 3) / 4 * 4];
+#pragma unroll
+                for (int k = 0; k < kA; k++) by[k] = av[k] & 0xffu;
+                by[kA] = done ? 1u : 0u;
+                by[kA + 1] = trunc ? 1u : 0u;
+#pragma unroll
+                for (int f = 0; f < kF; f++) by[kA + 2 + f] = row[f];
+#pragma unroll
+                for (int k = kNB; k < (kNB + 3) / 4 * 4; k++) by[k] = 0u;
+                uint32_t w[kRecDwords];
+#pragma unroll
+                for (int i = 0; i < kA; i++) w[i] = __float_as_uint(rr[i]);
+#pragma unroll
+                for (int k = 0; k < (kNB + 3) / 4; k++)
+                    w[kA + k] = by[4 * k] | (by[4 * k + 1] << 8) | (by[4 * k + 2] << 16) | (by[4 * k + 3] << 24);
+                store_dwords<kRecDwords>(drec, w);
+            }
             if (OUT == OUT_ANY) {
                 pa = pa ? pa + AB : pa;
                 pr = pr ? pr + AB : pr;
@@ -301,12 +342,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         if (kTraj) { // wave-uniform: next tick's slabs
             da.so += slab_a; dr.so += 4u * slab_a; dd.so += slab_d; dt.so += slab_d; dobs.so += slab_o;
         }
+        if (kRec) drec.so += slab_rec;
         STAMP(6);
     };
     // 1v1 trajectory kernels: a Philox block of the action stream serves four consecutive ticks (one word each), so
     // the loop runs block-wise with the word selection static and one generation per block; ticks before the first
     // block boundary of a launch and after its last full block run through the run-time flavour
-    constexpr bool kQuads = kTraj && !S::kGeneric && S::kA == 2;
+    constexpr bool kQuads = (kTraj || kRec) && !S::kGeneric && S::kA == 2;
     int tick = 0;
     while (tick < a.n_ticks) {
         if (kQuads && ((a.tick_base + (uint64_t)tick) & 3ull) == 0ull && tick + 3 < a.n_ticks) {
@@ -898,6 +940,27 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     return SUSNET_OK;
 }
 
+// the packed record exists for configurations whose whole raw row is known at compile time
+template <class SPEC>
+static void launch_record(dim3 g, dim3 blk, size_t sh, hipStream_t st, susnet_env *env, const RolloutArgs &a, const ObsArgs &o) {
+    if constexpr (!SPEC::kGeneric && SPEC::kRawF > 0) hipLaunchKernelGGL((k_rollout<SPEC, OUT_RECORD>), g, blk, sh, st, env->c, env->s, a, o);
+}
+
+extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out) {
+    if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c, env->float_exact) : 0;
+    if (spec != 2 && spec != 3 && spec != 4 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode
+    const int A = env->c.A, F = env->layout.obs_raw_size;
+    out->off_rewards = 0;
+    out->off_actions = 4 * A;
+    out->off_done = 5 * A;
+    out->off_truncated = 5 * A + 1;
+    out->off_obs = 5 * A + 2;
+    out->record_bytes = 4 * A + (A + 2 + F + 3) / 4 * 4;
+    return SUSNET_OK;
+}
+
 extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream) {
     if (int rc = check_bound(env)) return rc;
     if (!io || io->n_ticks < 1) return fail(SUSNET_E_INVALID, "n_ticks must be >= 1");
@@ -909,9 +972,20 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     a.rewards = io->rewards;
     a.done = io->done;
     a.trunc = io->truncated;
+    a.record = static_cast<uint8_t *>(io->record);
+    a.record_bytes = 0;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
     const int spec = pick_spec(env->c, env->float_exact);
+    if (a.record) {
+        if (a.actions || a.rewards || a.done || a.trunc || o.mode != SUSNET_OBS_NONE)
+            return fail(SUSNET_E_INVALID, "susnet_rollout: record is an alternative to the separate outputs, not an addition");
+        susnet_record_layout_t lay;
+        susnet_record_layout(env, &lay);
+        if (lay.record_bytes == 0) return fail(SUSNET_E_INVALID, "susnet_rollout: this configuration has no packed record mode");
+        if ((uintptr_t)a.record % 16) return fail(SUSNET_E_INVALID, "record buffer must be 16-byte aligned");
+        a.record_bytes = lay.record_bytes;
+    }
     size_t sh = lds_bytes(env, o, true, spec == 0);
     CHECK_LDS(sh);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -923,18 +997,20 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool traj = all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0;
     const bool traj_noobs = all_traj && o.mode == SUSNET_OBS_NONE;
     const uint64_t AB = (uint64_t)env->c.A * (uint64_t)env->c.B;
-    const uint64_t tick_bytes = std::max<uint64_t>(4u * AB, (uint64_t)o.tick_stride);
+    const uint64_t tick_bytes = a.record ? (uint64_t)env->c.B * (uint64_t)a.record_bytes : std::max<uint64_t>(4u * AB, (uint64_t)o.tick_stride);
     uint64_t limit = (1ull << 31) - 1u;
     if (const char *ev = getenv("SUSNET_TRAJ_MAX_BYTES")) { // tests: exercise the chunking on small batches
         const long long v = atoll(ev);
         if (v > 0 && (uint64_t)v < limit) limit = (uint64_t)v;
     }
     const uint64_t fit = limit / tick_bytes;
-    const int out = (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
+    if (a.record && fit < 1) return fail(SUSNET_E_INVALID, "susnet_rollout: one tick of records exceeds 2 GiB");
+    const int out = a.record                                ? OUT_RECORD
+                    : (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
                     : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
                                                             : OUT_ANY;
-    const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
+    const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
 #define LAUNCH_ROLLOUT(SPEC)                                                                                       \
     do {                                                                                                           \
         if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, env->c, env->s, a, o); \
@@ -942,12 +1018,15 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, env->c, env->s, a, o);            \
         else if (out == OUT_TRAJ)                                                                                  \
             hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, env->c, env->s, a, o);                 \
+        else if (out == OUT_RECORD)                                                                                \
+            launch_record<SPEC>(g, blk, sh, st, env, a, o);                                                        \
         else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, env->c, env->s, a, o);                 \
     } while (0)
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);
         a.tick_base = env->ticks + (uint64_t)t0;
-        if (t0 > 0) { // only reached in the trajectory modes: the four trajectory outputs are bound, [T][B][...] slabs
+        if (t0 > 0 && a.record) a.record += (uint64_t)chunk * tick_bytes;
+        if (t0 > 0 && !a.record) { // only reached in the trajectory modes: the four trajectory outputs are bound, [T][B][...] slabs
             a.actions += (uint64_t)chunk * AB;
             a.rewards += (uint64_t)chunk * AB;
             a.done += (uint64_t)chunk * (uint64_t)env->c.B;

@@ -588,7 +588,18 @@ struct RewardSink {
 
 struct RewardRowSink : RewardSink { // rollout flavour
     BufDst buf;      // SINK_ON == 2: this env's float32 row of the current tick
+    float *regs;     // SINK_ON == 3: the caller's register array (packed-record mode stores them itself)
 };
+
+// N consecutive dwords at a 4-byte aligned row destination: 16-byte stores, then an 8- and a 4-byte tail
+template <int N, class D>
+__device__ __forceinline__ void store_dwords(const D &d, const uint32_t *w) {
+    constexpr int k4 = N / 4 * 4;
+#pragma unroll
+    for (int k = 0; k < k4; k += 4) d.st128(4u * k, w[k], w[k + 1], w[k + 2], w[k + 3]);
+    if (N - k4 >= 2) d.st64(4u * k4, w[k4], w[k4 + 1]);
+    if ((N - k4) & 1) d.st32(4u * (N - 1), w[N - 1]);
+}
 
 // N consecutive 4-byte values / N consecutive bytes at a row destination that is naturally aligned to N's largest
 // power-of-two divisor times the element size: widest stores
@@ -631,7 +642,7 @@ __device__ __forceinline__ void clear_info_if_fresh(Env &e) {
 
 // returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
 // SINK_ON: the reward sink is bound to this env's float32 row of the rollout trajectory [T][B][A]: 1 = by pointer
-// (sink.ptr), 2 = by buffer descriptor (sink.buf); 0 = generic strided put
+// (sink.ptr), 2 = by buffer descriptor (sink.buf), 3 = left in the caller's registers (sink.regs); 0 = generic strided put
 // LAZY_INFO = false: the caller guarantees the env is not FRESH (the fused rollout clears once before its loop and
 // zeroes the counters itself at an episode end that is not the launch's last tick)
 template <class S, bool VALIDATE, int SINK_ON, bool LAZY_INFO = true, class RNG, class Store, class Sink>
@@ -840,7 +851,10 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             if (SINK_ON) rr[i] = r;
             else sink.put(i, b, r);
         }
-        if constexpr (SINK_ON == 2) store_row_f32<(S::kA > 0 ? S::kA : 1)>(sink.buf, rr);
+        if constexpr (SINK_ON == 3) {
+#pragma unroll
+            for (int i = 0; i < A; i++) sink.regs[i] = rr[i];
+        } else if constexpr (SINK_ON == 2) store_row_f32<(S::kA > 0 ? S::kA : 1)>(sink.buf, rr);
         else if (SINK_ON == 1) store_row_f32<(S::kA > 0 ? S::kA : 1)>(PtrDst{reinterpret_cast<uint8_t *>(sink.ptr)}, rr);
     } else {
 #pragma unroll
@@ -854,7 +868,8 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
             if (i < S::n_imp(c)) r *= (RT)-1; // indices [:n_imposters], NOT the imposter mask (base.py:559)
             if (!((e.alive >> i) & 1u)) r = rw<RT>(c, RW_DEAD); // base.py:562
             if (!tagging && r == (RT)0) r = rw<RT>(c, RW_TSR);  // base.py:389-390 (tagging.py has no fill)
-            if constexpr (SINK_ON == 2) sink.buf.st32(4u * (uint32_t)i, __float_as_uint((float)r));
+            if constexpr (SINK_ON == 3) sink.regs[i] = (float)r;
+            else if constexpr (SINK_ON == 2) sink.buf.st32(4u * (uint32_t)i, __float_as_uint((float)r));
             else if (SINK_ON == 1) reinterpret_cast<float *>(sink.ptr)[i] = (float)r;
             else sink.put(i, b, r);
         }

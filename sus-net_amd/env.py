@@ -477,11 +477,37 @@ class BatchedFourRoomEnv:
         obs = self.obs if self._obs_spec is not None else state
         return obs, rew, done | trunc, info
 
-    def alloc_rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None):
+    def record_layout(self):
+        """Field offsets of the packed per-env-step trajectory record, or None when the configuration has none."""
+        lay = L.RecordLayout()
+        L.check(self.lib.susnet_record_layout(self._h, C.byref(lay)))
+        return lay if lay.record_bytes else None
+
+    def alloc_rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None,
+                      packed: bool = False):
         """Allocate (once) the trajectory buffers a fused rollout of up to ``n_ticks`` ticks writes:
-        actions u8 [T, B, A], rewards f32 [T, B, A], done / truncated bool [T, B], obs [T, B, ...]."""
+        actions u8 [T, B, A], rewards f32 [T, B, A], done / truncated bool [T, B], obs [T, B, ...].
+
+        ``packed=True`` (compiled-in configurations, full trajectory + raw uint8 observation only): ONE buffer
+        ``record`` u8 [T, B, record_bytes] holding the same fields per env-step, which a lane writes with one or two wide
+        stores; the returned ``actions / rewards / done / truncated / obs`` are strided VIEWS into it (same shapes and
+        dtypes as the separate tensors)."""
         T, A, B = int(n_ticks), self.n_agents, self.batch
         out = {"n_ticks": T}
+        if packed:
+            lay = self.record_layout()
+            assert lay is not None, "this configuration has no packed record mode"
+            assert set(store) == {"actions", "rewards", "done", "truncated"} and obs is not None and obs.mode == "raw" \
+                and obs.dtype == torch.uint8, "packed=True carries the full trajectory and the raw uint8 observation"
+            rec = torch.empty(T, B, lay.record_bytes, dtype=torch.uint8, device=self.device)
+            F = self.flattened_state_size
+            out["record"] = rec
+            out["rewards"] = rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].view(torch.float32)
+            out["actions"] = rec[:, :, lay.off_actions:lay.off_actions + A]
+            out["done"] = rec[:, :, lay.off_done].view(torch.bool)
+            out["truncated"] = rec[:, :, lay.off_truncated].view(torch.bool)
+            out["obs"] = rec[:, :, lay.off_obs:lay.off_obs + F]
+            return out
         if "actions" in store:
             out["actions"] = torch.empty(T, B, A, dtype=torch.uint8, device=self.device)
         if "rewards" in store:
@@ -505,21 +531,25 @@ class BatchedFourRoomEnv:
         io = bufs.get("_io")  # the argument block is built once per buffer set (this call is on the launch-bound path)
         if io is None:
             io = L.RolloutIO()
-            for name in ("actions", "rewards", "done", "truncated"):
-                if name in bufs:
-                    setattr(io, name, bufs[name].data_ptr())
-            if "_obs_spec" in bufs:
-                io.obs = C.pointer(bufs["_obs_spec"])
+            if "record" in bufs:
+                io.record = bufs["record"].data_ptr()
+            else:
+                for name in ("actions", "rewards", "done", "truncated"):
+                    if name in bufs:
+                        setattr(io, name, bufs[name].data_ptr())
+                if "_obs_spec" in bufs:
+                    io.obs = C.pointer(bufs["_obs_spec"])
             bufs["_io"] = io
         io.n_ticks = int(n_ticks)
         with self._on_device():
             L.check(self.lib.susnet_rollout(self._h, C.byref(io), self._stream()))
 
-    def rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None):
+    def rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None,
+                packed: bool = False):
         """Fused random rollout (ReplayBuffer.populate's loop, reference src/replay_memory.py:96-143, without
         the buffer): ``n_ticks`` x {sample_actions; step; reset on done|truncated} in ONE launch.
         Returns a dict of trajectory tensors with a leading tick dimension."""
-        bufs = self.alloc_rollout(n_ticks, store, obs)
+        bufs = self.alloc_rollout(n_ticks, store, obs, packed=packed)
         self.rollout_into(n_ticks, bufs)
         return bufs
 

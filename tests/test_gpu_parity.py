@@ -378,6 +378,42 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
     compare_full_state(env, ob, f"{name} after the short launches")
 
 
+@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "itg_1v1_walls", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5"])
+def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch):
+    """The packed per-env-step record (one wide store per lane) holds the same fields as the separate trajectory tensors;
+    its strided views are checked against the oracle loop, across launches of odd lengths and a chunked launch."""
+    B, seed = 1000 if name != "base_2v6_j4_14" else 40000, 9
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+    if env.record_layout() is None:
+        pytest.skip("configuration not compiled in")
+    lay = env.record_layout()
+    assert lay.record_bytes % 4 == 0 and lay.off_obs + env.flattened_state_size <= lay.record_bytes
+    env.reset()
+    ob.reset(threads=0)
+    obs_cfg = pkg.ObsConfig("raw", dtype=torch.uint8)
+    for n in (24, 5, 1, 2, 3):
+        if n == 5:
+            monkeypatch.setenv("SUSNET_TRAJ_MAX_BYTES", str(2 * B * lay.record_bytes + 8))  # 2 ticks per launch
+        else:
+            monkeypatch.delenv("SUSNET_TRAJ_MAX_BYTES", raising=False)
+        traj = env.rollout(n, obs=obs_cfg, packed=True)
+        torch.cuda.synchronize()
+        assert traj["rewards"].shape == (n, B, env.n_agents) and traj["obs"].shape == (n, B, env.flattened_state_size)
+        for s in range(n):
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(traj["actions"])[s], oa, err_msg=f"{name} launch of {n}, tick {s}")
+            orew, odone, otrunc, _ = ob.step(oa, threads=0)
+            assert np.array_equal(np_(traj["rewards"])[s].astype(np.float64).view(np.uint64), orew.view(np.uint64))
+            np.testing.assert_array_equal(np_(traj["done"])[s], odone.astype(bool))
+            np.testing.assert_array_equal(np_(traj["truncated"])[s], otrunc.astype(bool))
+            ob.reset(mask=(odone | otrunc).astype(bool))
+            np.testing.assert_array_equal(np_(traj["obs"])[s], ob.obs_raw_u8())
+        pad = np_(traj["record"])[:, :, lay.off_obs + env.flattened_state_size:]
+        assert not pad.any(), "padding bytes are zero"
+    env._export(full=True)
+    compare_full_state(env, ob, f"{name} after packed rollouts")
+
+
 def test_long_trajectory_launches_are_chunked(pkg, oracle_mod, monkeypatch):
     """Trajectory-mode kernels address outputs with 32-bit offsets; requests whose arrays would pass 2 GiB run as
     consecutive launches.  Forced here with a small limit: 7 ticks per launch, i.e. odd starts and a ragged tail."""
