@@ -17,6 +17,8 @@
  *   susnet_rollout         ReplayBuffer.populate's loop    src/replay_memory.py:96-143 (minus the buffer)
  *   susnet_observe         flatten_state base.py:234; FlatFeaturizer / GlobalFeaturizer
  *                          src/features/model_ready.py:219-370, src/features/component.py:83-482
+ *   susnet_featurize       SequenceStateFeaturizer.fit(state_sequence[B,T,S]) on windows / replay batches
+ *                          src/features/model_ready.py:41-57, 254-289, 338-354 (callers: src/train.py:345-347)
  *   susnet_seed / _tick    np.random.seed(seed)            src/environment/base.py:126,267 (production stream)
  *   susnet_bind_tape       (numpy's own MT19937 words: decisions equal the reference's for that seed)
  *   susnet_export_state    the state tuple step()/reset() return (base.py:317-324, 397-402)
