@@ -20,6 +20,7 @@
  *   susnet_featurize       SequenceStateFeaturizer.fit(state_sequence[B,T,S]) on windows / replay batches
  *                          src/features/model_ready.py:41-57, 254-289, 338-354 (callers: src/train.py:345-347)
  *   susnet_seed / _tick    np.random.seed(seed)            src/environment/base.py:126,267 (production stream)
+ *   susnet_device_tick     (new) step counter in device memory: captured launches replay as a hipGraph
  *   susnet_bind_tape       (numpy's own MT19937 words: decisions equal the reference's for that seed)
  *   susnet_export_state    the state tuple step()/reset() return (base.py:317-324, 397-402)
  *   susnet_import_state    direct assignment to env.agent_positions etc. (what callers/tests do)
@@ -262,6 +263,14 @@ int susnet_import_state(susnet_env *env, const susnet_state_view *view, void *st
 /* Sum the per-env lifetime accumulators into out[SUSNET_N_LIFETIME] (device int64 buffer): the vector
  * the multi-GPU host all-gathers.  One small launch. */
 int susnet_reduce_lifetime(susnet_env *env, int64_t *out_device, void *stream);
+
+/* Graph-replayable launches.  By default the step counter that indexes the production action stream (susnet_tick)
+ * travels as a kernel argument, so a captured launch would replay with a stale value.  enable = 1 moves the counter
+ * into device memory (inside the bound state blob): sample_actions / rollout read it there, step / rollout advance it
+ * there, and a hipGraph captured from these calls (e.g. {susnet_sample_actions; susnet_step}) can be replayed any
+ * number of times.  enable = 0 reads it back.  susnet_tick() keeps working in both modes (it synchronises in device
+ * mode).  Synchronises `stream`. */
+int susnet_device_tick(susnet_env *env, int32_t enable, void *stream);
 
 /* Synchronises `stream`, reads and clears the device error word. Returns 0 or the most severe
  * SUSNET_E_ACTION_* / SUSNET_E_TAPE / SUSNET_E_ROW code; *bits_out receives the raw bits. */

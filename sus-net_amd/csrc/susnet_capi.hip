@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out,
     RNG rng = make_rng<RNG>(c, s, b);
     ActionStream as;
     as.init();
+    if (c.dev_tick) tick = *s.dev_tick;
     sample_actions_env<S>(c, st, e, rng, as, tick);
     for (int i = 0; i < c.A; i++) store_action(out, dtype, (int64_t)i * sa + b * sb, st.act(i));
     finish_rng(s, b, rng);
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         store_env<S>(c, s, st, b, e, jobs_changed);
         finish_rng(s, b, rng);
     }
+    if (c.dev_tick && blockIdx.x == 0 && tid == 0) *s.dev_tick += 1ull; // (nothing in this kernel reads the counter)
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
@@ -201,6 +203,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // trajectory mode with register-direct observation rows has no cooperative (all-lane) work past this point:
     // idle lanes of a ragged last wave leave, and the tick loop runs without per-block exec masking
     if (((OUT == OUT_TRAJ_RAW8 && S::kRawF > 0) || OUT == OUT_TRAJ || OUT == OUT_RECORD) && !active) return;
+    // the step counter of the action stream: a kernel argument, or (graph-replayable launches) a device word that the
+    // last workgroup to finish advances; either way wave-uniform, in scalar registers
+    uint64_t tick_base = a.tick_base;
+    if (c.dev_tick) {
+        const uint64_t t = *s.dev_tick;
+        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
+    }
     LifeAcc life;
     life.clear();
     const int64_t AB = (int64_t)A * c.B;
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #endif
         STAMP(0);
         if (active) {
-            sample_actions_env<S, PAR>(c, st, e, rng, as, a.tick_base + (uint64_t)tick, tick == 0);
+            sample_actions_env<S, PAR>(c, st, e, rng, as, tick_base + (uint64_t)tick, tick == 0);
             STAMP(1);
             uint32_t av[S::kA > 0 ? S::kA : 1];
             float rr[S::kA > 0 ? S::kA : 1];
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     constexpr bool kQuads = (kTraj || kRec) && !S::kGeneric && S::kA == 2;
     int tick = 0;
     while (tick < a.n_ticks) {
-        if (kQuads && ((a.tick_base + (uint64_t)tick) & 3ull) == 0ull && tick + 3 < a.n_ticks) {
+        if (kQuads && ((tick_base + (uint64_t)tick) & 3ull) == 0ull && tick + 3 < a.n_ticks) {
             tick_body(tick, std::integral_constant<int, 0>{});
             tick_body(tick + 1, std::integral_constant<int, 1>{});
             tick_body(tick + 2, std::integral_constant<int, 2>{});
@@ -373,6 +382,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         store_env<S>(c, s, st, b, e, true);
         s.rng[b] = rng.cur;
         life.flush(c, s, b);
+    }
+    if (c.dev_tick && tid == 0) { // every workgroup read the counter at its start: the last one to finish advances it
+        __threadfence();
+        if (atomicAdd(s.blk_done, 1u) == gridDim.x - 1u) {
+            *s.dev_tick = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+            *s.blk_done = 0u;
+            __threadfence();
+        }
     }
 }
 
@@ -579,6 +596,7 @@ struct susnet_env {
     bool bound = false;
     bool float_exact = false;
     uint64_t ticks = 0; // steps taken (index of the production action stream)
+    uint64_t ticks_staging = 0;
     susnet_layout layout;
     uint64_t off_err, off_agent, off_job, off_jobdone, off_t, off_timer, off_flags, off_rng, off_msteps, off_mfix, off_msab,
         off_mkv, off_life;
@@ -745,6 +763,8 @@ extern "C" int susnet_bind_state(susnet_env *env, void *blob, uint64_t bytes, vo
     const uint32_t *tape = s.tape;
     int64_t tape_len = s.tape_len;
     s.err = reinterpret_cast<uint32_t *>(p + env->off_err);
+    s.dev_tick = reinterpret_cast<uint64_t *>(p + env->off_err + 192); // (the diagnostic build's stamps end at byte 144)
+    s.blk_done = reinterpret_cast<uint32_t *>(p + env->off_err + 200);
     s.agent = reinterpret_cast<uint16_t *>(p + env->off_agent);
     s.job = reinterpret_cast<uint8_t *>(p + env->off_job);
     s.jobdone = reinterpret_cast<uint16_t *>(p + env->off_jobdone);
@@ -784,6 +804,7 @@ extern "C" int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void
     env->c.seed = seed;
     env->cfg.seed = seed;
     env->ticks = 0;
+    if (env->c.dev_tick) HIP_TRY(hipMemsetAsync(env->s.dev_tick, 0, sizeof(uint64_t), static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(k_fill_cursor, dim3((unsigned)((env->c.B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), env->c,
                        env->s, cursor);
     HIP_TRY(hipGetLastError());
@@ -1099,8 +1120,32 @@ extern "C" int susnet_import_state(susnet_env *env, const susnet_state_view *vie
 
 extern "C" int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get) {
     if (!env) return fail(SUSNET_E_INVALID, "null handle");
-    if (set) env->ticks = *set;
-    if (get) *get = env->ticks;
+    if (set) {
+        env->ticks = *set;
+        if (env->c.dev_tick) HIP_TRY(hipMemcpy(env->s.dev_tick, &env->ticks, sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    if (get) {
+        if (env->c.dev_tick) HIP_TRY(hipMemcpy(&env->ticks, env->s.dev_tick, sizeof(uint64_t), hipMemcpyDeviceToHost)); // (synchronises)
+        *get = env->ticks;
+    }
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_device_tick(susnet_env *env, int32_t enable, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (enable && !env->c.dev_tick) {
+        // the copy reads env->ticks_staging when it executes: a member, alive as long as the handle
+        env->ticks_staging = env->ticks;
+        HIP_TRY(hipMemcpyAsync(env->s.dev_tick, &env->ticks_staging, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(env->s.blk_done, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipStreamSynchronize(st));
+        env->c.dev_tick = 1;
+    } else if (!enable && env->c.dev_tick) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(&env->ticks, env->s.dev_tick, sizeof(uint64_t), hipMemcpyDeviceToHost));
+        env->c.dev_tick = 0;
+    }
     return SUSNET_OK;
 }
 

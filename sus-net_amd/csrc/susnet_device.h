@@ -56,7 +56,8 @@ struct Consts {
     int32_t A, J, N, n_imp, n_crew, variant;
     int32_t max_t, order_random, shuffle_imp, tag_interval;
     int32_t n_valid, auto_reset, nr_imp, nr_crew; // nr_* = length of the role part of agent_action_map
-    int32_t epw, pad0;                            // environments per wave in the fused rollout (64, or 32: see DESIGN.md)
+    int32_t epw, dev_tick;                        // environments per wave in the fused rollout; dev_tick: the step counter
+                                                  // is read from / advanced in device memory (graph-replayable launches)
     uint32_t grid_rows[SUSNET_MAX_GRID];          // bit j of row i = grid[i][j]
     uint32_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID / 4]; // np.argwhere(grid) order; bytes x | y << 4
     // move_tab[a][cell] = cell after role-relative action a in {STAY, UP, DOWN, LEFT, RIGHT, other}: the whole of
@@ -77,6 +78,8 @@ template <> __device__ __forceinline__ float rw<float>(const Consts &c, int k) {
 // Device pointers into the caller's state blob (SoA, row stride Bp).
 struct State {
     uint32_t *err;      // [1] device error word
+    uint64_t *dev_tick; // [1] device-resident step counter (used when Consts::dev_tick; same 256-byte block as err)
+    uint32_t *blk_done; // [1] finished-workgroup counter of the running rollout launch
     uint16_t *agent;    // [A][Bp]
     uint8_t *job;       // [J][Bp]  x | y << 4 (constant within an episode)
     uint16_t *jobdone;  // [Bp] bitmask

@@ -649,6 +649,33 @@ class BatchedFourRoomEnv:
         v = C.c_uint64(int(value))
         L.check(self.lib.susnet_tick(self._h, C.byref(v), None))
 
+    def device_tick(self, enable: bool = True) -> None:
+        """Keep the step counter of the action stream in device memory (``susnet_device_tick``): launches then carry no
+        per-call value and a captured hipGraph of them can be replayed.  ``env.tick`` keeps working (it synchronises)."""
+        with self._on_device():
+            L.check(self.lib.susnet_device_tick(self._h, int(bool(enable)), self._stream()))
+
+    def capture_random_step(self, n_ticks: int = 1) -> "torch.cuda.CUDAGraph":
+        """hipGraph of ``n_ticks`` drop-in ticks ``a = env.sample_actions(); env.step(a)`` (two kernel nodes each): the
+        launch-bound inner loop of a random-policy driver, replayable with ``graph.replay()``.  Outputs land in the env's persistent
+        tensors (``sample_actions()`` buffer, ``step()``'s rewards / done / truncated / fused observation).  Needs
+        ``check_errors=False, export_state=False`` (both would synchronise inside the capture)."""
+        assert self.rng_kind == "philox", "graph replay needs the counter-based production stream"
+        assert not self.check_errors and not self.export_state, "construct the env with check_errors=False, export_state=False"
+        self.device_tick(True)
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up on a side stream, as torch's capture rules ask (these two ticks count)
+            for _ in range(2):
+                self.step(self.sample_actions())
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(n_ticks):
+                self.step(self.sample_actions())
+        return graph
+
     def rng_cursor(self) -> torch.Tensor:
         cur = torch.zeros(self.batch, dtype=torch.int64, device=self.device)
         view = L.StateView()

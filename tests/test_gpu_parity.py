@@ -316,6 +316,55 @@ def test_tiny_and_ragged_batches(pkg, oracle_mod, B):
         compare_full_state(env, ob, f"{name} B={B}")
 
 
+def test_graph_replayed_random_steps_match_oracle(pkg, oracle_mod):
+    """hipGraph of {sample_actions; step}: the step counter lives in device memory, so every replay draws the next
+    tick's actions.  Each replay is checked against the oracle; a fused rollout afterwards continues the same streams
+    from the device counter, and turning device mode off hands the count back to the host."""
+    for name in ("itg_1v1_nowalls", "base_1v2_j4_14"):
+        B = 3000
+        env, ob = make_pair(pkg, oracle_mod, name, B, 23, auto_reset=True, check_errors=False, export_state=False)
+        env.reset()
+        ob.reset()
+        graph4 = env.capture_random_step(4)     # warm-up: 2 ticks (capturing itself executes nothing)
+        graph4.replay()                         # 4 ticks in one replay
+        torch.cuda.synchronize()
+        for _ in range(2 + 4):                  # (the oracle follows: 2 warm-up ticks + the replayed 4)
+            oa = ob.sample_actions()
+            _, odone, otrunc, _ = ob.step(oa)
+            ob.reset(mask=(odone | otrunc).astype(bool))
+        graph = env.capture_random_step()       # 2 more warm-up ticks, then a 1-tick graph
+        for _ in range(2):
+            oa = ob.sample_actions()
+            _, odone, otrunc, _ = ob.step(oa)
+            ob.reset(mask=(odone | otrunc).astype(bool))
+        acts_buf = env._actions_view
+        for s in range(40):
+            graph.replay()
+            torch.cuda.synchronize()
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(acts_buf), oa, err_msg=f"{name} replay {s}")
+            orew, odone, otrunc, _ = ob.step(oa)
+            assert np.array_equal(np_(env._rewards_view).astype(np.float64).view(np.uint64), orew.view(np.uint64))
+            np.testing.assert_array_equal(np_(env._done), odone.astype(bool))
+            ob.reset(mask=(odone | otrunc).astype(bool))
+        assert env.tick == 48
+        traj = env.rollout(9, obs=pkg.ObsConfig("raw", dtype=torch.uint8))   # device counter feeds the fused kernel too
+        torch.cuda.synchronize()
+        for s in range(9):
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(traj["actions"])[s], oa, err_msg=f"{name} rollout tick {s} after replays")
+            orew, odone, otrunc, _ = ob.step(oa)
+            ob.reset(mask=(odone | otrunc).astype(bool))
+            np.testing.assert_array_equal(np_(traj["obs"])[s], ob.obs_raw_u8())
+        assert env.tick == 57
+        env.device_tick(False)
+        assert env.tick == 57
+        a = env.sample_actions().clone()
+        np.testing.assert_array_equal(np_(a), ob.sample_actions())
+        env._export(full=True)
+        compare_full_state(env, ob, f"{name} after graph replays")
+
+
 def test_sharding_is_invisible(pkg, oracle_mod):
     """Env b of a shard with env_id_base = k behaves exactly as env k + b of one big batch."""
     name, B, seed = "base_2v6_j4_14", 1024, 5
