@@ -372,6 +372,33 @@ class BatchedFourRoomEnv:
         return ~self.imposter_mask
 
     @property
+    def crew_idxs(self):
+        """[B, n_crew] ascending agent indices of the crew (base.py:283)."""
+        return torch.nonzero(self.crew_mask)[:, 1].reshape(self.batch, self.n_crew)
+
+    @property
+    def agent_rewards(self):
+        """Rewards of the last step, [B, A] (base.py:369,387 keep them on the env as well as returning them)."""
+        return self._rewards_view
+
+    def compute_state_dims(self, state_field):
+        """base.py:565-579 evaluated on the reference's observation_space (base.py:211-228, tagging.py:42-60), its quirk
+        included: for a Box it returns ``[high[0] - low[0]] * ndim`` -- a 2x2 tensor of N for the (n, 2) position boxes."""
+        N, A, J = self.n_rows, self.n_agents, self.n_jobs
+        box2 = torch.tensor([[N, N], [N, N]])
+        table = {StateFields.AGENT_POSITIONS: box2, StateFields.ALIVE_AGENTS: torch.tensor([A])}
+        if J > 0 or self.VARIANT == L.VARIANT_TAGGING:
+            table[StateFields.JOB_POSITIONS] = box2
+            table[StateFields.JOB_STATUS] = torch.tensor([J])
+        if self.VARIANT == L.VARIANT_TAGGING:
+            table[StateFields.USED_TAGS] = torch.tensor([A])
+            table[StateFields.TAG_COUNTS] = torch.tensor([A])
+            table[StateFields.TAG_RESET_COUNT] = torch.tensor([self.tag_reset_interval - 1])
+        if state_field not in table:
+            raise IndexError("tuple index out of range")  # the reference indexes observation_space[state_field.value]
+        return table[state_field]
+
+    @property
     def t(self):
         return self._t
 

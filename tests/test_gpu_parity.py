@@ -666,6 +666,24 @@ def test_featurize_matches_oracle_on_tagging_rows(pkg, oracle_mod):
     assert torch.equal(flat, traj3["obs"])
 
 
+def test_small_attribute_mirrors(pkg):
+    """crew_idxs (base.py:283), agent_rewards (base.py:369,387), compute_state_dims (base.py:565-579: values recorded
+    from the reference for FourRoomEnv(1, 2, 4) and FourRoomEnvWithTagging(1, 4, 5), its 2x2 quirk included)."""
+    SF = pkg.StateFields
+    env = pkg.BatchedFourRoomEnv(1, 2, 4, batch=8, seed=1)
+    env.reset()
+    assert [env.compute_state_dims(f).tolist() for f in list(SF)[:4]] == [[[9, 9], [9, 9]], [3], [[9, 9], [9, 9]], [4]]
+    with pytest.raises(IndexError):
+        env.compute_state_dims(SF.USED_TAGS)
+    tag = pkg.BatchedFourRoomEnvWithTagging(1, 4, 5, batch=8, seed=1)
+    tag.reset()
+    assert [tag.compute_state_dims(f).tolist() for f in SF] == [[[9, 9], [9, 9]], [5], [[9, 9], [9, 9]], [5], [5], [5], [49]]
+    imp, crew = np_(env.imposter_idxs), np_(env.crew_idxs)
+    assert crew.shape == (8, 2) and all(sorted(list(imp[b]) + list(crew[b])) == [0, 1, 2] for b in range(8))
+    _, rew, *_ = env.step(env.sample_actions())
+    assert env.agent_rewards is rew or torch.equal(env.agent_rewards, rew)
+
+
 # ------------------------------------------------------------------------------------------------
 # error behaviour (reference: AssertionError base.py:357-362, IndexError base.py:379-382)
 # ------------------------------------------------------------------------------------------------
