@@ -11,7 +11,7 @@ import os as _os
 # an explicit HIP_FORCE_DEV_KERNARG=0 in the environment wins.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
-from .metrics import SusMetrics  # noqa: F401,E402
+from .metrics import EpisodicMetricHandler, SusMetrics  # noqa: F401,E402
 from .env import (  # noqa: F401,E402
     Action, BatchedFourRoomEnv, BatchedFourRoomEnvWithTagging, BatchedImposterTrainingGround, ObsConfig,
     StateFields, four_room_grid,

@@ -145,3 +145,24 @@ def test_q_network_mirrors_load_reference_parameters_and_reproduce_forward(name)
         assert torch.equal(out, out2)
         copy = model.create_copy()
         assert all(torch.equal(a, b) for a, b in zip(copy.state_dict().values(), model.state_dict().values()))
+
+
+def test_episodic_metric_handler_mirror(pkg, tmp_path):
+    """src/metrics.py:67-95: per-episode lists, mean, JSON round trip; batched `step` with an ended-mask."""
+    import torch
+
+    M = pkg.SusMetrics
+    h = pkg.EpisodicMetricHandler()
+    h.step({m: 1 for m in M})
+    info = {m: torch.tensor([2, 4, 6, 8]) for m in M}
+    h.step(info, ended=torch.tensor([True, False, True, False]))
+    assert h.metrics[M.IMP_KILLED_CREW] == [1, 2, 6] and h.compute()[M.CREW_WON] == 3.0
+    h.set({M.AVG_CREW_RETURNS: [1.5, 2.5]})
+    assert h.compute()[M.AVG_CREW_RETURNS] == 2.0
+    p = tmp_path / "m.json"
+    h.save_metrics(p)
+    h2 = pkg.EpisodicMetricHandler()
+    h2.load_metrics(p)
+    assert h2.metrics["imp_killed_crew"] == [1, 2, 6]
+    with pytest.raises(AssertionError):
+        h.set({"nonsense": [1]})
