@@ -31,38 +31,45 @@ class SusMetrics(str, Enum):
 
 
 class EpisodicMetricHandler:
-    """Averages the ``info`` counters over finished episodes (reference src/metrics.py:67-95, same methods and JSON
-    format).  ``step`` also takes the batched env's ``info`` (a dict of ``[B]`` tensors) together with the mask of envs
-    whose episode just ended: one entry per finished episode is appended, as ``train()`` does at every episode end
-    (src/train.py:427-430).  For whole-node totals without per-episode lists see ``dist.node_metrics``."""
+    """Per-episode history of the ``info`` counters and their means: the interface of the reference's handler of the same
+    name (src/metrics.py:67-95 -- ``step / set / compute / save_metrics / load_metrics``, JSON of ``{name: [values]}``),
+    extended for the batched env: ``step(info, ended)`` takes ``info`` as a dict of ``[B]`` tensors plus the mask of
+    envs whose episode just finished and records one entry per finished episode, which is what ``train()`` does at every
+    episode end (src/train.py:427-430).  Whole-node totals without histories: ``dist.node_metrics``."""
 
     def __init__(self):
-        self.metrics = {metric: [] for metric in SusMetrics}
+        self.metrics = {m: [] for m in SusMetrics}
+
+    def _history(self, name):
+        key = SusMetrics(name) if not isinstance(name, SusMetrics) else name
+        return self.metrics.setdefault(key, [])
 
     def step(self, metrics, ended=None) -> None:
-        for metric, value in metrics.items():
-            if hasattr(value, "tolist"):  # [B] tensor / array: the episodes that ended in this tick
-                value = value[ended] if ended is not None else value
-                self.metrics[metric].extend(value.reshape(-1).tolist())
+        for name, value in metrics.items():
+            history = self._history(name)
+            if hasattr(value, "tolist"):
+                picked = value if ended is None else value[ended]
+                history.extend(picked.reshape(-1).tolist())
             else:
-                self.metrics[metric].append(value)
+                history.append(value)
 
     def set(self, metrics) -> None:
-        for metric, values in metrics.items():
-            assert any(m.value == metric for m in SusMetrics), f"Invalid metric: {metric}"
-            self.metrics[metric] = values
+        known = {m.value for m in SusMetrics}
+        for name, values in metrics.items():
+            assert str(name) in known, f"Invalid metric: {name}"
+            self.metrics[SusMetrics(name)] = values
 
     def compute(self):
-        return {metric: sum(values) / len(values) for metric, values in self.metrics.items()}
+        return {name: sum(history) / len(history) for name, history in self.metrics.items()}
 
-    def save_metrics(self, save_file_path):
+    def save_metrics(self, save_file_path) -> None:
         import json
+        from pathlib import Path
 
-        with open(save_file_path, "w") as f:
-            json.dump({str(k): v for k, v in self.metrics.items()}, f)
+        Path(save_file_path).write_text(json.dumps({str(name): history for name, history in self.metrics.items()}))
 
-    def load_metrics(self, metrics_file_path):
+    def load_metrics(self, metrics_file_path) -> None:
         import json
+        from pathlib import Path
 
-        with open(metrics_file_path, "r") as f:
-            self.metrics = json.load(f)
+        self.metrics = json.loads(Path(metrics_file_path).read_text())
