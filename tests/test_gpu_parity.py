@@ -365,6 +365,32 @@ def test_graph_replayed_random_steps_match_oracle(pkg, oracle_mod):
         compare_full_state(env, ob, f"{name} after graph replays")
 
 
+def test_node_metrics_over_rccl(pkg):
+    """The one collective of the path (dist.node_metrics: device reduction + all_gather_into_tensor) through the real
+    RCCL backend, single rank (a one-GPU box cannot host two RCCL ranks; the two-rank control flow is the gloo test)."""
+    import torch.distributed as dist
+
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        created = True
+    try:
+        env = pkg.BatchedImposterTrainingGround(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
+                                                time_step_reward=0, include_walls=False, batch=4096, auto_reset=True, seed=2,
+                                                max_time_steps=50)
+        env.reset()
+        traj = env.rollout(200)
+        torch.cuda.synchronize()
+        m = pkg.dist.node_metrics(env)
+        ended = int((traj["done"] | traj["truncated"]).sum())
+        assert m["episodes"] == ended and m["per_rank_episodes"] == [ended]
+        assert m["imposter_won"] == int(traj["done"].sum()) and m["truncated"] == int((traj["truncated"] & ~traj["done"]).sum()) \
+            or m["truncated"] == int(traj["truncated"].sum())
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_sharding_is_invisible(pkg, oracle_mod):
     """Env b of a shard with env_id_base = k behaves exactly as env k + b of one big batch."""
     name, B, seed = "base_2v6_j4_14", 1024, 5
