@@ -25,6 +25,7 @@ struct StepArgs {
     int64_t act_sa, act_sb; // element strides (agent, env)
     RewardSink rewards;
     uint8_t *done, *trunc;
+    uint64_t tick; // steps taken so far (index of the action stream: the shuffled order of this step comes from it)
 };
 
 struct RolloutArgs {
@@ -139,7 +140,15 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
         RNG rng = make_rng<RNG>(c, s, b);
         bool done, trunc;
-        uint32_t bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc);
+        uint32_t ow = 0;
+        if constexpr (!RNG::kNumpy) {
+            if (S::order_random(c)) {
+                ActionStream as;
+                as.init();
+                ow = order_word<S>(c, rng, as, c.dev_tick ? *s.dev_tick : a.tick, false);
+            }
+        }
+        uint32_t bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc, nullptr, ow);
         if (bits) atomicOr(s.err, bits);
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
@@ -153,7 +162,14 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         store_env<S>(c, s, st, b, e, jobs_changed);
         finish_rng(s, b, rng);
     }
-    if (c.dev_tick && blockIdx.x == 0 && tid == 0) *s.dev_tick += 1ull; // (nothing in this kernel reads the counter)
+    if (c.dev_tick && tid == 0) { // every workgroup may have read the counter: the last one to finish advances it
+        __threadfence();
+        if (atomicAdd(s.blk_done, 1u) == gridDim.x - 1u) {
+            *s.dev_tick += 1ull;
+            *s.blk_done = 0u;
+            __threadfence();
+        }
+    }
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
@@ -258,6 +274,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         STAMP(0);
         if (active) {
             sample_actions_env<S, PAR>(c, st, e, rng, as, tick_base + (uint64_t)tick, tick == 0);
+            // shuffled order: the tick's permutation word sits next to its action words (usually in the block just used)
+            const uint32_t ow = S::order_random(c) ? order_word<S>(c, rng, as, tick_base + (uint64_t)tick, true) : 0u;
             STAMP(1);
             uint32_t av[S::kA > 0 ? S::kA : 1];
             float rr[S::kA > 0 ? S::kA : 1];
@@ -280,13 +298,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr, rr};
             bool done, trunc;
 #ifdef SUSNET_STAMPS
-            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
-            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
-            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2);
+            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
+            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
+            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
 #else
-            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc);
-            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc);
-            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc);
+            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
+            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
+            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
 #endif
             STAMP(3);
             if (kTraj) {
@@ -940,6 +958,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     }
     a.done = io->done;
     a.trunc = io->truncated;
+    a.tick = env->ticks;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -510,7 +510,35 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
     const int A = S::A(c);
     for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
 }
-// A tick owns W words of the action stream.  A > 2: W = A rounded up to a multiple of 4 (W/4 blocks per tick, agent i
+// Blocks of 4 action-stream words a tick owns when A > 2: the A agent words plus, when the action order is shuffled,
+// one word that carries the step's whole permutation (order_word / shuffle_from_word), in whole Philox blocks.
+template <class S>
+__device__ __forceinline__ uint64_t action_blocks_per_tick(const Consts &c) {
+    return (uint64_t)((S::A(c) + (S::order_random(c) ? 1 : 0) + 3) >> 2);
+}
+// The permutation word of `tick` (word A of the tick).  have_block: `as` already holds the block of the LAST agent word
+// (the caller sampled this tick's actions just before): unless A is a multiple of 4 that is the block of word A too.
+template <class S>
+__device__ __forceinline__ uint32_t order_word(const Consts &c, const PhiloxRng &rng, ActionStream &as, uint64_t tick, bool have_block) {
+    const int A = S::A(c);
+    if (!have_block || (A & 3) == 0) as.gen(rng, tick * action_blocks_per_tick<S>(c) + (uint64_t)(A >> 2));
+    const uint32_t q = (uint32_t)A & 3u;
+    const uint32_t lo = (q & 1u) ? as.w1 : as.w0, hi = (q & 1u) ? as.w3 : as.w2;
+    return (q & 2u) ? hi : lo;
+}
+// np.random.shuffle (base.py:374) from ONE word: the Fisher-Yates draws i = n-1 .. 1 are the successive mixed-radix
+// digits of the word (nested multiply-shift; joint bias <= n! * 2^-32)
+template <class ORD>
+__device__ __forceinline__ void shuffle_from_word(ORD &v, int n, uint32_t w) {
+#pragma unroll
+    for (int i = n - 1; i >= 1; i--) {
+        const uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(i + 1);
+        w = (uint32_t)p;
+        nibble_swap(v, i, (int)(uint32_t)(p >> 32));
+    }
+}
+
+// A tick owns W words of the action stream.  A > 2: W = 4 * action_blocks_per_tick (agent i
 // reads word i: static word assignment).  A <= 2 (the 1v1 game): W = 1 -- ONE word serves both agents by nested
 // multiply-shift (p = w * n0: agent 0 takes the high word of p, agent 1 the high word of lo32(p) * n1, i.e. the two
 // mixed-radix digits of w * n0 * n1 / 2^32; joint bias <= n0 * n1 * 2^-32), so one Philox block serves FOUR ticks.
@@ -530,7 +558,7 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
         st.set_act(0, (uint32_t)(p >> 32));
         if (A == 2) st.set_act(1, __umulhi((uint32_t)p, n_actions<S>(c, (S::imp(c, e.imp) >> 1) & 1u)));
     } else {
-        const uint64_t blocks = (uint64_t)((A + 3) >> 2);
+        const uint64_t blocks = action_blocks_per_tick<S>(c);
 #pragma unroll
         for (int i = 0; i < A; i++) {
             if ((i & 3) == 0) as.gen(rng, tick * blocks + (uint64_t)(i >> 2));
@@ -646,11 +674,12 @@ __device__ __forceinline__ void clear_info_if_fresh(Env &e) {
 // returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
 // SINK_ON: the reward sink is bound to this env's float32 row of the rollout trajectory [T][B][A]: 1 = by pointer
 // (sink.ptr), 2 = by buffer descriptor (sink.buf), 3 = left in the caller's registers (sink.regs); 0 = generic strided put
+// order_w: production stream, shuffled order only -- the tick's permutation word (order_word()).
 // LAZY_INFO = false: the caller guarantees the env is not FRESH (the fused rollout clears once before its loop and
 // zeroes the counters itself at an episode end that is not the launch's last tick)
 template <class S, bool VALIDATE, int SINK_ON, bool LAZY_INFO = true, class RNG, class Store, class Sink>
 __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const Sink &sink,
-                                             int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr) {
+                                             int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr, uint32_t order_w = 0u) {
 #ifdef SUSNET_STAMPS
     unsigned long long sprev = __builtin_readcyclecounter();
 #define SSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); if (sg) sg[k] += tn - sprev; sprev = tn; } while (0)
@@ -685,7 +714,10 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     OrderT order = (OrderT)0xFEDCBA9876543210ull; // identity permutation, 4 bits per turn
     rng.align();
     const bool shuffled = S::order_random(c);
-    if (shuffled) shuffle_nibbles<!S::kGeneric>(rng, order, A); // base.py:372-374
+    if (shuffled) { // base.py:372-374
+        if (RNG::kNumpy) shuffle_nibbles<false>(rng, order, A);
+        else shuffle_from_word(order, A, order_w); // production protocol: the caller read the tick's permutation word
+    }
 
     // The per-agent body is written as straight-line predicated code (selects instead of branches): with one
     // wave per SIMD a taken branch is an instruction-fetch bubble nothing else can hide, and a 64-lane wave

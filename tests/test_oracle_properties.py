@@ -121,3 +121,37 @@ def test_one_word_serves_both_1v1_agents_jointly_uniform(oracle_mod):
     assert _chi2(lag.ravel(), B * (ticks - 1) / 36) < 66
     # sampling twice before a step returns the same actions (the step advances the tick, sampling does not)
     np.testing.assert_array_equal(ob.sample_actions(), ob.sample_actions())
+
+
+def test_action_order_from_one_word_is_a_uniform_permutation(oracle_mod):
+    """Production protocol: the step's shuffled agent order is decoded from ONE action-stream word (Fisher-Yates digits by
+    nested multiply-shift).  All 3! orders of a 1v2 game must be equally likely (df = 5: 99.9 % quantile ~ 20.5), every
+    agent of a 2v6 game equally likely at every turn (8 x 8 table, df = 49: ~ 85), and consecutive steps unrelated."""
+    om = oracle_mod
+    B = 12000
+    ob = om.OracleBatch(om.make_config("base", n_imposters=1, n_crew=2, n_jobs=4), B)
+    ob.set_philox(5, 0, 0)
+    ob.reset()
+    counts, lag = {}, np.zeros((3, 3))
+    prev = None
+    for _ in range(4):
+        ob.step(np.zeros((B, 3), dtype=np.int64))
+        order = ob.order.copy()
+        assert (np.sort(order, axis=1) == np.arange(3)).all()
+        for row in map(tuple, order):
+            counts[row] = counts.get(row, 0) + 1
+        if prev is not None:
+            np.add.at(lag, (prev[:, 0], order[:, 0]), 1)
+        prev = order
+    assert len(counts) == 6 and _chi2(np.array(list(counts.values()), dtype=float), 4 * B / 6) < 20.5
+    assert _chi2(lag.ravel(), 3 * B / 9) < 26.1  # df = 8
+    ob8 = om.OracleBatch(om.make_config("base", n_imposters=2, n_crew=6, n_jobs=4), B)
+    ob8.set_philox(6, 0, 0)
+    ob8.reset()
+    ob8.step(np.zeros((B, 8), dtype=np.int64))
+    o8 = ob8.order
+    assert (np.sort(o8, axis=1) == np.arange(8)).all()
+    table = np.zeros((8, 8))
+    for turn in range(8):
+        table[turn] = np.bincount(o8[:, turn], minlength=8)
+    assert _chi2(table.ravel(), B / 8) < 85
