@@ -340,11 +340,16 @@ void so_reset(so_env *e) {
     }
 }
 
-/* production action stream: words a tick owns.  1 for the 1v1 game; otherwise the A agent words plus, when the action
- * order is shuffled, one word for the step's permutation, rounded up to whole Philox blocks of 4 */
+/* production action stream, layout of a tick's words for A > 2 (the 1v1 game uses one word per tick):
+ *   s = 1 if the action order is shuffled (one more word carries the step's permutation), else 0;
+ *   A + s <= 4: word i serves agent i, word A the permutation;
+ *   otherwise agents are packed FOUR per word by nested multiply-shift (word k serves agents 4k .. 4k+3 in index order),
+ *   the permutation word follows the ceil(A / 4) action words.  Everything is rounded up to whole Philox blocks. */
+static int so_action_packed(const so_env *e) { return e->A + (e->cfg.is_action_order_random ? 1 : 0) > 4; }
+static int so_action_words(const so_env *e) { return so_action_packed(e) ? (e->A + 3) / 4 : e->A; }
 static uint64_t so_action_words_per_tick(const so_env *e) {
     if (e->A <= 2) return 1u;
-    return (uint64_t)((e->A + (e->cfg.is_action_order_random ? 1 : 0) + 3) & ~3);
+    return (uint64_t)((so_action_words(e) + (e->cfg.is_action_order_random ? 1 : 0) + 3) & ~3);
 }
 
 /* base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order */
@@ -353,8 +358,8 @@ void so_sample_actions(so_env *e, int32_t *actions) {
         /* production protocol: agent i's action at step `tick` is word tick * W + i of the action stream; sampling
          * does not advance anything (the step does), so repeated calls before a step return the same actions */
         /* a tick owns W words of the action stream (so_action_words_per_tick).  A <= 2: W = 1, one word serves both
-         * agents by nested multiply-shift (p = w * n0: agent 0 = hi32(p), agent 1 = hi32(lo32(p) * n1)).  A > 2: agent i
-         * reads word i; with a shuffled action order word A carries the step's permutation (so_step). */
+         * agents by nested multiply-shift (p = w * n0: agent 0 = hi32(p), agent 1 = hi32(lo32(p) * n1)).  A > 2: see the
+         * layout comment above; with a shuffled action order one more word carries the step's permutation (so_step). */
         if (e->A <= 2) {
             uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick, SO_ACTION_STREAM_TAG);
             uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, 0);
@@ -363,9 +368,20 @@ void so_sample_actions(so_env *e, int32_t *actions) {
             return;
         }
         const uint64_t W = so_action_words_per_tick(e);
-        for (int i = 0; i < e->A; i++) {
-            uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * W + (uint64_t)i, SO_ACTION_STREAM_TAG);
-            actions[i] = (int)(((uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i)) >> 32);
+        if (!so_action_packed(e)) {
+            for (int i = 0; i < e->A; i++) {
+                uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * W + (uint64_t)i, SO_ACTION_STREAM_TAG);
+                actions[i] = (int)(((uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i)) >> 32);
+            }
+        } else {
+            uint32_t w = 0;
+            for (int i = 0; i < e->A; i++) {
+                if ((i & 3) == 0)
+                    w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * W + (uint64_t)(i >> 2), SO_ACTION_STREAM_TAG);
+                uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i);
+                actions[i] = (int)(p >> 32);
+                w = (uint32_t)p;
+            }
         }
         return;
     }
@@ -498,11 +514,11 @@ int so_step(so_env *e, const int32_t *actions, double *rewards, int32_t *done_ou
     draw_align(e);
     if (e->cfg.is_action_order_random) { /* base.py:372-374: np.random.shuffle(agent order) */
         if (e->rng.kind == SO_RNG_PHILOX) {
-            /* production protocol: the whole permutation comes from ONE word of the action stream (word A of this
-             * tick), the Fisher-Yates draws i = A-1 .. 1 being its successive mixed-radix digits (nested
+            /* production protocol: the whole permutation comes from ONE word of the action stream (the word after this
+             * tick's action words), the Fisher-Yates draws i = A-1 .. 1 being its successive mixed-radix digits (nested
              * multiply-shift: j = hi32(w * (i + 1)), w = lo32(w * (i + 1)); joint bias <= A! * 2^-32) */
-            uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * so_action_words_per_tick(e) + (uint64_t)A,
-                                            SO_ACTION_STREAM_TAG);
+            uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id,
+                                            e->rng.tick * so_action_words_per_tick(e) + (uint64_t)so_action_words(e), SO_ACTION_STREAM_TAG);
             for (int i = A - 1; i >= 1; i--) {
                 uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(i + 1);
                 int j = (int)(p >> 32);

@@ -510,19 +510,31 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
     const int A = S::A(c);
     for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
 }
-// Blocks of 4 action-stream words a tick owns when A > 2: the A agent words plus, when the action order is shuffled,
-// one word that carries the step's whole permutation (order_word / shuffle_from_word), in whole Philox blocks.
+// Layout of a tick's action-stream words when A > 2 (the 1v1 game: one word per tick, see sample_actions_env).
+//   s = 1 if the action order is shuffled (one more word carries the step's whole permutation), else 0.
+//   A + s <= 4 : word i serves agent i, word A the permutation: one Philox block.
+//   otherwise  : agents are packed FOUR per word by nested multiply-shift (word k serves agents 4k .. 4k+3 in index
+//                order: a = hi32(w * n), w = lo32(w * n); joint bias <= n^4 * 2^-32 < 4e-6), the permutation word follows
+//                the ceil(A / 4) action words -- one block per tick up to 12 agents instead of up to four.
 template <class S>
-__device__ __forceinline__ uint64_t action_blocks_per_tick(const Consts &c) {
-    return (uint64_t)((S::A(c) + (S::order_random(c) ? 1 : 0) + 3) >> 2);
-}
-// The permutation word of `tick` (word A of the tick).  have_block: `as` already holds the block of the LAST agent word
-// (the caller sampled this tick's actions just before): unless A is a multiple of 4 that is the block of word A too.
+struct ActionWords {
+    int A, s;
+    __device__ __forceinline__ ActionWords(const Consts &c) : A(S::A(c)), s(S::order_random(c) ? 1 : 0) {}
+    __device__ __forceinline__ bool packed() const { return A + s > 4; }
+    __device__ __forceinline__ int n_action_words() const { return packed() ? (A + 3) >> 2 : A; }
+    __device__ __forceinline__ int perm_word() const { return n_action_words(); }
+    __device__ __forceinline__ uint64_t blocks() const { return (uint64_t)((n_action_words() + s + 3) >> 2); }
+};
+template <class S>
+__device__ __forceinline__ uint64_t action_blocks_per_tick(const Consts &c) { return ActionWords<S>(c).blocks(); }
+// The permutation word of `tick`.  have_block: `as` already holds the block of the LAST action word (the caller sampled
+// this tick's actions just before): unless the permutation word starts a new block that is its block too.
 template <class S>
 __device__ __forceinline__ uint32_t order_word(const Consts &c, const PhiloxRng &rng, ActionStream &as, uint64_t tick, bool have_block) {
-    const int A = S::A(c);
-    if (!have_block || (A & 3) == 0) as.gen(rng, tick * action_blocks_per_tick<S>(c) + (uint64_t)(A >> 2));
-    const uint32_t q = (uint32_t)A & 3u;
+    const ActionWords<S> L(c);
+    const int P = L.perm_word();
+    if (!have_block || (P & 3) == 0) as.gen(rng, tick * L.blocks() + (uint64_t)(P >> 2));
+    const uint32_t q = (uint32_t)P & 3u;
     const uint32_t lo = (q & 1u) ? as.w1 : as.w0, hi = (q & 1u) ? as.w3 : as.w2;
     return (q & 2u) ? hi : lo;
 }
@@ -538,8 +550,7 @@ __device__ __forceinline__ void shuffle_from_word(ORD &v, int n, uint32_t w) {
     }
 }
 
-// A tick owns W words of the action stream.  A > 2: W = 4 * action_blocks_per_tick (agent i
-// reads word i: static word assignment).  A <= 2 (the 1v1 game): W = 1 -- ONE word serves both agents by nested
+// A tick owns W words of the action stream.  A > 2: see ActionWords (static word assignment either way).  A <= 2 (the 1v1 game): W = 1 -- ONE word serves both agents by nested
 // multiply-shift (p = w * n0: agent 0 takes the high word of p, agent 1 the high word of lo32(p) * n1, i.e. the two
 // mixed-radix digits of w * n0 * n1 / 2^32; joint bias <= n0 * n1 * 2^-32), so one Philox block serves FOUR ticks.
 // Q: the tick's position in its block when the caller knows it at compile time (the fused rollout's 4-tick loop
@@ -558,12 +569,26 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
         st.set_act(0, (uint32_t)(p >> 32));
         if (A == 2) st.set_act(1, __umulhi((uint32_t)p, n_actions<S>(c, (S::imp(c, e.imp) >> 1) & 1u)));
     } else {
-        const uint64_t blocks = action_blocks_per_tick<S>(c);
+        const ActionWords<S> L(c);
+        const uint64_t blocks = L.blocks();
+        if (!L.packed()) {
 #pragma unroll
-        for (int i = 0; i < A; i++) {
-            if ((i & 3) == 0) as.gen(rng, tick * blocks + (uint64_t)(i >> 2));
-            const uint32_t w = (i & 3) == 0 ? as.w0 : (i & 3) == 1 ? as.w1 : (i & 3) == 2 ? as.w2 : as.w3;
-            st.set_act(i, __umulhi(w, n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
+            for (int i = 0; i < A; i++) {
+                if ((i & 3) == 0) as.gen(rng, tick * blocks + (uint64_t)(i >> 2));
+                const uint32_t w = (i & 3) == 0 ? as.w0 : (i & 3) == 1 ? as.w1 : (i & 3) == 2 ? as.w2 : as.w3;
+                st.set_act(i, __umulhi(w, n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
+            }
+        } else {
+            uint32_t w = 0;
+#pragma unroll
+            for (int i = 0; i < A; i++) {
+                const int k = i >> 2; // this agent's word
+                if ((i & 15) == 0) as.gen(rng, tick * blocks + (uint64_t)(k >> 2));
+                if ((i & 3) == 0) w = (k & 3) == 0 ? as.w0 : (k & 3) == 1 ? as.w1 : (k & 3) == 2 ? as.w2 : as.w3;
+                const uint64_t p = (uint64_t)w * (uint64_t)n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u);
+                st.set_act(i, (uint32_t)(p >> 32));
+                w = (uint32_t)p;
+            }
         }
     }
 }

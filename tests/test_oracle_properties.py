@@ -155,3 +155,24 @@ def test_action_order_from_one_word_is_a_uniform_permutation(oracle_mod):
     for turn in range(8):
         table[turn] = np.bincount(o8[:, turn], minlength=8)
     assert _chi2(table.ravel(), B / 8) < 85
+
+
+def test_four_agents_share_one_action_word_independently(oracle_mod):
+    """Production protocol, more than four action-stream words per tick: agents are packed four per word by nested
+    multiply-shift.  Marginals stay uniform over each role's range and agents sharing a word are independent (a crew-crew
+    pair: 6 x 6 table, df = 35: 99.9 % quantile ~ 66.6; agent 3 vs agent 4 sit in different words: same bound)."""
+    om = oracle_mod
+    B = 40000
+    ob = om.OracleBatch(om.make_config("base", n_imposters=2, n_crew=6, n_jobs=4, shuffle_imposter_index=False), B)
+    ob.set_philox(11, 0, 0)
+    ob.reset()
+    a = ob.sample_actions()  # agents 0, 1 imposters (7 actions), 2..7 crew (6 actions)
+    assert a[:, :2].max() == 6 and a[:, 2:].max() == 5 and a.min() == 0
+    for i in range(8):
+        n = 7 if i < 2 else 6
+        assert _chi2(np.bincount(a[:, i], minlength=n).astype(float), B / n) < (22.5 if n == 7 else 20.5), i
+    for i, j in ((2, 3), (3, 4), (0, 1), (6, 7)):
+        ni, nj = (7 if i < 2 else 6), (7 if j < 2 else 6)
+        t = np.zeros((ni, nj))
+        np.add.at(t, (a[:, i], a[:, j]), 1)
+        assert _chi2(t.ravel(), B / (ni * nj)) < 85, (i, j)
