@@ -330,8 +330,8 @@ def main():
                              "ms_per_step": r2["seconds"] * 1e3 / k2, "launches_per_step": 2 if other == "step" else 1.0 / args.ticks}
         del r2
         if other == "step":
-            # the same two kernels per tick captured as a hipGraph of 16 ticks (32 kernel nodes; the step counter lives
-            # in device memory so that a replay draws fresh actions) and replayed
+            # the same two kernels per tick (+ the one-thread launch that advances the device-resident step counter, so
+            # that a replay draws fresh actions) captured as a hipGraph of 16 ticks and replayed
             env_g = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=obs_config(args.obs))
             env_g.reset()
             gt = 16
@@ -345,7 +345,7 @@ def main():
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
             line["secondary"]["hip_graph_replay"] = {"value": B * 4096 / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / 4096,
-                                                     "ticks_per_graph": gt, "nodes_per_tick": 2}
+                                                     "ticks_per_graph": gt, "nodes_per_tick": 3}
             del env_g, graph
     if rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy":
         # the same rollout with the reference's float32 feature layouts fused in (HBM-write bound)

@@ -266,8 +266,8 @@ int susnet_reduce_lifetime(susnet_env *env, int64_t *out_device, void *stream);
 
 /* Graph-replayable launches.  By default the step counter that indexes the production action stream (susnet_tick)
  * travels as a kernel argument, so a captured launch would replay with a stale value.  enable = 1 moves the counter
- * into device memory (inside the bound state blob): sample_actions / rollout read it there, step / rollout advance it
- * there, and a hipGraph captured from these calls (e.g. {susnet_sample_actions; susnet_step}) can be replayed any
+ * into device memory (inside the bound state blob): sample_actions / step / rollout read it there, and step / rollout
+ * are followed by a one-thread launch that advances it (no workgroup ever sees a half-advanced value), so a hipGraph captured from these calls (e.g. {susnet_sample_actions; susnet_step}) can be replayed any
  * number of times.  enable = 0 reads it back.  susnet_tick() keeps working in both modes (it synchronises in device
  * mode).  Synchronises `stream`. */
 int susnet_device_tick(susnet_env *env, int32_t enable, void *stream);

@@ -162,17 +162,13 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         store_env<S>(c, s, st, b, e, jobs_changed);
         finish_rng(s, b, rng);
     }
-    if (c.dev_tick && tid == 0) { // every workgroup may have read the counter: the last one to finish advances it
-        __threadfence();
-        if (atomicAdd(s.blk_done, 1u) == gridDim.x - 1u) {
-            *s.dev_tick += 1ull;
-            *s.blk_done = 0u;
-            __threadfence();
-        }
-    }
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
+
+// Device-resident step counter (susnet_device_tick): advanced by its own one-thread launch AFTER the kernel(s) that read
+// it, so that no workgroup can ever observe a half-advanced tick -- no atomics or fences on the stepping kernels.
+__global__ void k_bump_tick(uint64_t *tick, uint64_t n) { *tick += n; }
 
 // Fused random rollout: n_ticks x {sample_actions; step; auto-reset} with the state held on chip.
 // OUT selects what a tick stores, at compile time (run-time optional outputs cost uniform branches on a path
@@ -400,14 +396,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         store_env<S>(c, s, st, b, e, true);
         s.rng[b] = rng.cur;
         life.flush(c, s, b);
-    }
-    if (c.dev_tick && tid == 0) { // every workgroup read the counter at its start: the last one to finish advances it
-        __threadfence();
-        if (atomicAdd(s.blk_done, 1u) == gridDim.x - 1u) {
-            *s.dev_tick = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
-            *s.blk_done = 0u;
-            __threadfence();
-        }
     }
 }
 
@@ -975,6 +963,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     STEP_A(2) STEP_A(3) STEP_A(4) STEP_A(5) STEP_A(6) STEP_A(7) STEP_A(8)
 #undef STEP_A
     else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
+    if (env->c.dev_tick) hipLaunchKernelGGL(k_bump_tick, dim3(1), dim3(1), 0, st, env->s.dev_tick, (uint64_t)1);
     HIP_TRY(hipGetLastError());
     env->ticks += 1;
     return SUSNET_OK;
@@ -1081,6 +1070,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         ROLL_A(2) ROLL_A(3) ROLL_A(4) ROLL_A(5) ROLL_A(6) ROLL_A(7) ROLL_A(8)
 #undef ROLL_A
         else LAUNCH_ROLLOUT(GenericSpec);
+        if (env->c.dev_tick) hipLaunchKernelGGL(k_bump_tick, dim3(1), dim3(1), 0, st, env->s.dev_tick, (uint64_t)a.n_ticks);
         HIP_TRY(hipGetLastError());
     }
 #undef LAUNCH_ROLLOUT

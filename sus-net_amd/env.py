@@ -683,7 +683,7 @@ class BatchedFourRoomEnv:
             L.check(self.lib.susnet_device_tick(self._h, int(bool(enable)), self._stream()))
 
     def capture_random_step(self, n_ticks: int = 1) -> "torch.cuda.CUDAGraph":
-        """hipGraph of ``n_ticks`` drop-in ticks ``a = env.sample_actions(); env.step(a)`` (two kernel nodes each): the
+        """hipGraph of ``n_ticks`` drop-in ticks ``a = env.sample_actions(); env.step(a)`` (two kernel nodes + the counter bump each): the
         launch-bound inner loop of a random-policy driver, replayable with ``graph.replay()``.  Outputs land in the env's persistent
         tensors (``sample_actions()`` buffer, ``step()``'s rewards / done / truncated / fused observation).  Needs
         ``check_errors=False, export_state=False`` (both would synchronise inside the capture)."""
