@@ -770,7 +770,6 @@ extern "C" int susnet_bind_state(susnet_env *env, void *blob, uint64_t bytes, vo
     int64_t tape_len = s.tape_len;
     s.err = reinterpret_cast<uint32_t *>(p + env->off_err);
     s.dev_tick = reinterpret_cast<uint64_t *>(p + env->off_err + 192); // (the diagnostic build's stamps end at byte 144)
-    s.blk_done = reinterpret_cast<uint32_t *>(p + env->off_err + 200);
     s.agent = reinterpret_cast<uint16_t *>(p + env->off_agent);
     s.job = reinterpret_cast<uint8_t *>(p + env->off_job);
     s.jobdone = reinterpret_cast<uint16_t *>(p + env->off_jobdone);
@@ -1147,7 +1146,6 @@ extern "C" int susnet_device_tick(susnet_env *env, int32_t enable, void *stream)
         // the copy reads env->ticks_staging when it executes: a member, alive as long as the handle
         env->ticks_staging = env->ticks;
         HIP_TRY(hipMemcpyAsync(env->s.dev_tick, &env->ticks_staging, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(env->s.blk_done, 0, sizeof(uint32_t), st));
         HIP_TRY(hipStreamSynchronize(st));
         env->c.dev_tick = 1;
     } else if (!enable && env->c.dev_tick) {

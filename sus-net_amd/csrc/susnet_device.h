@@ -79,7 +79,6 @@ template <> __device__ __forceinline__ float rw<float>(const Consts &c, int k) {
 struct State {
     uint32_t *err;      // [1] device error word
     uint64_t *dev_tick; // [1] device-resident step counter (used when Consts::dev_tick; same 256-byte block as err)
-    uint32_t *blk_done; // [1] finished-workgroup counter of the running rollout launch
     uint16_t *agent;    // [A][Bp]
     uint8_t *job;       // [J][Bp]  x | y << 4 (constant within an episode)
     uint16_t *jobdone;  // [Bp] bitmask
