@@ -3,17 +3,22 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4] [--mode fused|step]
 
-A "step" is one lockstep tick of the hot path over the whole batch (every env samples uniform role-valid
-actions, steps, and auto-resets on done|truncated): the random-action rollout BASELINE.json names
-(`ReplayBuffer.populate`'s loop, reference src/replay_memory.py:96-143, minus the buffer).
+One pass of the hot path = every env samples uniform role-valid actions, steps, and auto-resets on done|truncated:
+the random-action rollout BASELINE.json names (`ReplayBuffer.populate`'s loop, reference
+src/replay_memory.py:96-143, minus the buffer).
 
-  --mode fused (default): `susnet_rollout`, `--ticks` ticks per launch, the trajectory (actions, rewards,
-                          done, truncated, raw observation) written to HBM every tick.
-  --mode step           : the drop-in API, two launches per tick (`sample_actions` + `step`).
+  --mode fused (default): a bench STEP is ONE `susnet_rollout` launch = `--ticks` (default 512) lockstep ticks over
+                          the whole batch, the trajectory (actions, rewards, done, truncated, raw observation)
+                          written to HBM every tick.  `--steps K --warmup W` = W untimed launches, then K timed ones;
+                          `value` = batch x ticks x K / wall time of the K launches, and `roofline` is derived from
+                          HIP events around the SAME K launches (one number, one set of launches).
+  --mode step           : the drop-in API; a bench step is one tick = two launches (`sample_actions` + `step`).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the batch is sharded by contiguous global env
-ids, per-GPU batch fixed (weak scaling); the only collective is one all-gather of the episode metrics after
-the timed region (sus-net_amd/dist.py).  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU (torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Started as a
+plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) the script launches the N ranks itself, before
+it touches the GPU.  The batch is sharded by contiguous global env ids, per-GPU batch fixed (weak scaling); the only
+collective is one all-gather of the episode metrics after the timed region (sus-net_amd/dist.py).  Rank 0 prints ONE
+JSON line.
 """
 from __future__ import annotations
 
@@ -73,10 +78,11 @@ def stored_bytes_per_step(A, J, N, obs):
     return b
 
 
-def profiled_traffic(kernel_prefix, obs):
+def profiled_traffic(config, obs):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN_pmc_summary.json; separate --pmc runs for FETCH_SIZE and WRITE_SIZE, KiB units; FETCH_SIZE
-    doubled per MI355X_MICROARCH.md's gfx950 correction).  bench.py cannot collect PMCs itself."""
+    (profiles/rNN_pmc_summary.json, written by tools/summarize_profiles.py: one entry per config, separate --pmc runs for
+    FETCH_SIZE and WRITE_SIZE, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  bench.py
+    cannot collect PMCs itself."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
@@ -84,13 +90,13 @@ def profiled_traffic(kernel_prefix, obs):
         return None, None
     try:
         d = json.load(open(files[-1]))
+        d = d.get(config, d if config == "cfg2" else {})  # (round-1 summaries held cfg2 only, at top level)
         wkey = {"raw": "pmc_WRITE_SIZE", "planes": "pmc_W_planes", "flat": "pmc_W_flat"}.get(obs)
-        w = next(v["WRITE_SIZE"]["mean_per_launch"] for k, v in d[wkey].items() if k.startswith(kernel_prefix))
-        f = 0.0
-        if obs == "raw":
-            f = next(v["FETCH_SIZE"]["mean_per_launch"] for k, v in d["pmc_FETCH_SIZE"].items() if k.startswith(kernel_prefix))
+        pick = lambda grp, ctr: next(v[ctr]["mean_per_launch"] for k, v in d[grp].items() if k.startswith("void k_rollout"))
+        w = pick(wkey, "WRITE_SIZE")
+        f = pick("pmc_FETCH_SIZE", "FETCH_SIZE") if obs == "raw" else 0.0
         return (w + 2.0 * f) * 1024.0, os.path.basename(files[-1])
-    except (KeyError, StopIteration, ValueError):
+    except (KeyError, StopIteration, ValueError, TypeError):
         return None, None
 
 
@@ -138,6 +144,9 @@ def cpu_baseline(spec, target_seconds=12.0):
         out[label] = dict(rate=n / dt, n=n, seconds=dt, episodes=eps)
     return dict(
         value=out["all"]["rate"], unit="env-steps/s", cores=cores, kind="port",
+        kind_note=("the C restatement of the reference algorithm (oracle/, pinned to the reference by the golden fixtures), OpenMP over "
+                   "independent envs; the reference itself is Python and never travels to the GPU box: its figures below are constants "
+                   "measured once in the build container, not on this host"),
         sample=(f"C oracle, numpy-legacy MT19937 stream, {B} envs x {out['all']['n'] // B} steps random-action rollout "
                 f"with reset on done|truncated ({out['all']['seconds']:.1f} s on {cores} threads)"),
         single_thread_value=out["1"]["rate"],
@@ -147,21 +156,41 @@ def cpu_baseline(spec, target_seconds=12.0):
     )
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without the torch.distributed.run environment: start the N ranks ourselves (one per
+    GPU), BEFORE this process makes any GPU call, relay their output and return their exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32768)
-    ap.add_argument("--warmup", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=64, help="timed bench steps (fused: launches of --ticks ticks; step mode: ticks)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="fused", choices=["fused", "step"])
     ap.add_argument("--obs", default="raw", choices=["none", "raw", "flat", "planes"])
-    ap.add_argument("--ticks", type=int, default=512, help="ticks per fused launch")
+    ap.add_argument("--ticks", type=int, default=512, help="ticks per fused launch (= per bench step in fused mode)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--packed", type=int, default=0, help="fused + raw obs: 1 = one packed record per env-step (compiled-in "
                     "configurations), 0 = separate trajectory tensors (default; faster on cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    assert args.gpus >= 1 and args.steps >= 1 and args.warmup >= 0 and args.ticks >= 1
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # nothing above this line touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -173,7 +202,13 @@ def main():
         os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local = pkg.dist.init_from_env(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launched world has {world} rank(s) (WORLD_SIZE); refusing to report "
+                         f"a line for a different GPU count")
+    if world > 1:  # every rank must be there: the gathered world is what n_gpus reports
+        seen = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
+        dist.all_reduce(seen)
+        assert int(seen.item()) == args.gpus, f"gathered {int(seen.item())} ranks, expected {args.gpus}"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     spec = CONFIGS[args.config]
@@ -196,23 +231,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def run_fused(env, n_ticks, T, bufs, events=None):
-        done = 0
-        launches = 0
+    def run_fused(env, n_launches, T, bufs, events=None):
         stream = torch.cuda.current_stream(device)
-        while done < n_ticks:
-            t = min(T, n_ticks - done)
+        for _ in range(n_launches):
             if events is not None:  # HIP events bracketing THIS launch on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                env.rollout_into(t, bufs)
+                env.rollout_into(T, bufs)
                 e1.record(stream)
-                events.append((e0, e1, t))
+                events.append((e0, e1))
             else:
-                env.rollout_into(t, bufs)
-            done += t
-            launches += 1
-        return launches
+                env.rollout_into(T, bufs)
+        return n_launches
 
     def run_step(env, n_ticks):
         for _ in range(n_ticks):
@@ -222,7 +252,8 @@ def main():
 
     used_packed = [False]
 
-    def measure(mode, obs_mode, K, W):
+    def measure(mode, obs_mode, K, W, ticks):
+        """W untimed + K timed bench steps.  fused: a step is one launch of `ticks` ticks; step / policy: one tick."""
         oc = obs_config(obs_mode) if mode == "fused" else None
         step_obs = obs_config(obs_mode) if mode == "step" else None
         if mode == "policy":
@@ -233,7 +264,7 @@ def main():
         if args.packed == 1 and mode == "fused" and obs_mode == "raw":
             assert packed, "this configuration has no packed record mode"
         used_packed[0] = packed if mode == "fused" and obs_mode == args.obs else used_packed[0]
-        bufs = env.alloc_rollout(args.ticks, obs=oc, packed=packed) if mode == "fused" else None
+        bufs = env.alloc_rollout(ticks, obs=oc, packed=packed) if mode == "fused" else None
         if mode == "policy":
             model = pkg.policy.reference_imposter_mlp(env, POLICY_COMPONENTS, seed=0)
             pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS)
@@ -242,77 +273,78 @@ def main():
                 pr.run(n)
                 return n
         else:
-            runner = (lambda n: run_fused(env, n, args.ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
-        per_launch_events = [] if mode == "fused" else None
+            runner = (lambda n: run_fused(env, n, ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
         runner(W)
         sync_all()
+        stream = torch.cuda.current_stream(device)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(torch.cuda.current_stream(device))
+        ev0.record(stream)
         launches = runner(K)
-        ev1.record(torch.cuda.current_stream(device))
+        ev1.record(stream)
         sync_all()
         dt = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1)
-        per_launch_us = None
-        if per_launch_events is not None:  # outside the timed region: 16 launches, each bracketed by its own event pair
-            run_fused(env, 16 * args.ticks, args.ticks, bufs, per_launch_events)
+        dev_ms = ev0.elapsed_time(ev1)  # HIP events around the timed region, on the launch stream
+        pair_us = None
+        if mode == "fused":  # cross-check OUTSIDE the timed region: 8 launches, each bracketed by its own event pair
+            pairs = []
+            run_fused(env, 8, ticks, bufs, pairs)
             torch.cuda.synchronize(device)
-            full = [a.elapsed_time(b) * 1e3 for a, b, t in per_launch_events if t == args.ticks]
-            per_launch_us = sum(full) / max(1, len(full))
+            pair_us = sum(a.elapsed_time(b) for a, b in pairs) * 1e3 / len(pairs)
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         env.poll_errors()
         metrics = pkg.dist.node_metrics(env)  # the ONE collective: all-gather of the episode totals
-        return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, env=env, per_launch_us=per_launch_us)
+        return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, pair_us=pair_us)
 
     K, W = args.steps, args.warmup
     if spec.get("policy"):
         args.mode, args.obs = "policy", "flat"
-        K, W = min(K, 1024), min(W, 64)
-    res = measure(args.mode, args.obs, K, W)
-    total_steps = B * world * K
+    ticks_per_step = args.ticks if args.mode == "fused" else 1
+    res = measure(args.mode, args.obs, K, W, args.ticks)
+    steps_per_launch = B * ticks_per_step          # env-steps one launch of the dominant kernel processes (this rank)
+    total_steps = steps_per_launch * world * K
     value = total_steps / res["seconds"]
-    # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration (HIP events)
-    steps_per_launch = B * (args.ticks if args.mode == "fused" else 1)
-    dominant_launches = res["launches"] if args.mode == "fused" else res["launches"] // 2
-    avg_launch_s = (res["device_ms"] / 1e3) / max(1, res["launches"] if args.mode == "fused" else dominant_launches)
-    if args.mode == "fused" and K % args.ticks:
-        avg_launch_s = (res["device_ms"] / 1e3) / (K / args.ticks)
-    launch_interval_us = avg_launch_s * 1e6  # timed region / launches (what the throughput is made of)
-    if args.mode == "fused" and res.get("per_launch_us"):
-        avg_launch_s = res["per_launch_us"] / 1e6  # mean of per-launch event pairs (what rocprofv3 reports per dispatch)
-    if args.mode == "policy":
-        avg_launch_s = (res["device_ms"] / 1e3) / K  # one k_step per tick; the tick also holds 5 GEMMs + glue
+    # roofline of the dominant kernel: algorithmic bytes per launch / its average duration over the TIMED region
+    # (HIP events on the launch stream around the K launches; fused: K back-to-back k_rollout launches and nothing else)
+    avg_launch_s = (res["device_ms"] / 1e3) / K
     b_alg = algorithmic_bytes_per_step(A, J, N, args.obs)
     b_stored = stored_bytes_per_step(A, J, N, args.obs)
     if used_packed[0]:
         b_stored = (b_stored + 3) // 4 * 4  # the packed record is padded to a multiple of 4 bytes
     achieved = steps_per_launch * b_alg / avg_launch_s / 1e9
     traffic, traffic_src = (None, None)
-    if args.mode == "fused" and args.config == "cfg2" and B == 65536 and args.ticks == 512 and world == 1:
-        traffic, traffic_src = profiled_traffic("void k_rollout", args.obs)
+    if args.mode == "fused" and B == spec["batch"] and args.ticks == 512 and world == 1:
+        traffic, traffic_src = profiled_traffic(args.config, args.obs)
     line = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": res["seconds"] * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": spec["workload"], "mode": args.mode, "obs": args.obs, "batch_per_gpu": B,
-                   "global_batch": B * world, "ticks_per_launch": args.ticks if args.mode == "fused" else 1,
+                   "global_batch": B * world, "ticks_per_launch": ticks_per_step,
+                   "step_definition": (f"one susnet_rollout launch = {ticks_per_step} lockstep ticks x {B} envs per GPU" if args.mode == "fused"
+                                       else "one lockstep tick (sample_actions + step)"),
+                   "env_steps_per_bench_step": steps_per_launch * world,
                    "trajectory_layout": "packed record per env-step" if used_packed[0] else "separate tensors",
                    "rng": "philox4x32-10 in-kernel", "auto_reset": True, "parallelism": f"dp{world}",
                    "agent_steps_per_s": value * A},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "stored_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "algorithmic_bytes_per_launch": steps_per_launch * b_alg, "stored_bytes_per_launch": steps_per_launch * b_stored,
             "kernel": "k_rollout" if args.mode == "fused" else "k_step<PhiloxRng>",
             "algorithmic_bytes_per_env_step": b_alg, "stored_bytes_per_env_step": b_stored,
             "achieved_stored_GBs": steps_per_launch * b_stored / avg_launch_s / 1e9,
-            "env_steps_per_launch": steps_per_launch, "avg_launch_us": avg_launch_s * 1e6, "launch_interval_us": launch_interval_us,
-            "note": "avg_launch_us = mean of HIP-event pairs around each launch of the timed region, on the launch stream; "
-                    "launch_interval_us = timed region / launches; rocprofv3 summaries in profiles/",
+            "env_steps_per_launch": steps_per_launch, "avg_launch_us": avg_launch_s * 1e6,
+            "avg_launch_us_event_pairs": res["pair_us"],
+            "note": "avg_launch_us = HIP-event time of the timed region (events on the launch stream around the K timed launches) / K: "
+                    "the launches `value` is made of; avg_launch_us_event_pairs = mean of 8 further launches bracketed one by one "
+                    "(cross-check, outside the timed region); frac = algorithmic bytes (SURVEY 8d) / avg_launch_us / 8 TB/s; "
+                    "traffic / stored_frac = PMC bytes (WRITE_SIZE + 2 x FETCH_SIZE) of the committed rocprofv3 pass of this command "
+                    "(profiles/), null when none matches",
         },
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
@@ -321,17 +353,18 @@ def main():
         line["roofline"].update(achieved=None, frac=None, kernel="k_step<PhiloxRng, Spec<3,4,..>> + hipBLASLt GEMMs",
                                 note="policy loop: per-tick time is dominated by the 5 fp32 GEMMs and host launch gaps, not by "
                                      "the env kernel; no single-kernel roofline is claimed for this config")
-        line["steps"], line["warmup"] = K, W
     if rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy":
         other = "step" if args.mode == "fused" else "fused"
-        r2 = measure(other, args.obs, 512 if other == "step" else 2048, 64)
-        k2 = 512 if other == "step" else 2048
-        line["secondary"] = {"mode": other, "value": B * k2 / r2["seconds"], "unit": "env-steps/s",
-                             "ms_per_step": r2["seconds"] * 1e3 / k2, "launches_per_step": 2 if other == "step" else 1.0 / args.ticks}
+        k2 = 512 if other == "step" else 8
+        r2 = measure(other, args.obs, k2, 64 if other == "step" else 2, args.ticks)
+        per2 = B * (1 if other == "step" else args.ticks)
+        line["secondary"] = {"mode": other, "value": per2 * k2 / r2["seconds"], "unit": "env-steps/s",
+                             "ms_per_tick": r2["seconds"] * 1e3 / (k2 * (1 if other == "step" else args.ticks)),
+                             "launches_per_tick": 2 if other == "step" else 1.0 / args.ticks}
         del r2
         if other == "step":
-            # the same two kernels per tick (+ the one-thread launch that advances the device-resident step counter, so
-            # that a replay draws fresh actions) captured as a hipGraph of 16 ticks and replayed
+            # the same two kernels per tick captured as a hipGraph of 16 ticks and replayed (the step counter of the
+            # action stream lives in device memory, so a replay draws fresh actions)
             env_g = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=obs_config(args.obs))
             env_g.reset()
             gt = 16
@@ -344,8 +377,8 @@ def main():
                 graph.replay()
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
-            line["secondary"]["hip_graph_replay"] = {"value": B * 4096 / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / 4096,
-                                                     "ticks_per_graph": gt, "nodes_per_tick": 3}
+            line["secondary"]["hip_graph_replay"] = {"value": B * 4096 / dt, "unit": "env-steps/s", "ms_per_tick": dt * 1e3 / 4096,
+                                                     "ticks_per_graph": gt, "nodes_per_tick": env_g.graph_nodes_per_tick()}
             del env_g, graph
     if rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy":
         # the same rollout with the reference's float32 feature layouts fused in (HBM-write bound)
@@ -353,20 +386,16 @@ def main():
         for om in ("flat", "planes"):
             if om == args.obs:
                 continue
-            k3 = 512
-            save_mode, save_ticks = args.mode, args.ticks
-            args.mode, args.ticks = "fused", min(args.ticks, 128)  # planes f32 at 128 ticks is already an 11 GB trajectory
-            r3 = measure("fused", om, k3, 128)
-            sweep_ticks = args.ticks
-            args.mode, args.ticks = save_mode, save_ticks
-            per_launch_s = (r3["per_launch_us"] / 1e6) if r3.get("per_launch_us") else (r3["device_ms"] / 1e3) / r3["launches"]
+            k3, t3 = 4, min(args.ticks, 128)  # planes f32 at 128 ticks is already an 11 GB trajectory
+            r3 = measure("fused", om, k3, 1, t3)
+            per_launch_s = (r3["device_ms"] / 1e3) / k3
             bs = stored_bytes_per_step(A, J, N, om)
             ba = algorithmic_bytes_per_step(A, J, N, om)
             line["obs_modes"].append({
-                "obs": om + ("(onehot_pos)" if om == "flat" else "") + " f32", "value": B * k3 / r3["seconds"], "unit": "env-steps/s",
+                "obs": om + ("(onehot_pos)" if om == "flat" else "") + " f32", "value": B * t3 * k3 / r3["seconds"], "unit": "env-steps/s",
                 "algorithmic_bytes_per_env_step": ba, "stored_bytes_per_env_step": bs,
-                "achieved_GBs": B * sweep_ticks * ba / per_launch_s / 1e9, "frac": B * sweep_ticks * ba / per_launch_s / 1e9 / HBM_PEAK_GBS,
-                "ticks_per_launch": sweep_ticks, "avg_launch_us": per_launch_s * 1e6})
+                "achieved_GBs": B * t3 * ba / per_launch_s / 1e9, "frac": B * t3 * ba / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                "ticks_per_launch": t3, "avg_launch_us": per_launch_s * 1e6})
             del r3
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(spec)

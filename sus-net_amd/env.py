@@ -703,6 +703,10 @@ class BatchedFourRoomEnv:
                 self.step(self.sample_actions())
         return graph
 
+    def graph_nodes_per_tick(self) -> int:
+        """Kernel nodes one captured drop-in tick holds (sample_actions + step + the step-counter bump)."""
+        return 3
+
     def rng_cursor(self) -> torch.Tensor:
         cur = torch.zeros(self.batch, dtype=torch.int64, device=self.device)
         view = L.StateView()

@@ -1,5 +1,5 @@
-"""Condense gpurun_out/prof/* (rocprofv3 CSV) into small tracked files under profiles/.
-usage: python tools/summarize_profiles.py r01"""
+"""Condense gpurun_out/prof/<config>/* (rocprofv3 CSV, tools/profile_gpu.sh) into small tracked files under profiles/.
+usage: python tools/summarize_profiles.py r02"""
 import collections
 import csv
 import glob
@@ -8,45 +8,75 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = "gpurun_out/prof"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = "gpurun_out/prof"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")
-if stats:
-    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
 summary = {}
-for d in sorted(glob.glob(f"{src}/pmc_*")):
-    if not os.path.isdir(d):
+for cdir in sorted(glob.glob(f"{root}/*")):
+    if not os.path.isdir(cdir):
         continue
-    name = os.path.basename(d)
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    dur = collections.defaultdict(list)
-    for f in glob.glob(f"{d}/*/*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][:80]
-            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    out = {}
-    for k, cs in agg.items():
-        if "rollout" not in k and "k_step" not in k and "k_sample" not in k:
+    cfg = os.path.basename(cdir)
+    stats = glob.glob(f"{cdir}/stats/*/*kernel_stats.csv")
+    if stats:
+        shutil.copy(stats[0], f"profiles/{tag}_{cfg}_kernel_stats.csv")
+    # the JSON line bench.py printed inside the profiled --stats run
+    log = f"{cdir}/stats.log"
+    if os.path.exists(log):
+        for ln in open(log, errors="replace"):
+            if ln.startswith('{"metric"'):
+                open(f"profiles/{tag}_{cfg}_bench_under_rocprofv3.json", "w").write(ln)
+    per = {}
+    for d in sorted(glob.glob(f"{cdir}/pmc_*")):
+        if not os.path.isdir(d):
             continue
-        out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in cs.items()}
-        out[k]["avg_duration_us"] = sum(dur[k]) / len(dur[k])
-    summary[name] = out
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        dur = collections.defaultdict(list)
+        for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0][:80]
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        out = {}
+        for k, cs in agg.items():
+            if "rollout" not in k and "k_step" not in k and "k_sample" not in k:
+                continue
+            out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in cs.items()}
+            # (every counter row of a dispatch repeats its timestamps: average over dispatches, not rows)
+            out[k]["avg_duration_us"] = sum(dur[k]) / len(dur[k])
+        per[os.path.basename(d)] = out
+    # derived per wave-tick figures of the fused rollout kernel (SQ_* cycle counters tick in quad-cycles)
+    try:
+        roll = lambda grp: next(v for k, v in per[grp].items() if k.startswith("void k_rollout"))
+        s1, s2 = roll("pmc_sq1"), roll("pmc_sq2")
+        waves = s1["SQ_WAVES"]["mean_per_launch"]
+        ticks = 512
+        wt = waves * ticks
+        wc = s1["SQ_WAVE_CYCLES"]["mean_per_launch"]
+        per["derived_per_wave_tick"] = {
+            "waves": waves, "ticks_per_launch": ticks,
+            "valu": s1["SQ_INSTS_VALU"]["mean_per_launch"] / wt, "salu": s1["SQ_INSTS_SALU"]["mean_per_launch"] / wt,
+            "lds": s1["SQ_INSTS_LDS"]["mean_per_launch"] / wt, "vmem_wr": s1["SQ_INSTS_VMEM_WR"]["mean_per_launch"] / wt,
+            "branch": s1["SQ_INSTS_BRANCH"]["mean_per_launch"] / wt, "cycles": 4.0 * wc / wt,
+            "share_active_inst_any": s2["SQ_ACTIVE_INST_ANY"]["mean_per_launch"] / wc,
+            "share_wait_any": s2["SQ_WAIT_ANY"]["mean_per_launch"] / wc,
+            "share_wait_inst_any": s2["SQ_WAIT_INST_ANY"]["mean_per_launch"] / wc,
+        }
+        w = roll("pmc_WRITE_SIZE")["WRITE_SIZE"]["mean_per_launch"]
+        f = roll("pmc_FETCH_SIZE")["FETCH_SIZE"]["mean_per_launch"]
+        per["traffic_bytes_per_launch"] = (w + 2.0 * f) * 1024.0
+    except (KeyError, StopIteration, ZeroDivisionError) as exc:
+        per["derived_error"] = repr(exc)
+    summary[cfg] = per
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
-print(json.dumps(summary, indent=1)[:3000])
-
-# bench.py reads `roofline.traffic` from the summary that was committed BEFORE the profiled run; the bench lines kept
-# next to this summary get the traffic of the SAME run (WRITE_SIZE + 2 x FETCH_SIZE, KiB -> bytes)
-try:
-    ksel = lambda grp, ctr: next(v[ctr]["mean_per_launch"] for k, v in summary[grp].items() if k.startswith("void k_rollout") and ", 2>" in k)
-    traffic = (ksel("pmc_WRITE_SIZE", "WRITE_SIZE") + 2.0 * ksel("pmc_FETCH_SIZE", "FETCH_SIZE")) * 1024.0
-    for name in (f"profiles/{tag}_bench_under_rocprofv3.json", f"profiles/{tag}_bench_unprofiled.json"):
-        if os.path.exists(name):
-            line = json.load(open(name))
-            line["roofline"]["traffic"] = traffic
-            line["roofline"]["traffic_source"] = f"{tag}_pmc_summary.json"
-            json.dump(line, open(name, "w"))
-    print("traffic per launch:", traffic)
-except (KeyError, StopIteration) as exc:
-    print("traffic not refreshed:", exc)
+for cfg, per in summary.items():
+    print(cfg, json.dumps(per.get("derived_per_wave_tick", per.get("derived_error"))), per.get("traffic_bytes_per_launch"))
+    # bench lines kept next to this summary get the traffic of the SAME profiling session
+    name = f"profiles/{tag}_{cfg}_bench_under_rocprofv3.json"
+    if os.path.exists(name) and per.get("traffic_bytes_per_launch"):
+        line = json.load(open(name))
+        t = per["traffic_bytes_per_launch"]
+        line["roofline"]["traffic"] = t
+        line["roofline"]["traffic_source"] = f"{tag}_pmc_summary.json"
+        if line["roofline"].get("avg_launch_us"):
+            line["roofline"]["stored_frac"] = t / (line["roofline"]["avg_launch_us"] * 1e-6) / 8e12
+        json.dump(line, open(name, "w"))
