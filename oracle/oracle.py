@@ -54,6 +54,7 @@ class SoEnv(C.Structure):
         ("used", C.c_int32 * MAX_AGENTS), ("counts", C.c_int32 * MAX_AGENTS), ("timer", C.c_int32),
         ("t", C.c_int32), ("n_role_actions", C.c_int32 * MAX_AGENTS), ("metrics", C.c_int64 * N_METRICS),
         ("rewards", C.c_double * MAX_AGENTS), ("order", C.c_int32 * MAX_AGENTS),
+        ("aw_W", C.c_int32), ("aw_tpw", C.c_int32), ("aw_word", C.c_uint8 * (2 * MAX_AGENTS)),
     ]
 
 

@@ -203,6 +203,40 @@ static void np_shuffle(so_env *e, int32_t *x, int n) {
  * ---------------------------------------------------------------------------------------------- */
 int so_sizeof_env(void) { return (int)sizeof(so_env); }
 
+/* PRODUCT protocol (not reference behaviour), restated so that the kernels can be checked bit for bit on the Philox
+ * stream: how a tick's bounded draws -- A action draws in agent order (base.py:326-330), then, with a shuffled action
+ * order, the A - 1 Fisher-Yates draws i = A-1 .. 1 of np.random.shuffle (base.py:372-374) -- are packed into 32-bit words
+ * of the ACTION stream.  Consecutive draws share a word by nested multiply-shift (digit = hi32(w * n), w = lo32(w * n):
+ * the mixed-radix digits of w * n1 * n2 .. / 2^32, joint bias <= n1 * n2 .. * 2^-32); a word is closed as soon as the
+ * product of the draws' LARGEST possible ranges (imposter action count; i + 1 for a shuffle draw) would pass 2^16, so
+ * the packing is static and the bias of any word stays below 2^-16.  A tick owns aw_W consecutive words (tick t: words
+ * t * aw_W ..), NOT rounded up to Philox blocks.  The 1v1 game (A == 2: ranges 6 and 5 whichever agent is the
+ * imposter, product 30) packs THREE ticks into a word (30^3 = 27000): tick t uses word t / 3 after t % 3 earlier ticks'
+ * worth of digits have been taken, i.e. starts from lo32(word * 30^(t % 3)). */
+#define SO_AW_CAP 65536u
+static int role_action_count(const so_env *e, int is_imp);
+static void so_action_layout(so_env *e) {
+    const int A = e->A;
+    const uint32_t R = (uint32_t)role_action_count(e, 1) + (e->cfg.variant == SO_VARIANT_TAGGING ? (uint32_t)(A - 1) : 0u);
+    int n = 0, word = 0;
+    uint32_t prod = 1;
+    for (int i = 0; i < A; i++) {
+        if (prod * R > SO_AW_CAP) { word++; prod = 1; }
+        prod *= R;
+        e->aw_word[n++] = (uint8_t)word;
+    }
+    if (e->cfg.is_action_order_random)
+        for (int i = A - 1; i >= 1; i--) {
+            uint32_t radix = (uint32_t)i + 1u;
+            if (prod * radix > SO_AW_CAP) { word++; prod = 1; }
+            prod *= radix;
+            e->aw_word[n++] = (uint8_t)word;
+        }
+    e->aw_W = word + 1;
+    e->aw_tpw = 1;
+    if (A == 2) { e->aw_W = 1; e->aw_tpw = 3; }
+}
+
 int so_env_init(so_env *e, const so_config *cfg) {
     memset(e, 0, sizeof(*e));
     e->cfg = *cfg;
@@ -233,6 +267,7 @@ int so_env_init(so_env *e, const so_config *cfg) {
                 e->n_valid++;
             }
     if (e->n_valid < e->J || e->n_valid < 1) return SO_ERR_CONFIG;
+    so_action_layout(e);
     so_seed_mt(e, 0);
     return SO_OK;
 }
@@ -340,48 +375,31 @@ void so_reset(so_env *e) {
     }
 }
 
-/* production action stream, layout of a tick's words for A > 2 (the 1v1 game uses one word per tick):
- *   s = 1 if the action order is shuffled (one more word carries the step's permutation), else 0;
- *   A + s <= 4: word i serves agent i, word A the permutation;
- *   otherwise agents are packed FOUR per word by nested multiply-shift (word k serves agents 4k .. 4k+3 in index order),
- *   the permutation word follows the ceil(A / 4) action words.  Everything is rounded up to whole Philox blocks. */
-static int so_action_packed(const so_env *e) { return e->A + (e->cfg.is_action_order_random ? 1 : 0) > 4; }
-static int so_action_words(const so_env *e) { return so_action_packed(e) ? (e->A + 3) / 4 : e->A; }
-static uint64_t so_action_words_per_tick(const so_env *e) {
-    if (e->A <= 2) return 1u;
-    return (uint64_t)((so_action_words(e) + (e->cfg.is_action_order_random ? 1 : 0) + 3) & ~3);
+/* base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order */
+/* word `index` of the production ACTION stream */
+static uint32_t action_word(const so_env *e, uint64_t index) {
+    return philox_word_tagged(e->rng.seed, e->rng.env_id, index, SO_ACTION_STREAM_TAG);
 }
 
-/* base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order */
 void so_sample_actions(so_env *e, int32_t *actions) {
     if (e->rng.kind == SO_RNG_PHILOX) {
-        /* production protocol: agent i's action at step `tick` is word tick * W + i of the action stream; sampling
-         * does not advance anything (the step does), so repeated calls before a step return the same actions */
-        /* a tick owns W words of the action stream (so_action_words_per_tick).  A <= 2: W = 1, one word serves both
-         * agents by nested multiply-shift (p = w * n0: agent 0 = hi32(p), agent 1 = hi32(lo32(p) * n1)).  A > 2: see the
-         * layout comment above; with a shuffled action order one more word carries the step's permutation (so_step). */
-        if (e->A <= 2) {
-            uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick, SO_ACTION_STREAM_TAG);
+        /* production protocol (so_action_layout): the actions of step `tick` are digits of the tick's action-stream words;
+         * sampling does not advance anything (the step does), so repeated calls before a step return the same actions */
+        if (e->A == 2) {
+            uint32_t w = action_word(e, e->rng.tick / 3u);
+            for (uint64_t s = 0; s < e->rng.tick % 3u; s++) w *= 30u; /* digits of the earlier ticks in this word */
             uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, 0);
             actions[0] = (int)(p >> 32);
-            if (e->A == 2) actions[1] = (int)(((uint64_t)(uint32_t)p * (uint64_t)(uint32_t)so_n_actions(e, 1)) >> 32);
+            actions[1] = (int)(((uint64_t)(uint32_t)p * (uint64_t)(uint32_t)so_n_actions(e, 1)) >> 32);
             return;
         }
-        const uint64_t W = so_action_words_per_tick(e);
-        if (!so_action_packed(e)) {
-            for (int i = 0; i < e->A; i++) {
-                uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * W + (uint64_t)i, SO_ACTION_STREAM_TAG);
-                actions[i] = (int)(((uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i)) >> 32);
-            }
-        } else {
-            uint32_t w = 0;
-            for (int i = 0; i < e->A; i++) {
-                if ((i & 3) == 0)
-                    w = philox_word_tagged(e->rng.seed, e->rng.env_id, e->rng.tick * W + (uint64_t)(i >> 2), SO_ACTION_STREAM_TAG);
-                uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i);
-                actions[i] = (int)(p >> 32);
-                w = (uint32_t)p;
-            }
+        uint32_t w = 0;
+        for (int i = 0; i < e->A; i++) {
+            if (i == 0 || e->aw_word[i] != e->aw_word[i - 1])
+                w = action_word(e, e->rng.tick * (uint64_t)e->aw_W + e->aw_word[i]);
+            uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)so_n_actions(e, i);
+            actions[i] = (int)(p >> 32);
+            w = (uint32_t)p;
         }
         return;
     }
@@ -514,12 +532,18 @@ int so_step(so_env *e, const int32_t *actions, double *rewards, int32_t *done_ou
     draw_align(e);
     if (e->cfg.is_action_order_random) { /* base.py:372-374: np.random.shuffle(agent order) */
         if (e->rng.kind == SO_RNG_PHILOX) {
-            /* production protocol: the whole permutation comes from ONE word of the action stream (the word after this
-             * tick's action words), the Fisher-Yates draws i = A-1 .. 1 being its successive mixed-radix digits (nested
-             * multiply-shift: j = hi32(w * (i + 1)), w = lo32(w * (i + 1)); joint bias <= A! * 2^-32) */
-            uint32_t w = philox_word_tagged(e->rng.seed, e->rng.env_id,
-                                            e->rng.tick * so_action_words_per_tick(e) + (uint64_t)so_action_words(e), SO_ACTION_STREAM_TAG);
-            for (int i = A - 1; i >= 1; i--) {
+            /* production protocol (so_action_layout): the Fisher-Yates draws i = A-1 .. 1 are the digits that FOLLOW the
+             * tick's action draws in its action-stream words; a draw that shares a word with action draws continues from
+             * what those left, lo32(word * product of their ranges) */
+            uint32_t w = 0;
+            for (int i = A - 1, d = A; i >= 1; i--, d++) {
+                if (e->aw_word[d] != e->aw_word[d - 1]) {
+                    w = action_word(e, e->rng.tick * (uint64_t)e->aw_W + e->aw_word[d]);
+                } else if (d == A) {
+                    w = action_word(e, e->rng.tick * (uint64_t)e->aw_W + e->aw_word[d]);
+                    for (int q = 0; q < A; q++)
+                        if (e->aw_word[q] == e->aw_word[d]) w *= (uint32_t)so_n_actions(e, q);
+                }
                 uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(i + 1);
                 int j = (int)(p >> 32);
                 w = (uint32_t)p;

@@ -102,6 +102,10 @@ typedef struct so_env {
     int64_t metrics[SO_N_METRICS];
     double rewards[SO_MAX_AGENTS];
     int32_t order[SO_MAX_AGENTS];                /* order used by the last step */
+    /* production (Philox) action stream: static packing of a tick's bounded draws into 32-bit words (so_action_layout) */
+    int32_t aw_W;                                /* words a tick owns (A == 2: one word serves aw_tpw ticks) */
+    int32_t aw_tpw;                              /* ticks per word: 3 for the 1v1 game, else 1 */
+    uint8_t aw_word[2 * SO_MAX_AGENTS];          /* draw d (A action draws, then the A - 1 shuffle draws) -> word of the tick */
 } so_env;
 
 /* return codes of so_step */

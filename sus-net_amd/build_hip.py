@@ -1,16 +1,29 @@
-"""Compile sus-net_amd/csrc/susnet_capi.hip -> sus-net_amd/libsusnet_hip.so for gfx950 (in-tree)."""
+"""Compile sus-net_amd/csrc/*.hip -> sus-net_amd/libsusnet_hip.so for gfx950 (in-tree).
+
+One object per translation unit (susnet_capi.hip = host side + the small kernels; inst_*.hip = one compiled-in
+configuration of the stepping kernels each), compiled in parallel, then linked into ONE shared library."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG_DIR, "csrc", "susnet_capi.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "susnet_device.h"), os.path.join(PKG_DIR, "csrc", "susnet_obs.h"),
-        os.path.join(os.path.dirname(PKG_DIR), "include", "susnet.h")]
+CSRC = os.path.join(PKG_DIR, "csrc")
+OBJ_DIR = os.path.join(PKG_DIR, "_obj")
 OUT = os.path.join(PKG_DIR, "libsusnet_hip.so")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-pass-failed"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(PKG_DIR), "include", "susnet.h")]
 
 
 def hipcc() -> str:
@@ -20,14 +33,34 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in DEPS):
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    srcs, hdrs = sources(), headers()
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = hipcc()
+    todo, objs = [], []
+    for src in srcs:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            todo.append((src, obj))
+    for stale in set(glob.glob(os.path.join(OBJ_DIR, "*.o"))) - set(objs):
+        os.remove(stale)
+    if not todo and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(o) for o in objs):
         return OUT
-    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-pass-failed", "-o", OUT, SRC]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [cc, *FLAGS, "-c", "-o", obj, src]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    jobs = jobs or int(os.environ.get("SUSNET_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(compile_one, todo))
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
     return OUT
 
 

@@ -11,71 +11,17 @@
 #include <string>
 #include <type_traits>
 
-#include "susnet_device.h"
-#include "susnet_obs.h"
+#include "susnet_kernels.h"
 
+namespace susnet {
+SUSNET_DECLARE(GenericSpec) SUSNET_DECLARE(SpecCfg2) SUSNET_DECLARE(SpecCfg3) SUSNET_DECLARE(SpecCfg4) SUSNET_DECLARE(SpecTag5)
+SUSNET_DECLARE(SpecA<2>) SUSNET_DECLARE(SpecA<3>) SUSNET_DECLARE(SpecA<4>) SUSNET_DECLARE(SpecA<5>) SUSNET_DECLARE(SpecA<6>) SUSNET_DECLARE(SpecA<7>) SUSNET_DECLARE(SpecA<8>)
+} // namespace susnet
 using namespace susnet;
 
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
-struct StepArgs {
-    const void *actions;
-    int32_t act_dtype;
-    int64_t act_sa, act_sb; // element strides (agent, env)
-    RewardSink rewards;
-    uint8_t *done, *trunc;
-    uint64_t tick; // steps taken so far (index of the action stream: the shuffled order of this step comes from it)
-};
-
-struct RolloutArgs {
-    int32_t n_ticks;
-    uint64_t tick_base; // steps this handle has taken before the launch (index of the action stream)
-    uint8_t *actions; // [T][B][A]
-    float *rewards;   // [T][B][A]
-    uint8_t *done, *trunc; // [T][B]
-    uint8_t *record;       // packed mode: [T][B][record_bytes]
-    int32_t record_bytes;
-};
-
-template <class RNG>
-__device__ __forceinline__ RNG make_rng(const Consts &c, const State &s, int64_t b);
-
-template <>
-__device__ __forceinline__ PhiloxRng make_rng<PhiloxRng>(const Consts &c, const State &s, int64_t b) {
-    PhiloxRng r;
-    r.init(c.seed, c.env_id_base + (uint64_t)b, s.rng[b]);
-    return r;
-}
-template <>
-__device__ __forceinline__ TapeRng make_rng<TapeRng>(const Consts &c, const State &s, int64_t b) {
-    TapeRng r;
-    r.init(s.tape ? s.tape + b * s.tape_len : nullptr, s.tape ? s.tape_len : 0, s.rng[b]);
-    return r;
-}
-
-__device__ __forceinline__ uint32_t load_action(const void *p, int dtype, int64_t k) {
-    int64_t v;
-    if (dtype == SUSNET_U8) v = reinterpret_cast<const uint8_t *>(p)[k];
-    else if (dtype == SUSNET_I32) v = reinterpret_cast<const int32_t *>(p)[k];
-    else v = reinterpret_cast<const int64_t *>(p)[k];
-    if (v < 0) v = -1;
-    if (v > 0x7ffffff0ll) v = 0x7ffffff0ll;
-    return (uint32_t)(int32_t)v;
-}
-
-__device__ __forceinline__ void store_action(void *p, int dtype, int64_t k, uint32_t a) {
-    if (dtype == SUSNET_U8) reinterpret_cast<uint8_t *>(p)[k] = (uint8_t)a;
-    else if (dtype == SUSNET_I32) reinterpret_cast<int32_t *>(p)[k] = (int32_t)a;
-    else reinterpret_cast<int64_t *>(p)[k] = (int64_t)a;
-}
-
-template <class RNG>
-__device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG &rng) {
-    s.rng[b] = rng.cur;
-    if (rng.ovf) atomicOr(s.err, SUSNET_ERRBIT_TAPE);
-}
-
 template <class RNG>
 __global__ __launch_bounds__(kBlock) void k_reset(Consts c, State s, const uint8_t *mask, ObsArgs o) {
     using S = GenericSpec;
@@ -122,282 +68,9 @@ __global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out,
     finish_rng(s, b, rng);
 }
 
-template <class RNG, class S>
-__global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, ObsArgs o) {
-    extern __shared__ uint32_t smem[];
-    const int tid = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
-    const bool active = b < c.B;
-    typename StoreFor<S>::type st;
-    Tables T = setup_lds<S>(c, smem, tid, st);
-    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
-    wave_lds_fence();
-    Env e = {};
-    if (active) {
-        const int A = S::A(c);
-        load_env<S>(c, s, st, b, e);
-#pragma unroll
-        for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
-        RNG rng = make_rng<RNG>(c, s, b);
-        bool done, trunc;
-        uint32_t ow = 0;
-        if constexpr (!RNG::kNumpy) {
-            if (S::order_random(c)) {
-                ActionStream as;
-                as.init();
-                ow = order_word<S>(c, rng, as, c.dev_tick ? *s.dev_tick : a.tick, false);
-            }
-        }
-        uint32_t bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc, nullptr, ow);
-        if (bits) atomicOr(s.err, bits);
-        if (a.done) a.done[b] = done ? 1 : 0;
-        if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
-        bool jobs_changed = false;
-        if (__builtin_expect(c.auto_reset && (done || trunc), 0)) {
-            accumulate_lifetime(c, s, b, e, trunc);
-            reset_env<S>(c, T, st, tid, e, rng);
-            e.flags |= FLAG_FRESH; // info counters stay readable until the next step
-            jobs_changed = true;
-        }
-        store_env<S>(c, s, st, b, e, jobs_changed);
-        finish_rng(s, b, rng);
-    }
-    int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
-    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
-}
-
 // Device-resident step counter (susnet_device_tick): advanced by its own one-thread launch AFTER the kernel(s) that read
 // it, so that no workgroup can ever observe a half-advanced tick -- no atomics or fences on the stepping kernels.
 __global__ void k_bump_tick(uint64_t *tick, uint64_t n) { *tick += n; }
-
-// Fused random rollout: n_ticks x {sample_actions; step; auto-reset} with the state held on chip.
-// OUT selects what a tick stores, at compile time (run-time optional outputs cost uniform branches on a path
-// that is instruction-fetch bound): OUT_ANY = whatever pointers are non-null / any observation mode;
-// OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
-// uint8 observation (the populate()-shaped record)
-enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4 };
-// OUT_TRAJ = OUT_TRAJ_RAW8 without an observation; OUT_RECORD = the OUT_TRAJ_RAW8 fields packed into ONE record per
-// env-step (rewards f32[A] | actions u8[A] | done | truncated | raw obs u8[F], padded to a dword): a lane stores its
-// record with one or two wide stores through a single buffer descriptor instead of six stores through five
-template <class S>
-struct RecordLayout {
-    static constexpr int kBytesTail = (S::kA > 0 ? S::kA : 0) + 2 + (S::kRawF > 0 ? S::kRawF : 0);
-    static constexpr int kDwords = (S::kA > 0 ? S::kA : 0) + (kBytesTail + 3) / 4;
-};
-template <class S, int OUT>
-__global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
-    extern __shared__ uint32_t smem[];
-    const int tid = threadIdx.x;
-    // XCD-aware wave -> environment-block mapping: workgroup ids are dealt round-robin to the 8 XCDs, each with its
-    // own L2.  Consecutive env blocks write adjacent pieces of the same 128-byte lines (a wave's 64 done flags are
-    // half a line), so they are given to workgroups of the SAME XCD, dispatched back to back: the halves meet in one
-    // L2 instead of leaving two XCDs as partial-line write-backs.
-    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t per = nblk >> 3, rem = nblk & 7u;
-    const uint32_t wave_id = xcd * per + (xcd < rem ? xcd : rem) + slot;
-    const int64_t b0 = (int64_t)wave_id * c.epw, b = b0 + tid;
-    const bool active = tid < c.epw && b < c.B;
-    const int nrows = (int)((c.B - b0) < c.epw ? (c.B - b0) : c.epw);
-    const int A = S::A(c);
-    typename StoreFor<S>::type st;
-    Tables T = setup_lds<S>(c, smem, tid, st);
-    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
-    wave_lds_fence();
-    Env e = {};
-    PhiloxRng rng;
-    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
-    ActionStream as;
-    as.init();
-    if (active) {
-        load_env<S>(c, s, st, b, e);
-        rng.cur = s.rng[b];
-    }
-    // trajectory mode with register-direct observation rows has no cooperative (all-lane) work past this point:
-    // idle lanes of a ragged last wave leave, and the tick loop runs without per-block exec masking
-    if (((OUT == OUT_TRAJ_RAW8 && S::kRawF > 0) || OUT == OUT_TRAJ || OUT == OUT_RECORD) && !active) return;
-    // the step counter of the action stream: a kernel argument, or (graph-replayable launches) a device word that the
-    // last workgroup to finish advances; either way wave-uniform, in scalar registers
-    uint64_t tick_base = a.tick_base;
-    if (c.dev_tick) {
-        const uint64_t t = *s.dev_tick;
-        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
-    }
-    LifeAcc life;
-    life.clear();
-    const int64_t AB = (int64_t)A * c.B;
-    // per-lane output cursors, bumped once per tick (no 64-bit index arithmetic per store)
-    const int64_t bb = active ? b : 0;
-    uint8_t *pa = a.actions ? a.actions + bb * A : nullptr; // env-major rows: one lane writes its A values with wide stores
-    float *pr = a.rewards ? a.rewards + bb * A : nullptr;
-    uint8_t *pd = a.done ? a.done + bb : nullptr;
-    uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
-    constexpr int kRawF = S::kRawF;
-    // compiled-in configurations write their raw uint8 row straight from registers (a few 4-byte stores per lane:
-    // the 64 rows of a wave are contiguous, so every touched line is fully written within the tick); measured
-    // faster than the LDS image + 16-byte copy-out, also when that copy-out was software-pipelined across ticks
-    constexpr bool kDirect = (OUT == OUT_TRAJ_RAW8) && S::kRawF > 0;
-    // OUT_TRAJ_RAW8: every output goes through a buffer descriptor (wave-uniform base and size, hardware range
-    // check) with a fixed per-lane byte offset and the tick's slab offset in a scalar register, so a store costs no
-    // vector address arithmetic and a tick advances five scalar offsets.  The host only selects this mode when
-    // every output array of the launch is below 2 GiB.
-    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
-    const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
-    BufDst da = make_buf_dst(a.actions, nt * (uint64_t)AB, (uint32_t)(bb * A));
-    BufDst dr = make_buf_dst(a.rewards, nt * (uint64_t)AB * 4u, (uint32_t)(bb * A) * 4u);
-    BufDst dd = make_buf_dst(a.done, nt * (uint64_t)c.B, (uint32_t)bb);
-    BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
-    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * (kRawF > 0 ? kRawF : 0)));
-    const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
-    constexpr bool kRec = OUT == OUT_RECORD; // (host: compiled-in configurations with a static raw row only)
-    constexpr int kRecDwords = RecordLayout<S>::kDwords > 0 ? RecordLayout<S>::kDwords : 1;
-    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
-    const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
-    if (kTraj) { pa = nullptr; pr = nullptr; pd = nullptr; pt = nullptr; }
-#ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    unsigned long long seg2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define STAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); seg[k] += tn - tprev; tprev = tn; } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-    if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
-    // one tick; PAR = compile-time position of the absolute tick in its 4-tick action-stream block, or -1 = run time
-    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par)::value;
-#ifdef SUSNET_STAMPS
-        tprev = __builtin_readcyclecounter();
-#endif
-        STAMP(0);
-        if (active) {
-            sample_actions_env<S, PAR>(c, st, e, rng, as, tick_base + (uint64_t)tick, tick == 0);
-            // shuffled order: the tick's permutation word sits next to its action words (usually in the block just used)
-            const uint32_t ow = S::order_random(c) ? order_word<S>(c, rng, as, tick_base + (uint64_t)tick, true) : 0u;
-            STAMP(1);
-            uint32_t av[S::kA > 0 ? S::kA : 1];
-            float rr[S::kA > 0 ? S::kA : 1];
-            if (kRec) {
-#pragma unroll
-                for (int i = 0; i < (S::kA > 0 ? S::kA : 0); i++) av[i] = st.act(i);
-            } else if (kTraj || (OUT == OUT_ANY && pa != nullptr)) {
-                if (!S::kGeneric) {
-#pragma unroll
-                    for (int i = 0; i < A; i++) av[i] = st.act(i);
-                    if (kTraj) store_row_u8<(S::kA > 0 ? S::kA : 1)>(da, av);
-                    else store_row_u8<(S::kA > 0 ? S::kA : 1)>(PtrDst{pa}, av);
-                } else if (kTraj) {
-                    for (int i = 0; i < A; i++) da.st8((uint32_t)i, st.act(i));
-                } else {
-                    for (int i = 0; i < A; i++) pa[i] = (uint8_t)st.act(i);
-                }
-            }
-            STAMP(2);
-            RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr, rr};
-            bool done, trunc;
-#ifdef SUSNET_STAMPS
-            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
-            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
-            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
-#else
-            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
-            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
-            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
-#endif
-            STAMP(3);
-            if (kTraj) {
-                dd.st8(0u, done ? 1u : 0u);
-                dt.st8(0u, trunc ? 1u : 0u);
-            } else if (OUT == OUT_ANY) {
-                if (pd != nullptr) *pd = done ? 1 : 0;
-                if (pt != nullptr) *pt = trunc ? 1 : 0;
-            }
-            STAMP(4);
-            if (__builtin_expect(done || trunc, 0)) {
-                life.add_episode(e, trunc);
-                reset_env<S>(c, T, st, tid, e, rng);
-                // info counters of a terminal step stay readable until the next step: only the launch's last
-                // tick can be observed, every other episode end zeroes them right away (wave-uniform branch)
-                if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
-                else zero_metrics(e);
-            }
-            STAMP(5);
-            if (kRec) { // one packed record per env-step: rewards | actions | done | truncated | raw observation
-                constexpr int kA = S::kA > 0 ? S::kA : 0, kF = kRawF > 0 ? kRawF : 0, kNB = kA + 2 + kF;
-                uint8_t row[kF + 4];
-                fill_raw<S>(c, st, e, row);
-                uint32_t by[(kNB + 3) / 4 * 4];
-#pragma unroll
-                for (int k = 0; k < kA; k++) by[k] = av[k] & 0xffu;
-                by[kA] = done ? 1u : 0u;
-                by[kA + 1] = trunc ? 1u : 0u;
-#pragma unroll
-                for (int f = 0; f < kF; f++) by[kA + 2 + f] = row[f];
-#pragma unroll
-                for (int k = kNB; k < (kNB + 3) / 4 * 4; k++) by[k] = 0u;
-                uint32_t w[kRecDwords];
-#pragma unroll
-                for (int i = 0; i < kA; i++) w[i] = __float_as_uint(rr[i]);
-#pragma unroll
-                for (int k = 0; k < (kNB + 3) / 4; k++)
-                    w[kA + k] = by[4 * k] | (by[4 * k + 1] << 8) | (by[4 * k + 2] << 16) | (by[4 * k + 3] << 24);
-                store_dwords<kRecDwords>(drec, w);
-            }
-            if (OUT == OUT_ANY) {
-                pa = pa ? pa + AB : pa;
-                pr = pr ? pr + AB : pr;
-                pd = pd ? pd + c.B : pd;
-                pt = pt ? pt + c.B : pt;
-            }
-        }
-        if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        if (OUT == OUT_TRAJ_RAW8 && !kDirect) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        if (kDirect) {
-            if (active) {
-                uint8_t row[(kRawF > 0 ? kRawF : 1) + 4];
-                fill_raw<S>(c, st, e, row);
-                // 4-byte stores (naturally aligned when F % 4 == 0, otherwise the hardware's unaligned
-                // access splits them), then a 2-byte and a 1-byte tail
-                uint32_t rv[(kRawF > 0 ? kRawF : 1)];
-#pragma unroll
-                for (int k = 0; k < kRawF; k++) rv[k] = row[k];
-                store_row_u8<(kRawF > 0 ? kRawF : 1)>(dobs, rv);
-            }
-        }
-        if (kTraj) { // wave-uniform: next tick's slabs
-            da.so += slab_a; dr.so += 4u * slab_a; dd.so += slab_d; dt.so += slab_d; dobs.so += slab_o;
-        }
-        if (kRec) drec.so += slab_rec;
-        STAMP(6);
-    };
-    // 1v1 trajectory kernels: a Philox block of the action stream serves four consecutive ticks (one word each), so
-    // the loop runs block-wise with the word selection static and one generation per block; ticks before the first
-    // block boundary of a launch and after its last full block run through the run-time flavour
-    constexpr bool kQuads = (kTraj || kRec) && !S::kGeneric && S::kA == 2;
-    int tick = 0;
-    while (tick < a.n_ticks) {
-        if (kQuads && ((tick_base + (uint64_t)tick) & 3ull) == 0ull && tick + 3 < a.n_ticks) {
-            tick_body(tick, std::integral_constant<int, 0>{});
-            tick_body(tick + 1, std::integral_constant<int, 1>{});
-            tick_body(tick + 2, std::integral_constant<int, 2>{});
-            tick_body(tick + 3, std::integral_constant<int, 3>{});
-            tick += 4;
-        } else {
-            tick_body(tick, std::integral_constant<int, -1>{});
-            tick++;
-        }
-    }
-#ifdef SUSNET_STAMPS
-    if (blockIdx.x == 100 && tid == 0)
-        for (int k = 0; k < 8; k++) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 2 + k, seg[k]);
-            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 10 + k, seg2[k]);
-        }
-#endif
-    if (active) {
-        store_env<S>(c, s, st, b, e, true);
-        s.rng[b] = rng.cur;
-        life.flush(c, s, b);
-    }
-}
 
 __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o) {
     using S = GenericSpec;
@@ -472,17 +145,10 @@ __global__ __launch_bounds__(kBlock) void k_featurize(Consts c, const void *rows
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
 
-// configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
-using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>; // ImposterTrainingGround 1v1, no jobs, fixed order, imposter = agent 0 (any wall map)
-using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
-using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
-using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
-// agent count compiled in, everything else read at run time (any variant / order / up to 8 jobs): the packed-VGPR
-// tables without a full specialisation
-template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
-
 static int pick_spec(const Consts &c, bool float_exact) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
+    if (const char *ev = getenv("SUSNET_FORCE_GENERIC")) // tests: the same fixtures through the generic LDS-table kernels
+        if (ev[0] == '1') return 0;
     if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG && !c.order_random && !c.shuffle_imp && c.n_imp == 1) return 2;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
@@ -675,6 +341,11 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     }
     c.nr_imp = cfg->variant == SUSNET_VARIANT_ITG ? 6 : 7;  // pred_prey.py:12-19 / base.py:91-99
     c.nr_crew = cfg->variant == SUSNET_VARIANT_ITG ? 5 : 6; // pred_prey.py:4-10  / base.py:82-89
+    { // action-stream word layout of the production protocol (same function the compiled-in kernels evaluate statically)
+        const AwLayout L = make_aw_layout(A, (uint32_t)c.nr_imp + (cfg->variant == SUSNET_VARIANT_TAGGING ? (uint32_t)(A - 1) : 0u), order_random != 0);
+        c.aw_W = L.W;
+        for (int d = 0; d < 32; d++) c.aw_word[d] = L.word[d];
+    }
     c.n_valid = 0;
     for (int i = 0; i < N; i++) {
         c.grid_rows[i] = cfg->grid_rows[i] & ((1u << N) - 1u);
@@ -949,29 +620,31 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c, env->float_exact) : 0;
+    // the compiled-in kernels also serve TAPE handles (numpy parity mode): the reference's golden traces run through the
+    // same code the production stream uses
+    const bool tape = env->cfg.rng_mode == SUSNET_RNG_TAPE;
+    const int spec = pick_spec(env->c, env->float_exact);
     size_t sh = lds_bytes(env, o, env->c.auto_reset != 0, spec == 0);
     CHECK_LDS(sh);
     const dim3 g = grid_for(env), blk(kBlock);
-    if (env->cfg.rng_mode == SUSNET_RNG_TAPE) hipLaunchKernelGGL((k_step<TapeRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
-    else if (spec == 2) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg2>), g, blk, sh, st, env->c, env->s, a, o);
-    else if (spec == 3) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg3>), g, blk, sh, st, env->c, env->s, a, o);
-    else if (spec == 4) hipLaunchKernelGGL((k_step<PhiloxRng, SpecCfg4>), g, blk, sh, st, env->c, env->s, a, o);
-    else if (spec == 6) hipLaunchKernelGGL((k_step<PhiloxRng, SpecTag5>), g, blk, sh, st, env->c, env->s, a, o);
-#define STEP_A(N) else if (spec == 10 + N) hipLaunchKernelGGL((k_step<PhiloxRng, SpecA<N>>), g, blk, sh, st, env->c, env->s, a, o);
-    STEP_A(2) STEP_A(3) STEP_A(4) STEP_A(5) STEP_A(6) STEP_A(7) STEP_A(8)
-#undef STEP_A
-    else hipLaunchKernelGGL((k_step<PhiloxRng, GenericSpec>), g, blk, sh, st, env->c, env->s, a, o);
+    switch (spec) {
+    case 2: launch_step<SpecCfg2>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 3: launch_step<SpecCfg3>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 4: launch_step<SpecCfg4>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 6: launch_step<SpecTag5>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 12: launch_step<SpecA<2>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 13: launch_step<SpecA<3>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 14: launch_step<SpecA<4>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 15: launch_step<SpecA<5>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 16: launch_step<SpecA<6>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 17: launch_step<SpecA<7>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    case 18: launch_step<SpecA<8>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    default: launch_step<GenericSpec>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
+    }
     if (env->c.dev_tick) hipLaunchKernelGGL(k_bump_tick, dim3(1), dim3(1), 0, st, env->s.dev_tick, (uint64_t)1);
     HIP_TRY(hipGetLastError());
     env->ticks += 1;
     return SUSNET_OK;
-}
-
-// the packed record exists for configurations whose whole raw row is known at compile time
-template <class SPEC>
-static void launch_record(dim3 g, dim3 blk, size_t sh, hipStream_t st, susnet_env *env, const RolloutArgs &a, const ObsArgs &o) {
-    if constexpr (!SPEC::kGeneric && SPEC::kRawF > 0) hipLaunchKernelGGL((k_rollout<SPEC, OUT_RECORD>), g, blk, sh, st, env->c, env->s, a, o);
 }
 
 extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out) {
@@ -1039,17 +712,6 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
                                                             : OUT_ANY;
     const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
-#define LAUNCH_ROLLOUT(SPEC)                                                                                       \
-    do {                                                                                                           \
-        if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, env->c, env->s, a, o); \
-        else if (out == OUT_TRAJ_RAW8)                                                                             \
-            hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, env->c, env->s, a, o);            \
-        else if (out == OUT_TRAJ)                                                                                  \
-            hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, env->c, env->s, a, o);                 \
-        else if (out == OUT_RECORD)                                                                                \
-            launch_record<SPEC>(g, blk, sh, st, env, a, o);                                                        \
-        else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, env->c, env->s, a, o);                 \
-    } while (0)
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);
         a.tick_base = env->ticks + (uint64_t)t0;
@@ -1061,18 +723,23 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             a.trunc += (uint64_t)chunk * (uint64_t)env->c.B;
             if (o.out) o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (uint64_t)o.tick_stride;
         }
-        if (spec == 2) LAUNCH_ROLLOUT(SpecCfg2);
-        else if (spec == 3) LAUNCH_ROLLOUT(SpecCfg3);
-        else if (spec == 4) LAUNCH_ROLLOUT(SpecCfg4);
-        else if (spec == 6) LAUNCH_ROLLOUT(SpecTag5);
-#define ROLL_A(N) else if (spec == 10 + N) LAUNCH_ROLLOUT(SpecA<N>);
-        ROLL_A(2) ROLL_A(3) ROLL_A(4) ROLL_A(5) ROLL_A(6) ROLL_A(7) ROLL_A(8)
-#undef ROLL_A
-        else LAUNCH_ROLLOUT(GenericSpec);
+        switch (spec) {
+        case 2: launch_rollout<SpecCfg2>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 3: launch_rollout<SpecCfg3>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 4: launch_rollout<SpecCfg4>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 6: launch_rollout<SpecTag5>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 12: launch_rollout<SpecA<2>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 13: launch_rollout<SpecA<3>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 14: launch_rollout<SpecA<4>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 15: launch_rollout<SpecA<5>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 16: launch_rollout<SpecA<6>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 17: launch_rollout<SpecA<7>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 18: launch_rollout<SpecA<8>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        default: launch_rollout<GenericSpec>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        }
         if (env->c.dev_tick) hipLaunchKernelGGL(k_bump_tick, dim3(1), dim3(1), 0, st, env->s.dev_tick, (uint64_t)a.n_ticks);
         HIP_TRY(hipGetLastError());
     }
-#undef LAUNCH_ROLLOUT
     env->ticks += (uint64_t)io->n_ticks;
     return SUSNET_OK;
 }

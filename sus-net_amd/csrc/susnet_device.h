@@ -58,6 +58,8 @@ struct Consts {
     int32_t n_valid, auto_reset, nr_imp, nr_crew; // nr_* = length of the role part of agent_action_map
     int32_t epw, dev_tick;                        // environments per wave in the fused rollout; dev_tick: the step counter
                                                   // is read from / advanced in device memory (graph-replayable launches)
+    int32_t aw_W, aw_pad;                         // action-stream words a tick owns (see AwLayout)
+    uint8_t aw_word[32];                          // draw d (A action draws, then the A - 1 shuffle draws) -> word of the tick
     uint32_t grid_rows[SUSNET_MAX_GRID];          // bit j of row i = grid[i][j]
     uint32_t valid_xy[SUSNET_MAX_GRID * SUSNET_MAX_GRID / 4]; // np.argwhere(grid) order; bytes x | y << 4
     // move_tab[a][cell] = cell after role-relative action a in {STAY, UP, DOWN, LEFT, RIGHT, other}: the whole of
@@ -95,10 +97,49 @@ struct State {
     int64_t tape_len;
 };
 
+// Packing of a tick's bounded draws into 32-bit words of the ACTION stream (production protocol; restated in
+// oracle/susnet_oracle.c so_action_layout).  The draws are the A action draws in agent order (base.py:326-330) and, with a
+// shuffled action order, the A - 1 Fisher-Yates draws i = A-1 .. 1 of np.random.shuffle (base.py:372-374).  Consecutive
+// draws share a word by nested multiply-shift (digit = hi32(w * n), w = lo32(w * n): joint bias <= product of the ranges
+// * 2^-32); a word is closed as soon as the product of the draws' LARGEST possible ranges would pass 2^16, so the packing
+// is static.  A tick owns W consecutive words (tick t: words t * W ..), not rounded up to Philox blocks.  The 1v1 game
+// (A == 2: ranges 6 and 5 whichever agent is the imposter) packs THREE ticks into one word (30^3 = 27000).
+constexpr uint32_t kAwCap = 65536u;
+struct AwLayout {
+    int W;
+    uint8_t word[32];
+};
+__host__ __device__ constexpr AwLayout make_aw_layout(int A, uint32_t max_range, bool shuffled) {
+    AwLayout L = {1, {}};
+    int n = 0, word = 0;
+    uint32_t prod = 1;
+    for (int i = 0; i < A; i++) {
+        if (prod * max_range > kAwCap) { word++; prod = 1; }
+        prod *= max_range;
+        L.word[n++] = (uint8_t)word;
+    }
+    if (shuffled)
+        for (int i = A - 1; i >= 1; i--) {
+            const uint32_t radix = (uint32_t)i + 1u;
+            if (prod * radix > kAwCap) { word++; prod = 1; }
+            prod *= radix;
+            L.word[n++] = (uint8_t)word;
+        }
+    L.W = A == 2 ? 1 : word + 1;
+    return L;
+}
+constexpr int kDuelTicksPerWord = 3; // 1v1: ticks served by one action-stream word
+constexpr uint32_t kDuelRange = 30u; // 6 * 5: what a 1v1 tick takes out of its word
+
 // Compile-time specialisation of a configuration; -1 = read the value from Consts at run time.
 template <int A_, int J_, int VAR_, int ORD_, int SHUF_ = -1, int NI_ = -1>
 struct Spec {
     static constexpr bool kGeneric = A_ < 0;
+    // action-stream layout known at compile time (agent count, variant and order compiled in)
+    static constexpr bool kStaticAw = A_ > 0 && VAR_ >= 0 && ORD_ >= 0;
+    static constexpr AwLayout kAw = make_aw_layout(A_ > 0 ? A_ : 1, (VAR_ == SUSNET_VARIANT_ITG ? 6u : 7u) + (VAR_ == SUSNET_VARIANT_TAGGING ? (uint32_t)(A_ > 0 ? A_ - 1 : 0) : 0u), ORD_ > 0);
+    __device__ static __forceinline__ int aw_W(const Consts &c) { return kStaticAw ? kAw.W : c.aw_W; }
+    __device__ static __forceinline__ int aw_word(const Consts &c, int d) { return kStaticAw ? (int)kAw.word[d] : (int)c.aw_word[d]; }
     static constexpr int kA = A_, kJ = J_;
     // flattened_state_size (base.py:230-232; tagging.py:42-60) when the configuration is compiled in
     static constexpr int kRawF = (A_ < 0 || J_ < 0 || VAR_ < 0) ? -1
@@ -182,7 +223,8 @@ constexpr uint32_t kActionStreamTag = 0x80000000u;
 struct ActionStream {
     uint64_t blk;          // block currently held (uniform across the wave)
     uint32_t w0, w1, w2, w3;
-    __device__ __forceinline__ void init() { blk = ~0ull; w0 = w1 = w2 = w3 = 0; }
+    uint32_t rem;          // what the last draw left of its word (the next draw of the same word continues from it)
+    __device__ __forceinline__ void init() { blk = ~0ull; w0 = w1 = w2 = w3 = 0; rem = 0; }
     __device__ __forceinline__ void gen(const PhiloxRng &r, uint64_t b) {
         uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32) | kActionStreamTag, c2 = r.e0, c3 = r.e1;
         uint32_t a = r.k0, d = r.k1;
@@ -195,6 +237,23 @@ struct ActionStream {
         }
         w0 = c0; w1 = c1; w2 = c2; w3 = c3;
         blk = b;
+    }
+    // word q (compile-time after unrolling / inlining) of the held block
+    __device__ __forceinline__ uint32_t at(int q) const { return q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : w3; }
+    // word `index` of the stream, run-time index (wave-uniform): generates its block unless it is the one held
+    // (two-level select: a 4-way chain on a run-time position is turned into an indexed stack array, i.e. scratch memory)
+    __device__ __forceinline__ uint32_t word(const PhiloxRng &r, uint64_t index) {
+        const uint64_t b = index >> 2;
+        if (b != blk) gen(r, b);
+        const uint32_t q = (uint32_t)index & 3u;
+        const uint32_t lo = (q & 1u) ? w1 : w0, hi = (q & 1u) ? w3 : w2;
+        return (q & 2u) ? hi : lo;
+    }
+    // word number `g` (compile-time) of the group of words that starts at stream index `base` (a multiple of 4): blocks are
+    // generated exactly where a new one starts, the word selection is static
+    __device__ __forceinline__ uint32_t word_in_group(const PhiloxRng &r, uint64_t base, int g) {
+        if ((g & 3) == 0) gen(r, (base >> 2) + (uint64_t)(g >> 2));
+        return at(g & 3);
     }
 };
 
@@ -404,6 +463,10 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, uint32_t r) {
     return __ffs((int)m) - 1;
 }
 
+// the agent order of a step, 4 bits per turn: 32 bits hold up to 8 agents (compiled-in agent counts)
+template <class S>
+using OrderOf = typename std::conditional<(!S::kGeneric && S::kA <= 8), uint32_t, uint64_t>::type;
+
 // np.random.shuffle / permutation on a nibble-packed list (base.py:374): i = n-1 .. 1, j in [0, i]
 // STATIC: n is a compile-time constant and the run starts right after rng.align()
 template <bool STATIC, class RNG, class ORD>
@@ -504,91 +567,78 @@ __device__ __forceinline__ void zero_metrics(Env &e) {
 
 // base.py:326-330: one randint(len(agent_action_map[i])) per agent in index order.
 // TAPE: numpy semantics on the env's own word stream.  PHILOX: word tick * A + i of the action stream.
-template <class S, int PAR = -1, class Store>
-__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, TapeRng &rng, ActionStream &, uint64_t, bool = true) {
+template <class S, int POS = -1, class Store>
+__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, TapeRng &rng, ActionStream &, uint64_t) {
     const int A = S::A(c);
     for (int i = 0; i < A; i++) st.set_act(i, rng.bounded(n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
 }
-// Layout of a tick's action-stream words when A > 2 (the 1v1 game: one word per tick, see sample_actions_env).
-//   s = 1 if the action order is shuffled (one more word carries the step's whole permutation), else 0.
-//   A + s <= 4 : word i serves agent i, word A the permutation: one Philox block.
-//   otherwise  : agents are packed FOUR per word by nested multiply-shift (word k serves agents 4k .. 4k+3 in index
-//                order: a = hi32(w * n), w = lo32(w * n); joint bias <= n^4 * 2^-32 < 4e-6), the permutation word follows
-//                the ceil(A / 4) action words -- one block per tick up to 12 agents instead of up to four.
-template <class S>
-struct ActionWords {
-    int A, s;
-    __device__ __forceinline__ ActionWords(const Consts &c) : A(S::A(c)), s(S::order_random(c) ? 1 : 0) {}
-    __device__ __forceinline__ bool packed() const { return A + s > 4; }
-    __device__ __forceinline__ int n_action_words() const { return packed() ? (A + 3) >> 2 : A; }
-    __device__ __forceinline__ int perm_word() const { return n_action_words(); }
-    __device__ __forceinline__ uint64_t blocks() const { return (uint64_t)((n_action_words() + s + 3) >> 2); }
-};
-template <class S>
-__device__ __forceinline__ uint64_t action_blocks_per_tick(const Consts &c) { return ActionWords<S>(c).blocks(); }
-// The permutation word of `tick`.  have_block: `as` already holds the block of the LAST action word (the caller sampled
-// this tick's actions just before): unless the permutation word starts a new block that is its block too.
-template <class S>
-__device__ __forceinline__ uint32_t order_word(const Consts &c, const PhiloxRng &rng, ActionStream &as, uint64_t tick, bool have_block) {
-    const ActionWords<S> L(c);
-    const int P = L.perm_word();
-    if (!have_block || (P & 3) == 0) as.gen(rng, tick * L.blocks() + (uint64_t)(P >> 2));
-    const uint32_t q = (uint32_t)P & 3u;
-    const uint32_t lo = (q & 1u) ? as.w1 : as.w0, hi = (q & 1u) ? as.w3 : as.w2;
-    return (q & 2u) ? hi : lo;
-}
-// np.random.shuffle (base.py:374) from ONE word: the Fisher-Yates draws i = n-1 .. 1 are the successive mixed-radix
-// digits of the word (nested multiply-shift; joint bias <= n! * 2^-32)
-template <class ORD>
-__device__ __forceinline__ void shuffle_from_word(ORD &v, int n, uint32_t w) {
+// Production stream (see AwLayout).  POS: the tick's position inside its group of ticks when the caller knows it at
+// compile time -- the fused rollout walks the stream in groups of 4 ticks (12 for the 1v1 game: 3 ticks per word) that start
+// on a Philox block boundary, so blocks are generated where they start and every word selection is static; -1 = run time
+// (any tick; blocks generated on demand).  Actions land in the store; `as.rem` keeps what the last action draw left of its
+// word, which the tick's shuffle draws continue (order_from_stream).
+template <class S, int POS = -1, class Store>
+__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, PhiloxRng &rng, ActionStream &as, uint64_t tick) {
+    const int A = S::A(c);
+    if (A <= 2) {
+        uint32_t w;
+        if (POS >= 0) {
+            constexpr int q = POS >= 0 ? POS / kDuelTicksPerWord : 0, sl = POS >= 0 ? POS % kDuelTicksPerWord : 0;
+            if (POS == 0) as.gen(rng, tick / (uint64_t)(4 * kDuelTicksPerWord));
+            w = sl == 0 ? as.at(q) : as.rem; // (ticks of a group run in sequence: `rem` is what the previous tick left)
+        } else {
+            const uint32_t sl = (uint32_t)(tick % (uint64_t)kDuelTicksPerWord);
+            w = as.word(rng, tick / (uint64_t)kDuelTicksPerWord);
+            w *= sl >= 1u ? kDuelRange : 1u;
+            w *= sl >= 2u ? kDuelRange : 1u;
+        }
+        const uint64_t p = (uint64_t)w * (uint64_t)n_actions<S>(c, S::imp(c, e.imp) & 1u);
+        st.set_act(0, (uint32_t)(p >> 32));
+        const uint64_t p1 = (uint64_t)(uint32_t)p * (uint64_t)n_actions<S>(c, (S::imp(c, e.imp) >> 1) & 1u);
+        if (A == 2) st.set_act(1, (uint32_t)(p1 >> 32));
+        as.rem = (uint32_t)p1;
+    } else {
+        const uint64_t W = (uint64_t)S::aw_W(c);
+        uint32_t w = 0;
 #pragma unroll
-    for (int i = n - 1; i >= 1; i--) {
-        const uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(i + 1);
-        w = (uint32_t)p;
-        nibble_swap(v, i, (int)(uint32_t)(p >> 32));
+        for (int i = 0; i < A; i++) {
+            const int k = S::aw_word(c, i);
+            if (i == 0 || k != S::aw_word(c, i - 1))
+                w = (POS >= 0 && S::kStaticAw) ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * W, (POS >= 0 ? POS : 0) * S::kAw.W + k)
+                                               : as.word(rng, tick * W + (uint64_t)k);
+            const uint64_t p = (uint64_t)w * (uint64_t)n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u);
+            st.set_act(i, (uint32_t)(p >> 32));
+            w = (uint32_t)p;
+        }
+        as.rem = w;
     }
 }
 
-// A tick owns W words of the action stream.  A > 2: see ActionWords (static word assignment either way).  A <= 2 (the 1v1 game): W = 1 -- ONE word serves both agents by nested
-// multiply-shift (p = w * n0: agent 0 takes the high word of p, agent 1 the high word of lo32(p) * n1, i.e. the two
-// mixed-radix digits of w * n0 * n1 / 2^32; joint bias <= n0 * n1 * 2^-32), so one Philox block serves FOUR ticks.
-// Q: the tick's position in its block when the caller knows it at compile time (the fused rollout's 4-tick loop
-// generates at Q == 0), -1 = run time.  `first` = the stream holds no block yet (a launch may start mid-block).
-template <class S, int Q = -1, class Store>
-__device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, const Env &e, PhiloxRng &rng, ActionStream &as, uint64_t tick,
-                                                   bool first = true) {
+// np.random.shuffle of the agent order (base.py:372-374) on the production stream: the Fisher-Yates draws i = A-1 .. 1 are
+// the digits that follow the tick's action draws.  have_rem: the caller sampled this tick's actions just before through
+// the same ActionStream (its `rem` is valid); otherwise the shared word's remainder is rebuilt from the action ranges.
+template <class S, int POS = -1, class ORD>
+__device__ __forceinline__ void order_from_stream(const Consts &c, const Env &e, PhiloxRng &rng, ActionStream &as, uint64_t tick, bool have_rem, ORD &order) {
     const int A = S::A(c);
-    if (A <= 2) {
-        const uint32_t q = Q >= 0 ? (uint32_t)Q : ((uint32_t)tick & 3u);
-        if (Q == 0 || (Q < 0 && (q == 0u || first))) as.gen(rng, tick >> 2);
-        // (two-level select: a 4-way chain on a run-time q is turned into an indexed stack array, i.e. scratch memory)
-        const uint32_t lo = (q & 1u) ? as.w1 : as.w0, hi = (q & 1u) ? as.w3 : as.w2;
-        const uint32_t w = (q & 2u) ? hi : lo;
-        const uint64_t p = (uint64_t)w * (uint64_t)n_actions<S>(c, S::imp(c, e.imp) & 1u);
-        st.set_act(0, (uint32_t)(p >> 32));
-        if (A == 2) st.set_act(1, __umulhi((uint32_t)p, n_actions<S>(c, (S::imp(c, e.imp) >> 1) & 1u)));
-    } else {
-        const ActionWords<S> L(c);
-        const uint64_t blocks = L.blocks();
-        if (!L.packed()) {
+    const uint64_t W = (uint64_t)S::aw_W(c);
+    uint32_t w = as.rem;
+    auto fetch = [&](int k) __attribute__((always_inline)) {
+        return (POS >= 0 && S::kStaticAw) ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * W, (POS >= 0 ? POS : 0) * S::kAw.W + k)
+                                          : as.word(rng, tick * W + (uint64_t)k);
+    };
+    if (!have_rem && S::aw_word(c, A) == S::aw_word(c, A - 1)) {
+        w = fetch(S::aw_word(c, A));
 #pragma unroll
-            for (int i = 0; i < A; i++) {
-                if ((i & 3) == 0) as.gen(rng, tick * blocks + (uint64_t)(i >> 2));
-                const uint32_t w = (i & 3) == 0 ? as.w0 : (i & 3) == 1 ? as.w1 : (i & 3) == 2 ? as.w2 : as.w3;
-                st.set_act(i, __umulhi(w, n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)));
-            }
-        } else {
-            uint32_t w = 0;
+        for (int q = 0; q < A; q++)
+            if (S::aw_word(c, q) == S::aw_word(c, A)) w *= n_actions<S>(c, (S::imp(c, e.imp) >> q) & 1u);
+    }
 #pragma unroll
-            for (int i = 0; i < A; i++) {
-                const int k = i >> 2; // this agent's word
-                if ((i & 15) == 0) as.gen(rng, tick * blocks + (uint64_t)(k >> 2));
-                if ((i & 3) == 0) w = (k & 3) == 0 ? as.w0 : (k & 3) == 1 ? as.w1 : (k & 3) == 2 ? as.w2 : as.w3;
-                const uint64_t p = (uint64_t)w * (uint64_t)n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u);
-                st.set_act(i, (uint32_t)(p >> 32));
-                w = (uint32_t)p;
-            }
-        }
+    for (int i = A - 1; i >= 1; i--) {
+        const int d = A + (A - 1 - i);
+        if (S::aw_word(c, d) != S::aw_word(c, d - 1)) w = fetch(S::aw_word(c, d));
+        const uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(i + 1);
+        w = (uint32_t)p;
+        nibble_swap(order, i, (int)(uint32_t)(p >> 32));
     }
 }
 
@@ -698,12 +748,12 @@ __device__ __forceinline__ void clear_info_if_fresh(Env &e) {
 // returns error bits (0 = stepped).  Actions are read from the store; rewards go to `sink` at env index b.
 // SINK_ON: the reward sink is bound to this env's float32 row of the rollout trajectory [T][B][A]: 1 = by pointer
 // (sink.ptr), 2 = by buffer descriptor (sink.buf), 3 = left in the caller's registers (sink.regs); 0 = generic strided put
-// order_w: production stream, shuffled order only -- the tick's permutation word (order_word()).
+// order_pre: production stream, shuffled order only -- the tick's agent order (order_from_stream()), 4 bits per turn.
 // LAZY_INFO = false: the caller guarantees the env is not FRESH (the fused rollout clears once before its loop and
 // zeroes the counters itself at an episode end that is not the launch's last tick)
 template <class S, bool VALIDATE, int SINK_ON, bool LAZY_INFO = true, class RNG, class Store, class Sink>
 __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, Store &st, Env &e, RNG &rng, const Sink &sink,
-                                             int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr, uint32_t order_w = 0u) {
+                                             int64_t b, bool &done, bool &trunc, unsigned long long *sg = nullptr, uint64_t order_pre = 0xFEDCBA9876543210ull) {
 #ifdef SUSNET_STAMPS
     unsigned long long sprev = __builtin_readcyclecounter();
 #define SSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); if (sg) sg[k] += tn - sprev; sprev = tn; } while (0)
@@ -734,13 +784,13 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
     uint32_t rc = 0; // 2-bit reward code per agent
     RT team = 0;
 
-    using OrderT = typename std::conditional<(!S::kGeneric && S::kA <= 8), uint32_t, uint64_t>::type;
+    using OrderT = OrderOf<S>;
     OrderT order = (OrderT)0xFEDCBA9876543210ull; // identity permutation, 4 bits per turn
     rng.align();
     const bool shuffled = S::order_random(c);
     if (shuffled) { // base.py:372-374
         if (RNG::kNumpy) shuffle_nibbles<false>(rng, order, A);
-        else shuffle_from_word(order, A, order_w); // production protocol: the caller read the tick's permutation word
+        else order = (OrderT)order_pre; // production protocol: the caller decoded the tick's shuffle draws
     }
 
     // The per-agent body is written as straight-line predicated code (selects instead of branches): with one

@@ -1,0 +1,389 @@
+// susnet_kernels.h -- the stepping kernels (k_step, k_rollout) as templates over the compiled-in configuration, plus the
+// launchers the host calls.  Every compiled-in configuration is instantiated in a translation unit of its own
+// (inst_*.hip: SUSNET_INSTANTIATE), so the library builds in parallel; susnet_capi.hip only declares them.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "susnet_device.h"
+#include "susnet_obs.h"
+
+namespace susnet {
+
+struct StepArgs {
+    const void *actions;
+    int32_t act_dtype;
+    int64_t act_sa, act_sb; // element strides (agent, env)
+    RewardSink rewards;
+    uint8_t *done, *trunc;
+    uint64_t tick; // steps taken so far (index of the action stream: the shuffled order of this step comes from it)
+};
+
+struct RolloutArgs {
+    int32_t n_ticks;
+    uint64_t tick_base; // steps this handle has taken before the launch (index of the action stream)
+    uint8_t *actions; // [T][B][A]
+    float *rewards;   // [T][B][A]
+    uint8_t *done, *trunc; // [T][B]
+    uint8_t *record;       // packed mode: [T][B][record_bytes]
+    int32_t record_bytes;
+};
+
+// f(std::integral_constant<int, I>{}) for I = BEGIN .. END - 1
+template <int BEGIN, int END, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
+
+template <class RNG>
+__device__ __forceinline__ RNG make_rng(const Consts &c, const State &s, int64_t b);
+
+template <>
+__device__ __forceinline__ PhiloxRng make_rng<PhiloxRng>(const Consts &c, const State &s, int64_t b) {
+    PhiloxRng r;
+    r.init(c.seed, c.env_id_base + (uint64_t)b, s.rng[b]);
+    return r;
+}
+template <>
+__device__ __forceinline__ TapeRng make_rng<TapeRng>(const Consts &c, const State &s, int64_t b) {
+    TapeRng r;
+    r.init(s.tape ? s.tape + b * s.tape_len : nullptr, s.tape ? s.tape_len : 0, s.rng[b]);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t load_action(const void *p, int dtype, int64_t k) {
+    int64_t v;
+    if (dtype == SUSNET_U8) v = reinterpret_cast<const uint8_t *>(p)[k];
+    else if (dtype == SUSNET_I32) v = reinterpret_cast<const int32_t *>(p)[k];
+    else v = reinterpret_cast<const int64_t *>(p)[k];
+    if (v < 0) v = -1;
+    if (v > 0x7ffffff0ll) v = 0x7ffffff0ll;
+    return (uint32_t)(int32_t)v;
+}
+
+__device__ __forceinline__ void store_action(void *p, int dtype, int64_t k, uint32_t a) {
+    if (dtype == SUSNET_U8) reinterpret_cast<uint8_t *>(p)[k] = (uint8_t)a;
+    else if (dtype == SUSNET_I32) reinterpret_cast<int32_t *>(p)[k] = (int32_t)a;
+    else reinterpret_cast<int64_t *>(p)[k] = (int64_t)a;
+}
+
+template <class RNG>
+__device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG &rng) {
+    s.rng[b] = rng.cur;
+    if (rng.ovf) atomicOr(s.err, SUSNET_ERRBIT_TAPE);
+}
+
+template <class RNG, class S>
+__global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, ObsArgs o) {
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+    const bool active = b < c.B;
+    typename StoreFor<S>::type st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
+    Env e = {};
+    if (active) {
+        const int A = S::A(c);
+        load_env<S>(c, s, st, b, e);
+#pragma unroll
+        for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
+        RNG rng = make_rng<RNG>(c, s, b);
+        bool done, trunc;
+        OrderOf<S> ord = (OrderOf<S>)0xFEDCBA9876543210ull;
+        if constexpr (!RNG::kNumpy) {
+            if (S::order_random(c)) {
+                ActionStream as;
+                as.init();
+                order_from_stream<S>(c, e, rng, as, c.dev_tick ? *s.dev_tick : a.tick, false, ord);
+            }
+        }
+        uint32_t bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc, nullptr, ord);
+        if (bits) atomicOr(s.err, bits);
+        if (a.done) a.done[b] = done ? 1 : 0;
+        if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
+        bool jobs_changed = false;
+        if (__builtin_expect(c.auto_reset && (done || trunc), 0)) {
+            accumulate_lifetime(c, s, b, e, trunc);
+            reset_env<S>(c, T, st, tid, e, rng);
+            e.flags |= FLAG_FRESH; // info counters stay readable until the next step
+            jobs_changed = true;
+        }
+        store_env<S>(c, s, st, b, e, jobs_changed);
+        finish_rng(s, b, rng);
+    }
+    int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
+    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
+}
+
+// Fused random rollout: n_ticks x {sample_actions; step; auto-reset} with the state held on chip.
+// OUT selects what a tick stores, at compile time (run-time optional outputs cost uniform branches on a path
+// that is instruction-fetch bound): OUT_ANY = whatever pointers are non-null / any observation mode;
+// OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
+// uint8 observation (the populate()-shaped record)
+enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4 };
+// OUT_TRAJ = OUT_TRAJ_RAW8 without an observation; OUT_RECORD = the OUT_TRAJ_RAW8 fields packed into ONE record per
+// env-step (rewards f32[A] | actions u8[A] | done | truncated | raw obs u8[F], padded to a dword): a lane stores its
+// record with one or two wide stores through a single buffer descriptor instead of six stores through five
+template <class S>
+struct RecordLayout {
+    static constexpr int kBytesTail = (S::kA > 0 ? S::kA : 0) + 2 + (S::kRawF > 0 ? S::kRawF : 0);
+    static constexpr int kDwords = (S::kA > 0 ? S::kA : 0) + (kBytesTail + 3) / 4;
+};
+template <class S, int OUT>
+__global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x;
+    // XCD-aware wave -> environment-block mapping: workgroup ids are dealt round-robin to the 8 XCDs, each with its
+    // own L2.  Consecutive env blocks write adjacent pieces of the same 128-byte lines (a wave's 64 done flags are
+    // half a line), so they are given to workgroups of the SAME XCD, dispatched back to back: the halves meet in one
+    // L2 instead of leaving two XCDs as partial-line write-backs.
+    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t per = nblk >> 3, rem = nblk & 7u;
+    const uint32_t wave_id = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    const int64_t b0 = (int64_t)wave_id * c.epw, b = b0 + tid;
+    const bool active = tid < c.epw && b < c.B;
+    const int nrows = (int)((c.B - b0) < c.epw ? (c.B - b0) : c.epw);
+    const int A = S::A(c);
+    typename StoreFor<S>::type st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
+    Env e = {};
+    PhiloxRng rng;
+    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
+    ActionStream as;
+    as.init();
+    if (active) {
+        load_env<S>(c, s, st, b, e);
+        rng.cur = s.rng[b];
+    }
+    // trajectory mode with register-direct observation rows has no cooperative (all-lane) work past this point:
+    // idle lanes of a ragged last wave leave, and the tick loop runs without per-block exec masking
+    if (((OUT == OUT_TRAJ_RAW8 && S::kRawF > 0) || OUT == OUT_TRAJ || OUT == OUT_RECORD) && !active) return;
+    // the step counter of the action stream: a kernel argument, or (graph-replayable launches) a device word that the
+    // last workgroup to finish advances; either way wave-uniform, in scalar registers
+    uint64_t tick_base = a.tick_base;
+    if (c.dev_tick) {
+        const uint64_t t = *s.dev_tick;
+        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
+    }
+    LifeAcc life;
+    life.clear();
+    const int64_t AB = (int64_t)A * c.B;
+    // per-lane output cursors, bumped once per tick (no 64-bit index arithmetic per store)
+    const int64_t bb = active ? b : 0;
+    uint8_t *pa = a.actions ? a.actions + bb * A : nullptr; // env-major rows: one lane writes its A values with wide stores
+    float *pr = a.rewards ? a.rewards + bb * A : nullptr;
+    uint8_t *pd = a.done ? a.done + bb : nullptr;
+    uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
+    constexpr int kRawF = S::kRawF;
+    // compiled-in configurations write their raw uint8 row straight from registers (a few 4-byte stores per lane:
+    // the 64 rows of a wave are contiguous, so every touched line is fully written within the tick); measured
+    // faster than the LDS image + 16-byte copy-out, also when that copy-out was software-pipelined across ticks
+    constexpr bool kDirect = (OUT == OUT_TRAJ_RAW8) && S::kRawF > 0;
+    // OUT_TRAJ_RAW8: every output goes through a buffer descriptor (wave-uniform base and size, hardware range
+    // check) with a fixed per-lane byte offset and the tick's slab offset in a scalar register, so a store costs no
+    // vector address arithmetic and a tick advances five scalar offsets.  The host only selects this mode when
+    // every output array of the launch is below 2 GiB.
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
+    const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+    BufDst da = make_buf_dst(a.actions, nt * (uint64_t)AB, (uint32_t)(bb * A));
+    BufDst dr = make_buf_dst(a.rewards, nt * (uint64_t)AB * 4u, (uint32_t)(bb * A) * 4u);
+    BufDst dd = make_buf_dst(a.done, nt * (uint64_t)c.B, (uint32_t)bb);
+    BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
+    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * (kRawF > 0 ? kRawF : 0)));
+    const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    constexpr bool kRec = OUT == OUT_RECORD; // (host: compiled-in configurations with a static raw row only)
+    constexpr int kRecDwords = RecordLayout<S>::kDwords > 0 ? RecordLayout<S>::kDwords : 1;
+    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
+    const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
+    if (kTraj) { pa = nullptr; pr = nullptr; pd = nullptr; pt = nullptr; }
+#ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycle shares of the tick's segments, one wave
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long seg2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); seg[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+    if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
+    // one tick; PAR = compile-time position of the absolute tick in its 4-tick action-stream block, or -1 = run time
+    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par)::value;
+#ifdef SUSNET_STAMPS
+        tprev = __builtin_readcyclecounter();
+#endif
+        STAMP(0);
+        if (active) {
+            sample_actions_env<S, PAR>(c, st, e, rng, as, tick_base + (uint64_t)tick);
+            // shuffled order: the tick's shuffle draws follow its action draws in the stream
+            OrderOf<S> ow = (OrderOf<S>)0xFEDCBA9876543210ull;
+            if (S::order_random(c)) order_from_stream<S, PAR>(c, e, rng, as, tick_base + (uint64_t)tick, true, ow);
+            STAMP(1);
+            uint32_t av[S::kA > 0 ? S::kA : 1];
+            float rr[S::kA > 0 ? S::kA : 1];
+            if (kRec) {
+#pragma unroll
+                for (int i = 0; i < (S::kA > 0 ? S::kA : 0); i++) av[i] = st.act(i);
+            } else if (kTraj || (OUT == OUT_ANY && pa != nullptr)) {
+                if (!S::kGeneric) {
+#pragma unroll
+                    for (int i = 0; i < A; i++) av[i] = st.act(i);
+                    if (kTraj) store_row_u8<(S::kA > 0 ? S::kA : 1)>(da, av);
+                    else store_row_u8<(S::kA > 0 ? S::kA : 1)>(PtrDst{pa}, av);
+                } else if (kTraj) {
+                    for (int i = 0; i < A; i++) da.st8((uint32_t)i, st.act(i));
+                } else {
+                    for (int i = 0; i < A; i++) pa[i] = (uint8_t)st.act(i);
+                }
+            }
+            STAMP(2);
+            RewardRowSink sink{{(OUT == OUT_ANY && pr) ? (void *)pr : nullptr, 1, 0, 0}, dr, rr};
+            bool done, trunc;
+#ifdef SUSNET_STAMPS
+            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
+            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
+            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, seg2, ow);
+#else
+            if (kRec) step_env<S, false, 3, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
+            else if (kTraj) step_env<S, false, 2, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
+            else step_env<S, false, 0, false>(c, T, st, e, rng, sink, 0, done, trunc, nullptr, ow);
+#endif
+            STAMP(3);
+            if (kTraj) {
+                dd.st8(0u, done ? 1u : 0u);
+                dt.st8(0u, trunc ? 1u : 0u);
+            } else if (OUT == OUT_ANY) {
+                if (pd != nullptr) *pd = done ? 1 : 0;
+                if (pt != nullptr) *pt = trunc ? 1 : 0;
+            }
+            STAMP(4);
+            if (__builtin_expect(done || trunc, 0)) {
+                life.add_episode(e, trunc);
+                reset_env<S>(c, T, st, tid, e, rng);
+                // info counters of a terminal step stay readable until the next step: only the launch's last
+                // tick can be observed, every other episode end zeroes them right away (wave-uniform branch)
+                if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+                else zero_metrics(e);
+            }
+            STAMP(5);
+            if (kRec) { // one packed record per env-step: rewards | actions | done | truncated | raw observation
+                constexpr int kA = S::kA > 0 ? S::kA : 0, kF = kRawF > 0 ? kRawF : 0, kNB = kA + 2 + kF;
+                uint8_t row[kF + 4];
+                fill_raw<S>(c, st, e, row);
+                uint32_t by[(kNB + 3) / 4 * 4];
+#pragma unroll
+                for (int k = 0; k < kA; k++) by[k] = av[k] & 0xffu;
+                by[kA] = done ? 1u : 0u;
+                by[kA + 1] = trunc ? 1u : 0u;
+#pragma unroll
+                for (int f = 0; f < kF; f++) by[kA + 2 + f] = row[f];
+#pragma unroll
+                for (int k = kNB; k < (kNB + 3) / 4 * 4; k++) by[k] = 0u;
+                uint32_t w[kRecDwords];
+#pragma unroll
+                for (int i = 0; i < kA; i++) w[i] = __float_as_uint(rr[i]);
+#pragma unroll
+                for (int k = 0; k < (kNB + 3) / 4; k++)
+                    w[kA + k] = by[4 * k] | (by[4 * k + 1] << 8) | (by[4 * k + 2] << 16) | (by[4 * k + 3] << 24);
+                store_dwords<kRecDwords>(drec, w);
+            }
+            if (OUT == OUT_ANY) {
+                pa = pa ? pa + AB : pa;
+                pr = pr ? pr + AB : pr;
+                pd = pd ? pd + c.B : pd;
+                pt = pt ? pt + c.B : pt;
+            }
+        }
+        if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (OUT == OUT_TRAJ_RAW8 && !kDirect) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (kDirect) {
+            if (active) {
+                uint8_t row[(kRawF > 0 ? kRawF : 1) + 4];
+                fill_raw<S>(c, st, e, row);
+                // 4-byte stores (naturally aligned when F % 4 == 0, otherwise the hardware's unaligned
+                // access splits them), then a 2-byte and a 1-byte tail
+                uint32_t rv[(kRawF > 0 ? kRawF : 1)];
+#pragma unroll
+                for (int k = 0; k < kRawF; k++) rv[k] = row[k];
+                store_row_u8<(kRawF > 0 ? kRawF : 1)>(dobs, rv);
+            }
+        }
+        if (kTraj) { // wave-uniform: next tick's slabs
+            da.so += slab_a; dr.so += 4u * slab_a; dd.so += slab_d; dt.so += slab_d; dobs.so += slab_o;
+        }
+        if (kRec) drec.so += slab_rec;
+        STAMP(6);
+    };
+    // The action stream is walked in GROUPS of ticks that start on a Philox block boundary: 4 ticks (4 * W words) when the
+    // word layout is compiled in, 12 for the 1v1 game (three ticks per word).  Inside a group every block generation and
+    // word selection is static; ticks before the first group boundary of a launch and after its last full group run
+    // through the run-time flavour.
+    constexpr int kGroup = (S::kGeneric || OUT == OUT_ANY) ? 0 : (S::kA == 2 ? 4 * kDuelTicksPerWord : (S::kStaticAw ? 4 : 0));
+    int tick = 0;
+    while (tick < a.n_ticks) {
+        if (kGroup > 0 && tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) % (uint64_t)(kGroup > 0 ? kGroup : 1)) == 0ull) {
+            static_for<0, (kGroup > 0 ? kGroup : 1)>([&](auto pos) __attribute__((always_inline)) { tick_body(tick + decltype(pos)::value, pos); });
+            tick += kGroup;
+        } else {
+            tick_body(tick, std::integral_constant<int, -1>{});
+            tick++;
+        }
+    }
+#ifdef SUSNET_STAMPS
+    if (blockIdx.x == 100 && tid == 0)
+        for (int k = 0; k < 8; k++) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 2 + k, seg[k]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 10 + k, seg2[k]);
+        }
+#endif
+    if (active) {
+        store_env<S>(c, s, st, b, e, true);
+        s.rng[b] = rng.cur;
+        life.flush(c, s, b);
+    }
+}
+
+// configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
+using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>; // ImposterTrainingGround 1v1, no jobs, fixed order, imposter = agent 0 (any wall map)
+using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
+using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
+using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
+// agent count compiled in, everything else read at run time (any variant / order / up to 8 jobs): the packed-VGPR
+// tables without a full specialisation
+template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
+
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+template <class SPEC>
+void launch_rollout(int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
+    if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+    else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+    else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
+    else if (out == OUT_RECORD) {
+        // the packed record exists for configurations whose whole raw row is known at compile time
+        if constexpr (!SPEC::kGeneric && SPEC::kRawF > 0) hipLaunchKernelGGL((k_rollout<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
+    } else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
+}
+// tape: the handle draws from caller-supplied words (numpy parity) instead of the production stream
+template <class SPEC>
+void launch_step(bool tape, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const StepArgs &a, const ObsArgs &o) {
+    if (tape) hipLaunchKernelGGL((k_step<TapeRng, SPEC>), g, blk, sh, st, c, s, a, o);
+    else hipLaunchKernelGGL((k_step<PhiloxRng, SPEC>), g, blk, sh, st, c, s, a, o);
+}
+#define SUSNET_DECLARE(SPEC)                                                                                              \
+    extern template void launch_rollout<SPEC>(int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
+    extern template void launch_step<SPEC>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
+#define SUSNET_INSTANTIATE(SPEC)                                                                                          \
+    template void launch_rollout<SPEC>(int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
+    template void launch_step<SPEC>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
+
+} // namespace susnet

@@ -143,8 +143,11 @@ def test_device_code_has_no_scratch_memory_traffic(pkg, tmp_path):
     shutil.copy(pkg._lib.LIB_PATH, so)
     subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
-    assert len(objs) == 1, "expected exactly one gfx950 code object in the library"
-    asm = subprocess.run([objdump, "-d", str(objs[0])], check=True, capture_output=True, text=True).stdout
-    assert asm.count("v_mad_u64_u32") > 1000, "disassembly looks empty"
-    scratch = [ln for ln in asm.splitlines() if "scratch_" in ln]
-    assert not scratch, f"{len(scratch)} scratch instructions, e.g. {scratch[:3]}"
+    assert len(objs) >= 1, "expected gfx950 code objects in the library (one per translation unit)"
+    muls = 0
+    for obj in objs:
+        asm = subprocess.run([objdump, "-d", str(obj)], check=True, capture_output=True, text=True).stdout
+        muls += asm.count("v_mad_u64_u32")
+        scratch = [ln for ln in asm.splitlines() if "scratch_" in ln]
+        assert not scratch, f"{obj.name}: {len(scratch)} scratch instructions, e.g. {scratch[:3]}"
+    assert muls > 1000, "disassembly looks empty"

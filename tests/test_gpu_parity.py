@@ -75,8 +75,22 @@ def check_step_against_golden(env, gs, s, rew, done, trunc, tagging):
 # ------------------------------------------------------------------------------------------------
 # (a) HIP kernels vs the reference's golden traces, fed numpy's MT19937 words as the tape
 # ------------------------------------------------------------------------------------------------
+KERNELS = ["compiled", "generic"]  # the compiled-in (Spec) kernels bench.py times, and the generic LDS-table kernels
+
+
+def select_kernels(monkeypatch, kernels):
+    """Route a handle's step launches: 'compiled' = whatever pick_spec selects (Spec<...> / SpecA<A> where one exists),
+    'generic' = the generic kernels for every configuration (SUSNET_FORCE_GENERIC is read at each launch)."""
+    if kernels == "generic":
+        monkeypatch.setenv("SUSNET_FORCE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("SUSNET_FORCE_GENERIC", raising=False)
+
+
+@pytest.mark.parametrize("kernels", KERNELS)
 @pytest.mark.parametrize("family", sorted(FAMILIES))
-def test_hip_replays_reference_traces(pkg, family):
+def test_hip_replays_reference_traces(pkg, family, kernels, monkeypatch):
+    select_kernels(monkeypatch, kernels)
     gs = [load_golden(f"{GOLDEN_DIR}/{n}.npz") for n in FAMILIES[family]]
     meta = gs[0]["meta"]
     B = len(gs)
@@ -123,10 +137,13 @@ def test_hip_replays_reference_traces(pkg, family):
             assert cur[b] == g["words"][-1], g["name"]
 
 
+@pytest.mark.parametrize("kernels", KERNELS)
 @pytest.mark.parametrize("name", crc_names())
-def test_hip_matches_reference_crc_streams(pkg, name):
+def test_hip_matches_reference_crc_streams(pkg, name, kernels, monkeypatch):
     """64 numpy seeds per configuration at once (one env per seed, TAPE mode fed numpy's own words)."""
     import zlib
+
+    select_kernels(monkeypatch, kernels)
 
     g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
     meta = g["meta"]
@@ -157,6 +174,35 @@ def test_hip_matches_reference_crc_streams(pkg, name):
     env.poll_errors()
     bad = np.argwhere(got != g["crc"])
     assert bad.size == 0, f"{name}: first mismatch at (seed index, step) = {bad[0].tolist()}"
+
+
+@pytest.mark.parametrize("family", [f for f in sorted(FAMILIES) if f.startswith("itg_1v1_")])
+def test_production_1v1_kernel_steps_reference_states(pkg, family):
+    """The kernel bench.py's headline number runs (k_step / k_rollout<PhiloxRng, Spec<2,0,ITG,...>>: branch-free duel) against
+    the reference's own traces.  A 1v1 step with a fixed order draws nothing, so the production kernel can be fed the
+    reference's pre-step states and actions directly: every recorded step of a trace becomes one env of a batch (state,
+    t and info counters injected), ONE step launch, and the post-step state / rewards (bit patterns) / done / truncated /
+    info must equal what the reference produced."""
+    for n in FAMILIES[family]:
+        g = load_golden(f"{GOLDEN_DIR}/{n}.npz")
+        meta = g["meta"]
+        S = len(g["done"])
+        env = env_from_meta(pkg, meta, S, rng="philox", reward_dtype=torch.float64)
+        env.reset()
+        assert bool(np_(env.imposter_mask)[:, 0].all()) and not np_(env.imposter_mask)[:, 1].any()
+        pre_metrics = np.zeros((S, 13), dtype=np.int64)
+        for s in range(1, S):
+            if not g["ep_start"][s]:
+                pre_metrics[s] = g["metrics"][s - 1]
+        env.set_state(agent_positions=g["pre_pos"], alive_agents=g["pre_alive"], t=g["pre_t"], metrics=pre_metrics)
+        _, rew, done, trunc, _ = env.step(torch.as_tensor(g["actions"].astype(np.int64)))
+        np.testing.assert_array_equal(np_(env.agent_positions), g["pos"], err_msg=n + " pos")
+        np.testing.assert_array_equal(np_(env.alive_agents), g["alive"].astype(bool), err_msg=n + " alive")
+        got = np_(rew).astype(np.float64)
+        assert got.view(np.uint64).tolist() == g["rewards"].view(np.uint64).tolist(), n + " rewards"
+        np.testing.assert_array_equal(np_(done), g["done"].astype(bool), err_msg=n + " done")
+        np.testing.assert_array_equal(np_(trunc), g["trunc"].astype(bool), err_msg=n + " trunc")
+        np.testing.assert_array_equal(np_(env._metrics), g["metrics"], err_msg=n + " info")
 
 
 # ------------------------------------------------------------------------------------------------

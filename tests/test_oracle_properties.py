@@ -176,3 +176,67 @@ def test_four_agents_share_one_action_word_independently(oracle_mod):
         t = np.zeros((ni, nj))
         np.add.at(t, (a[:, i], a[:, j]), 1)
         assert _chi2(t.ravel(), B / (ni * nj)) < 85, (i, j)
+
+
+def test_three_1v1_ticks_share_one_action_word_independently(oracle_mod):
+    """1v1 production protocol: ONE action-stream word serves THREE consecutive ticks (six nested digits, 30^3 = 27000 << 2^32).
+    The imposter's actions at ticks 3k, 3k+1, 3k+2 -- all digits of the same word -- must be jointly uniform over their
+    6^3 = 216 cells (df = 215: 99.9 % quantile ~ 284), and so must (crew at 3k, imposter at 3k+2)."""
+    om = oracle_mod
+    B = 30000
+    cfg = om.make_config("itg", n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
+                         time_step_reward=0, include_walls=False, shuffle_imposter_index=False, max_time_steps=100000)
+    ob = om.OracleBatch(cfg, B)
+    ob.set_philox(99, 0, 0)
+    ob.reset()
+    acts = []
+    for t in range(6):
+        a = ob.sample_actions()
+        acts.append(a.copy())
+        ob.step(np.zeros((B, 2), dtype=np.int64))  # (STAY, STAY): nobody dies, roles stay put
+    for k in (0, 3):
+        tri = np.zeros((6, 6, 6))
+        np.add.at(tri, (acts[k][:, 0], acts[k + 1][:, 0], acts[k + 2][:, 0]), 1)
+        assert _chi2(tri.ravel(), B / 216) < 284
+        pair = np.zeros((5, 6))
+        np.add.at(pair, (acts[k][:, 1], acts[k + 2][:, 0]), 1)
+        assert _chi2(pair.ravel(), B / 30) < 58
+    # a different word serves ticks 3..5: no relation to ticks 0..2
+    cross = np.zeros((6, 6))
+    np.add.at(cross, (acts[2][:, 0], acts[3][:, 0]), 1)
+    assert _chi2(cross.ravel(), B / 36) < 66
+
+
+def test_large_games_keep_every_word_below_the_bias_cap(oracle_mod):
+    """The word packing closes a word before the product of its draws' largest ranges passes 2^16, whatever the agent count:
+    a 4v8 game's 12! orders cannot come from one 32-bit word.  Checked on the layout itself and on the resulting order
+    distribution of a 12-agent game (every agent equally likely at every turn: 12 x 12 table, df = 121: 99.9 % ~ 175;
+    first-two-turns pairs: 132 cells, df = 131: ~ 187)."""
+    om = oracle_mod
+    B = 30000
+    cfg = om.make_config("base", n_imposters=4, n_crew=8, n_jobs=2)
+    ob = om.OracleBatch(cfg, B)
+    env0 = ob.envs[0]
+    A = 12
+    words = list(env0.aw_word[:2 * A - 1])
+    ranges = [7] * A + list(range(A, 1, -1))
+    assert words == sorted(words) and words[0] == 0 and env0.aw_W == words[-1] + 1 and env0.aw_tpw == 1
+    for k in range(env0.aw_W):
+        prod = 1
+        for w, r in zip(words, ranges):
+            if w == k:
+                prod *= r
+        assert 1 < prod <= 65536, (k, prod)
+    ob.set_philox(17, 0, 0)
+    ob.reset()
+    ob.step(np.zeros((B, A), dtype=np.int64))
+    order = ob.order
+    assert (np.sort(order, axis=1) == np.arange(A)).all()
+    table = np.zeros((A, A))
+    for turn in range(A):
+        table[turn] = np.bincount(order[:, turn], minlength=A)
+    assert _chi2(table.ravel(), B / A) < 175
+    first2 = np.zeros((A, A))
+    np.add.at(first2, (order[:, 0], order[:, 1]), 1)
+    off = first2[~np.eye(A, dtype=bool)]
+    assert first2.trace() == 0 and _chi2(off, B / (A * (A - 1))) < 187
