@@ -205,8 +205,8 @@ int so_sizeof_env(void) { return (int)sizeof(so_env); }
 
 /* PRODUCT protocol (not reference behaviour), restated so that the kernels can be checked bit for bit on the Philox
  * stream: how a tick's bounded draws -- A action draws in agent order (base.py:326-330), then, with a shuffled action
- * order, the A - 1 Fisher-Yates draws i = A-1 .. 1 of np.random.shuffle (base.py:372-374) -- are packed into 32-bit words
- * of the ACTION stream.  Consecutive draws share a word by nested multiply-shift (digit = hi32(w * n), w = lo32(w * n):
+ * order (np.random.shuffle, base.py:372-374), the A - 1 placement draws k = 1 .. A-1 (range k + 1, see so_step) -- are
+ * packed into 32-bit words of the ACTION stream.  Consecutive draws share a word by nested multiply-shift (digit = hi32(w * n), w = lo32(w * n):
  * the mixed-radix digits of w * n1 * n2 .. / 2^32, joint bias <= n1 * n2 .. * 2^-32); a word is closed as soon as the
  * product of the draws' LARGEST possible ranges (imposter action count; i + 1 for a shuffle draw) would pass 2^16, so
  * the packing is static and the bias of any word stays below 2^-16.  A tick owns aw_W consecutive words (tick t: words
@@ -226,8 +226,8 @@ static void so_action_layout(so_env *e) {
         e->aw_word[n++] = (uint8_t)word;
     }
     if (e->cfg.is_action_order_random)
-        for (int i = A - 1; i >= 1; i--) {
-            uint32_t radix = (uint32_t)i + 1u;
+        for (int k = 1; k < A; k++) {
+            uint32_t radix = (uint32_t)k + 1u;
             if (prod * radix > SO_AW_CAP) { word++; prod = 1; }
             prod *= radix;
             e->aw_word[n++] = (uint8_t)word;
@@ -532,11 +532,15 @@ int so_step(so_env *e, const int32_t *actions, double *rewards, int32_t *done_ou
     draw_align(e);
     if (e->cfg.is_action_order_random) { /* base.py:372-374: np.random.shuffle(agent order) */
         if (e->rng.kind == SO_RNG_PHILOX) {
-            /* production protocol (so_action_layout): the Fisher-Yates draws i = A-1 .. 1 are the digits that FOLLOW the
-             * tick's action draws in its action-stream words; a draw that shares a word with action draws continues from
-             * what those left, lo32(word * product of their ranges) */
+            /* production protocol (so_action_layout): a uniform random order built as turn RANKS from the digits that
+             * FOLLOW the tick's action draws in its action-stream words.  Agents are placed one after the other: draw
+             * k = 1 .. A-1 (range k + 1) is the slot agent k takes among agents 0 .. k, every earlier agent at a slot >= it
+             * moves one up.  A draw that shares a word with action draws continues from what those left, lo32(word *
+             * product of their ranges).  (Same distribution as np.random.shuffle, different mapping from the words.) */
+            int rank[SO_MAX_AGENTS];
             uint32_t w = 0;
-            for (int i = A - 1, d = A; i >= 1; i--, d++) {
+            rank[0] = 0;
+            for (int k = 1, d = A; k < A; k++, d++) {
                 if (e->aw_word[d] != e->aw_word[d - 1]) {
                     w = action_word(e, e->rng.tick * (uint64_t)e->aw_W + e->aw_word[d]);
                 } else if (d == A) {
@@ -544,13 +548,14 @@ int so_step(so_env *e, const int32_t *actions, double *rewards, int32_t *done_ou
                     for (int q = 0; q < A; q++)
                         if (e->aw_word[q] == e->aw_word[d]) w *= (uint32_t)so_n_actions(e, q);
                 }
-                uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(i + 1);
-                int j = (int)(p >> 32);
+                uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(k + 1);
+                int slot = (int)(p >> 32);
                 w = (uint32_t)p;
-                int32_t tmp = e->order[i];
-                e->order[i] = e->order[j];
-                e->order[j] = tmp;
+                for (int q = 0; q < k; q++)
+                    if (rank[q] >= slot) rank[q]++;
+                rank[k] = slot;
             }
+            for (int i = 0; i < A; i++) e->order[rank[i]] = i;
         } else {
             np_shuffle(e, e->order, A);
         }

@@ -150,8 +150,8 @@ static int pick_spec(const Consts &c, bool float_exact) {
     if (const char *ev = getenv("SUSNET_FORCE_GENERIC")) // tests: the same fixtures through the generic LDS-table kernels
         if (ev[0] == '1') return 0;
     if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG && !c.order_random && !c.shuffle_imp && c.n_imp == 1) return 2;
-    if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 3;
-    if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random) return 4;
+    if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 1) return 3;
+    if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 2) return 4;
     if (c.A == 5 && c.J == 5 && c.variant == SUSNET_VARIANT_TAGGING && c.order_random) return 6;
     if (c.A >= 2 && c.A <= 8 && c.J <= 8) return 10 + c.A; // SpecA<A>
     return 0;
@@ -651,7 +651,7 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
     if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
     const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c, env->float_exact) : 0;
-    if (spec != 2 && spec != 3 && spec != 4 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode
+    if (spec != 2 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode (the byte-parallel configurations have none)
     const int A = env->c.A, F = env->layout.obs_raw_size;
     out->off_rewards = 0;
     out->off_actions = 4 * A;

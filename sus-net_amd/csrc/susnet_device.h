@@ -99,7 +99,8 @@ struct State {
 
 // Packing of a tick's bounded draws into 32-bit words of the ACTION stream (production protocol; restated in
 // oracle/susnet_oracle.c so_action_layout).  The draws are the A action draws in agent order (base.py:326-330) and, with a
-// shuffled action order, the A - 1 Fisher-Yates draws i = A-1 .. 1 of np.random.shuffle (base.py:372-374).  Consecutive
+// shuffled action order (np.random.shuffle, base.py:372-374), the A - 1 draws k = 1 .. A-1 (range k + 1) that place agent k
+// among agents 0 .. k (see ranks_from_stream: a uniform random order, built as turn RANKS).  Consecutive
 // draws share a word by nested multiply-shift (digit = hi32(w * n), w = lo32(w * n): joint bias <= product of the ranges
 // * 2^-32); a word is closed as soon as the product of the draws' LARGEST possible ranges would pass 2^16, so the packing
 // is static.  A tick owns W consecutive words (tick t: words t * W ..), not rounded up to Philox blocks.  The 1v1 game
@@ -119,8 +120,8 @@ __host__ __device__ constexpr AwLayout make_aw_layout(int A, uint32_t max_range,
         L.word[n++] = (uint8_t)word;
     }
     if (shuffled)
-        for (int i = A - 1; i >= 1; i--) {
-            const uint32_t radix = (uint32_t)i + 1u;
+        for (int k = 1; k < A; k++) {
+            const uint32_t radix = (uint32_t)k + 1u;
             if (prod * radix > kAwCap) { word++; prod = 1; }
             prod *= radix;
             L.word[n++] = (uint8_t)word;
@@ -140,7 +141,7 @@ struct Spec {
     static constexpr AwLayout kAw = make_aw_layout(A_ > 0 ? A_ : 1, (VAR_ == SUSNET_VARIANT_ITG ? 6u : 7u) + (VAR_ == SUSNET_VARIANT_TAGGING ? (uint32_t)(A_ > 0 ? A_ - 1 : 0) : 0u), ORD_ > 0);
     __device__ static __forceinline__ int aw_W(const Consts &c) { return kStaticAw ? kAw.W : c.aw_W; }
     __device__ static __forceinline__ int aw_word(const Consts &c, int d) { return kStaticAw ? (int)kAw.word[d] : (int)c.aw_word[d]; }
-    static constexpr int kA = A_, kJ = J_;
+    static constexpr int kA = A_, kJ = J_, kVar = VAR_, kOrd = ORD_, kShuf = SHUF_, kNI = NI_;
     // flattened_state_size (base.py:230-232; tagging.py:42-60) when the configuration is compiled in
     static constexpr int kRawF = (A_ < 0 || J_ < 0 || VAR_ < 0) ? -1
                                  : 3 * A_ + ((J_ > 0 || VAR_ == SUSNET_VARIANT_TAGGING) ? 3 * (J_ > 0 ? J_ : 0) : 0) +
@@ -614,11 +615,21 @@ __device__ __forceinline__ void sample_actions_env(const Consts &c, Store &st, c
     }
 }
 
-// np.random.shuffle of the agent order (base.py:372-374) on the production stream: the Fisher-Yates draws i = A-1 .. 1 are
-// the digits that follow the tick's action draws.  have_rem: the caller sampled this tick's actions just before through
-// the same ActionStream (its `rem` is valid); otherwise the shared word's remainder is rebuilt from the action ranges.
-template <class S, int POS = -1, class ORD>
-__device__ __forceinline__ void order_from_stream(const Consts &c, const Env &e, PhiloxRng &rng, ActionStream &as, uint64_t tick, bool have_rem, ORD &order) {
+// SWAR on bytes packed four to a 32-bit word (values < 0x80; bit 7 of a byte is the lane's flag)
+constexpr uint32_t k01 = 0x01010101u, k80 = 0x80808080u, k7f = 0x7f7f7f7fu;
+__device__ __forceinline__ uint32_t bcast_byte0(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0u); } // byte 0 of v in all four bytes
+
+// np.random.shuffle of the agent order (base.py:372-374) on the production stream, as turn RANKS: rank[i] = the turn at
+// which agent i acts.  Agents are placed one after the other: draw k = 1 .. A-1 (range k + 1, the digits that follow the
+// tick's action draws in its action-stream words) is the slot d agent k takes among agents 0 .. k, and every earlier agent
+// at slot >= d moves one slot up -- each of the (k + 1)! arrangements of agents 0 .. k equally likely, so the final order
+// is a uniform random permutation (same distribution as numpy's Fisher-Yates, different mapping from the words).
+// R[w]: byte i % 4 of word i / 4 = rank[i] | 0x80 (the flag bit makes the byte-wise compare below borrow-free).
+// have_rem: the caller sampled this tick's actions just before through the same ActionStream (its `rem` is valid);
+// otherwise the shared word's remainder is rebuilt from the action ranges.
+template <class S, int POS = -1, int NW>
+__device__ __forceinline__ void ranks_from_stream(const Consts &c, uint32_t imp_bits, PhiloxRng &rng, ActionStream &as, uint64_t tick, bool have_rem,
+                                                  uint32_t (&R)[NW]) {
     const int A = S::A(c);
     const uint64_t W = (uint64_t)S::aw_W(c);
     uint32_t w = as.rem;
@@ -626,21 +637,47 @@ __device__ __forceinline__ void order_from_stream(const Consts &c, const Env &e,
         return (POS >= 0 && S::kStaticAw) ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * W, (POS >= 0 ? POS : 0) * S::kAw.W + k)
                                           : as.word(rng, tick * W + (uint64_t)k);
     };
-    if (!have_rem && S::aw_word(c, A) == S::aw_word(c, A - 1)) {
+    if (!have_rem && A > 1 && S::aw_word(c, A) == S::aw_word(c, A - 1)) {
         w = fetch(S::aw_word(c, A));
 #pragma unroll
-        for (int q = 0; q < A; q++)
-            if (S::aw_word(c, q) == S::aw_word(c, A)) w *= n_actions<S>(c, (S::imp(c, e.imp) >> q) & 1u);
+        for (int q = 0; q < 4 * NW; q++)
+            if (q < A && S::aw_word(c, q) == S::aw_word(c, A)) w *= n_actions<S>(c, (imp_bits >> q) & 1u);
     }
 #pragma unroll
-    for (int i = A - 1; i >= 1; i--) {
-        const int d = A + (A - 1 - i);
-        if (S::aw_word(c, d) != S::aw_word(c, d - 1)) w = fetch(S::aw_word(c, d));
-        const uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(i + 1);
-        w = (uint32_t)p;
-        nibble_swap(order, i, (int)(uint32_t)(p >> 32));
+    for (int q = 0; q < NW; q++) R[q] = k80; // agent 0 at slot 0; the other bytes are overwritten when their agent is placed
+#pragma unroll
+    for (int k = 1; k < 4 * NW; k++) {
+        if (k < A) { // (a guard, not a break: the loop must unroll completely -- R[] is indexed statically)
+            const int d = A + k - 1; // draw number
+            if (S::aw_word(c, d) != S::aw_word(c, d - 1)) w = fetch(S::aw_word(c, d));
+            const uint64_t p = (uint64_t)w * (uint64_t)(uint32_t)(k + 1);
+            w = (uint32_t)p;
+            const uint32_t slot = (uint32_t)(p >> 32);
+            const uint32_t sb = bcast_byte0(slot);
+#pragma unroll
+            for (int q = 0; q <= (k - 1) / 4; q++) R[q] += ((R[q] - sb) >> 7) & k01; // rank >= slot: one up (bytes of agents not placed yet are rewritten below)
+            // byte k % 4 of word k / 4 := slot | 0x80
+            const uint32_t sel = 0x03020100u ^ ((0x04u ^ (uint32_t)(k & 3)) << (8 * (k & 3))); // identity selector, position k & 3 takes byte 0 of the first operand
+            R[k / 4] = __builtin_amdgcn_perm(slot | 0x80u, R[k / 4], sel);
+        }
+    }
+    as.rem = w;
+}
+
+// turn order (4 bits per turn: order[rank[i]] = i) from the packed ranks -- what the per-turn kernels walk
+template <class S, class ORD, int NW>
+__device__ __forceinline__ void order_from_ranks(const Consts &c, const uint32_t (&R)[NW], ORD &order) {
+    const int A = S::A(c);
+    order = 0;
+#pragma unroll
+    for (int i = 0; i < 4 * NW; i++) {
+        if (i < A) {
+            const uint32_t r = (R[i / 4] >> (8 * (i & 3))) & 0x7fu;
+            order |= (ORD)i << (4u * r);
+        }
     }
 }
+constexpr int rank_words(int A) { return A > 0 ? (A + 3) / 4 : SUSNET_MAX_AGENTS / 4; }
 
 // ---------------------------------------------------------------------------------------------------
 // step

@@ -9,6 +9,7 @@
 
 #include "susnet_device.h"
 #include "susnet_obs.h"
+#include "susnet_swar.h"
 
 namespace susnet {
 
@@ -95,16 +96,61 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
 #pragma unroll
         for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
         RNG rng = make_rng<RNG>(c, s, b);
-        bool done, trunc;
-        OrderOf<S> ord = (OrderOf<S>)0xFEDCBA9876543210ull;
-        if constexpr (!RNG::kNumpy) {
-            if (S::order_random(c)) {
-                ActionStream as;
-                as.init();
-                order_from_stream<S>(c, e, rng, as, c.dev_tick ? *s.dev_tick : a.tick, false, ord);
+        bool done = false, trunc = false;
+        uint32_t bits = 0;
+        if constexpr (UseSwar<S>::value) {
+            // the index-order byte-parallel step (susnet_swar.h): validate like base.py:357-362 / 379-382, then repack
+            using W = Swar<S>;
+            const uint32_t space_n = 8u;
+#pragma unroll
+            for (int i = 0; i < A; i++) {
+                const int32_t ai = (int32_t)st.act(i);
+                if (ai >= (int32_t)space_n) bits |= SUSNET_ERRBIT_ASSERT;
+                else if (ai < 0 || (uint32_t)ai >= n_actions<S>(c, (S::imp(c, e.imp) >> i) & 1u)) bits |= SUSNET_ERRBIT_INDEX;
             }
+            if (bits) {
+                for (int i = 0; i < A; i++) a.rewards.put(i, b, 0.0f);
+            } else {
+                W w;
+                to_swar<S>(c, st, e, w);
+                uint32_t act[W::NW], R[W::NW];
+#pragma unroll
+                for (int q = 0; q < W::NW; q++) act[q] = 0;
+#pragma unroll
+                for (int i = 0; i < A; i++) act[i / 4] |= (st.act(i) & 0xffu) << (8 * (i & 3));
+                clear_info_if_fresh(e);
+                identity_ranks<S>(R);
+                if (S::order_random(c)) {
+                    if constexpr (RNG::kNumpy) {
+                        OrderOf<S> ord = (OrderOf<S>)0xFEDCBA9876543210ull;
+                        rng.align();
+                        shuffle_nibbles<false>(rng, ord, A); // base.py:372-374
+                        ranks_from_order<S>(ord, R);
+                    } else {
+                        ActionStream as;
+                        as.init();
+                        ranks_from_stream<S>(c, S::imp(c, e.imp), rng, as, c.dev_tick ? *s.dev_tick : a.tick, false, R);
+                    }
+                }
+                float rr[W::A];
+                step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc);
+                from_swar<S>(c, w, st, e);
+#pragma unroll
+                for (int i = 0; i < A; i++) a.rewards.put(i, b, rr[i]);
+            }
+        } else {
+            OrderOf<S> ord = (OrderOf<S>)0xFEDCBA9876543210ull;
+            if constexpr (!RNG::kNumpy) {
+                if (S::order_random(c)) {
+                    ActionStream as;
+                    as.init();
+                    uint32_t R[rank_words(S::kA)];
+                    ranks_from_stream<S>(c, S::imp(c, e.imp), rng, as, c.dev_tick ? *s.dev_tick : a.tick, false, R);
+                    order_from_ranks<S>(c, R, ord);
+                }
+            }
+            bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc, nullptr, ord);
         }
-        uint32_t bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc, nullptr, ord);
         if (bits) atomicOr(s.err, bits);
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
@@ -220,11 +266,22 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         tprev = __builtin_readcyclecounter();
 #endif
         STAMP(0);
+        // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index -- nothing loop-carried (loop-carried
+        // scalar offsets ended up in vector registers, every store inside a waterfall loop)
+        if (kTraj) {
+            const uint32_t t32 = (uint32_t)tick;
+            da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
+        }
+        if (kRec) drec.so = (uint32_t)tick * slab_rec;
         if (active) {
             sample_actions_env<S, PAR>(c, st, e, rng, as, tick_base + (uint64_t)tick);
             // shuffled order: the tick's shuffle draws follow its action draws in the stream
             OrderOf<S> ow = (OrderOf<S>)0xFEDCBA9876543210ull;
-            if (S::order_random(c)) order_from_stream<S, PAR>(c, e, rng, as, tick_base + (uint64_t)tick, true, ow);
+            if (S::order_random(c)) {
+                uint32_t R[rank_words(S::kA)];
+                ranks_from_stream<S, PAR>(c, S::imp(c, e.imp), rng, as, tick_base + (uint64_t)tick, true, R);
+                order_from_ranks<S>(c, R, ow);
+            }
             STAMP(1);
             uint32_t av[S::kA > 0 ? S::kA : 1];
             float rr[S::kA > 0 ? S::kA : 1];
@@ -315,10 +372,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 store_row_u8<(kRawF > 0 ? kRawF : 1)>(dobs, rv);
             }
         }
-        if (kTraj) { // wave-uniform: next tick's slabs
-            da.so += slab_a; dr.so += 4u * slab_a; dd.so += slab_d; dt.so += slab_d; dobs.so += slab_o;
-        }
-        if (kRec) drec.so += slab_rec;
         STAMP(6);
     };
     // The action stream is walked in GROUPS of ticks that start on a Philox block boundary: 4 ticks (4 * W words) when the
@@ -350,10 +403,147 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     }
 }
 
+// N consecutive bytes (packed four to a word) at a row destination: widest naturally-splitting stores
+template <int N, class D>
+__device__ __forceinline__ void store_packed_bytes(const D &d, const uint32_t *w) {
+    constexpr int kW = N / 4;
+    if (kW >= 4) {
+#pragma unroll
+        for (int k = 0; k + 4 <= kW; k += 4) d.st128(4u * k, w[k], w[k + 1], w[k + 2], w[k + 3]);
+    }
+    constexpr int k4 = kW / 4 * 4;
+    if (kW - k4 >= 2) d.st64(4u * k4, w[k4], w[k4 + 1]);
+    if ((kW - k4) & 1) d.st32(4u * (kW - 1), w[kW - 1]);
+    if ((N & 3) >= 2) d.st16(4u * kW, w[kW] & 0xffffu);
+    if (N & 1) d.st8((uint32_t)(N - 1), (w[kW] >> (8 * ((N & 3) - 1))) & 0xffu);
+}
+
+// Fused random rollout of the byte-parallel (SWAR) configurations: the same contract as k_rollout, the state held as
+// packed bytes (susnet_swar.h) for the whole launch.  OUT_RECORD is not offered for these configurations.
+template <class S, int OUT>
+__global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, RolloutArgs a, ObsArgs o) {
+    using W = Swar<S>;
+    constexpr int A = W::A, NW = W::NW;
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x;
+    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3; // XCD-aware mapping (see k_rollout)
+    const uint32_t per = nblk >> 3, rem = nblk & 7u;
+    const uint32_t wave_id = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    const int64_t b0 = (int64_t)wave_id * c.epw, b = b0 + tid;
+    const bool active = tid < c.epw && b < c.B;
+    const int nrows = (int)((c.B - b0) < c.epw ? (c.B - b0) : c.epw);
+    typename StoreFor<S>::type st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
+    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    wave_lds_fence();
+    Env e = {};
+    PhiloxRng rng;
+    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
+    ActionStream as;
+    as.init();
+    if (active) {
+        load_env<S>(c, s, st, b, e);
+        rng.cur = s.rng[b];
+    }
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
+    if ((kTraj || OUT == OUT_NONE) && !active) return; // no cooperative work past this point in these modes
+    W w;
+    to_swar<S>(c, st, e, w);
+    uint64_t tick_base = a.tick_base;
+    if (c.dev_tick) {
+        const uint64_t t = *s.dev_tick;
+        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
+    }
+    LifeAcc life;
+    life.clear();
+    const int64_t AB = (int64_t)A * c.B;
+    const int64_t bb = active ? b : 0;
+    uint8_t *pa = a.actions ? a.actions + bb * A : nullptr;
+    float *pr = a.rewards ? a.rewards + bb * A : nullptr;
+    uint8_t *pd = a.done ? a.done + bb : nullptr;
+    uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
+    constexpr int kRawF = S::kRawF;
+    const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+    BufDst da = make_buf_dst(a.actions, nt * (uint64_t)AB, (uint32_t)(bb * A));
+    BufDst dr = make_buf_dst(a.rewards, nt * (uint64_t)AB * 4u, (uint32_t)(bb * A) * 4u);
+    BufDst dd = make_buf_dst(a.done, nt * (uint64_t)c.B, (uint32_t)bb);
+    BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
+    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * kRawF));
+    const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
+    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
+        constexpr int POS = decltype(par)::value;
+        if (kTraj) { // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index, nothing loop-carried
+            const uint32_t t32 = (uint32_t)tick;
+            da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
+        }
+        if (active) {
+            uint32_t act[NW], R[NW];
+            sample_actions_swar<S, POS>(c, w, rng, as, tick_base + (uint64_t)tick, act);
+            if (S::kOrd > 0) ranks_from_stream<S, POS>(c, 0u, rng, as, tick_base + (uint64_t)tick, true, R);
+            else identity_ranks<S>(R);
+            if (kTraj) store_packed_bytes<A>(da, act);
+            else if (OUT == OUT_ANY && pa != nullptr) store_packed_bytes<A>(PtrDst{pa}, act);
+            float rr[A];
+            bool done, trunc;
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc);
+            if (kTraj) {
+                store_row_f32<A>(dr, rr);
+                dd.st8(0u, done ? 1u : 0u);
+                dt.st8(0u, trunc ? 1u : 0u);
+            } else if (OUT == OUT_ANY) {
+                if (pr != nullptr) store_row_f32<A>(PtrDst{reinterpret_cast<uint8_t *>(pr)}, rr);
+                if (pd != nullptr) *pd = done ? 1 : 0;
+                if (pt != nullptr) *pt = trunc ? 1 : 0;
+            }
+            if (__builtin_expect(done || trunc, 0)) {
+                life.add_episode(e, trunc);
+                reset_env<S>(c, T, st, tid, e, rng);
+                to_swar<S>(c, st, e, w);
+                // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed
+                if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+                else zero_metrics(e);
+            }
+            if (OUT == OUT_TRAJ_RAW8) {
+                uint32_t row[(kRawF + 3) / 4];
+                raw_row_swar<S>(w, row);
+                store_packed_bytes<kRawF>(dobs, row);
+            }
+            if (OUT == OUT_ANY) {
+                pa = pa ? pa + AB : pa;
+                pr = pr ? pr + AB : pr;
+                pd = pd ? pd + c.B : pd;
+                pt = pt ? pt + c.B : pt;
+            }
+        }
+        if (OUT == OUT_ANY) { // any observation mode: through the cooperative writer, on the bitmask / packed-store form
+            if (active) from_swar<S>(c, w, st, e);
+            write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        }
+    };
+    constexpr int kGroup = OUT == OUT_ANY ? 0 : 4; // groups of 4 ticks start on a Philox block boundary of the action stream
+    int tick = 0;
+    while (tick < a.n_ticks) {
+        if (kGroup > 0 && tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) & 3ull) == 0ull) {
+            static_for<0, (kGroup > 0 ? kGroup : 1)>([&](auto pos) __attribute__((always_inline)) { tick_body(tick + decltype(pos)::value, pos); });
+            tick += kGroup;
+        } else {
+            tick_body(tick, std::integral_constant<int, -1>{});
+            tick++;
+        }
+    }
+    if (active) {
+        from_swar<S>(c, w, st, e);
+        store_env<S>(c, s, st, b, e, true);
+        s.rng[b] = rng.cur;
+        life.flush(c, s, b);
+    }
+}
+
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
 using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>; // ImposterTrainingGround 1v1, no jobs, fixed order, imposter = agent 0 (any wall map)
-using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 1v2, 4 jobs, random order
-using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1>; // FourRoomEnv 2v6, 4 jobs, random order
+using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1, -1, 1>; // FourRoomEnv 1v2, 4 jobs, random order (index-order SWAR step)
+using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1, -1, 2>; // FourRoomEnv 2v6, 4 jobs, random order (index-order SWAR step)
 using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
 // agent count compiled in, everything else read at run time (any variant / order / up to 8 jobs): the packed-VGPR
 // tables without a full specialisation
@@ -365,13 +555,20 @@ template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
 // ---------------------------------------------------------------------------------------------------
 template <class SPEC>
 void launch_rollout(int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
-    if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
-    else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
-    else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
-    else if (out == OUT_RECORD) {
-        // the packed record exists for configurations whose whole raw row is known at compile time
-        if constexpr (!SPEC::kGeneric && SPEC::kRawF > 0) hipLaunchKernelGGL((k_rollout<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
-    } else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
+    if constexpr (UseSwar<SPEC>::value) {
+        if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
+        else hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
+    } else {
+        if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_RECORD) {
+            // the packed record exists for configurations whose whole raw row is known at compile time
+            if constexpr (!SPEC::kGeneric && SPEC::kRawF > 0) hipLaunchKernelGGL((k_rollout<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
+        } else hipLaunchKernelGGL((k_rollout<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
+    }
 }
 // tape: the handle draws from caller-supplied words (numpy parity) instead of the production stream
 template <class SPEC>

@@ -1,0 +1,419 @@
+// susnet_swar.h -- index-order step for the compiled-in multi-agent games (3..8 agents, up to 4 jobs, FourRoomEnv /
+// ImposterTrainingGround rules): one lane per environment, every per-agent quantity a BYTE of a packed 32-bit word, the
+// whole step written as byte-parallel (SWAR) arithmetic over all agents at once.
+//
+// Reference behaviour (paths relative to the reference repo root):
+//   step             src/environment/base.py:332-407
+//   _agent_step      src/environment/base.py:462-533   (move / KILL / FIX / SABOTAGE)
+//   win conditions   src/environment/base.py:409-460, src/environment/pred_prey.py:78-99
+//   _merge_rewards   src/environment/base.py:553-563, zero fill 389-390
+//
+// Why the agent loop of base.py:377-382 can be evaluated in INDEX order although the reference walks a shuffled order:
+//   * a move depends on nothing but the agent's own cell and action (base.py:484-487);
+//   * FIX / SABOTAGE act on the agent's own (unmoved) cell; two agents only interact when they work on the SAME job in the
+//     same step (rare: resolved in turn order behind a wave-uniform branch);
+//   * KILL is the one real ordering point: the killer sees every other agent where it stands at the killer's turn (agents
+//     with an earlier turn have moved, later ones have not) and its victim, if its own turn comes later, never acts.
+//     At most n_imposters kills per step: they are resolved in turn order, each over all agents at once, using the
+//     agents' turn RANKS (rank[i] < rank[killer] <=> agent i has already acted).
+// Everything else (win check, reward merge, truncation) is order-free.
+#pragma once
+
+#include "susnet_device.h"
+#include "susnet_obs.h"
+
+namespace susnet {
+
+template <class S>
+struct UseSwar {
+    static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kA <= 8 && S::kJ >= 0 && S::kJ <= 4 && S::kOrd >= 0 &&
+                                  (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG) && (S::kNI == 1 || S::kNI == 2);
+};
+
+// 0x80 flags -> 0xff bytes
+__device__ __forceinline__ uint32_t ff_from80(uint32_t m) { return (m - (m >> 7)) | m; }
+// 0x80 in every byte of x that is zero (exact, no cross-byte carries)
+__device__ __forceinline__ uint32_t zero80(uint32_t x) {
+    const uint32_t t = (x & k7f) + k7f;
+    return __builtin_amdgcn_bitop3_b32(t, x, k80, 0x02); // ~t & ~x & k80 (truth table index = t << 2 | x << 1 | k80)
+}
+// bytes of a where the 0xff mask m is set, else bytes of b
+__device__ __forceinline__ uint32_t sel_bytes(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+
+template <class S>
+struct Swar {
+    static constexpr int A = S::kA, J = S::kJ, NW = (S::kA + 3) / 4, NI = S::kNI > 0 ? S::kNI : 1;
+    static constexpr bool kBase = S::kVar == SUSNET_VARIANT_BASE;
+    static constexpr uint32_t kKillIdx = kBase ? 6u : 5u; // role-relative index of KILL (base.py:91-99 / pred_prey.py:12-19)
+    uint32_t xy[NW];           // cell x | y << 4, one byte per agent
+    uint32_t al[NW];           // alive: 0x01 per agent
+    uint32_t im80[NW];         // imposter: 0x80 per agent (constant within an episode)
+    uint32_t isel[NI];         // v_perm selector that extracts imposter s's byte (zeros elsewhere)
+    uint32_t ihot[NI][NW];     // 0x80 at imposter s's byte
+    uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes (constant within an episode)
+    uint32_t jobs_obs[2];      // x0 y0 x1 y1 | x2 y2 x3 y3 of the job cells (observation bytes; constant within an episode)
+    uint32_t jd;               // completed: 0x01 per job
+};
+
+// (Env bitmasks + packed store) -> byte-parallel form.  Runs once per launch and after each reset.
+template <class S, class Store>
+__device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const Env &e, Swar<S> &w) {
+    using W = Swar<S>;
+    const uint32_t imp = S::imp(c, e.imp);
+#pragma unroll
+    for (int q = 0; q < W::NW; q++) { w.xy[q] = 0; w.al[q] = 0; w.im80[q] = 0; }
+#pragma unroll
+    for (int s = 0; s < W::NI; s++) {
+        w.isel[s] = 0x0c0c0c0cu;
+#pragma unroll
+        for (int q = 0; q < W::NW; q++) w.ihot[s][q] = 0;
+    }
+    uint32_t seen = 0; // imposters met so far (ascending agent index)
+#pragma unroll
+    for (int i = 0; i < W::A; i++) {
+        const int q = i / 4, sh = 8 * (i & 3);
+        w.xy[q] |= st.xy(i) << sh;
+        w.al[q] |= ((e.alive >> i) & 1u) << sh;
+        const uint32_t is = (imp >> i) & 1u;
+        w.im80[q] |= (is << 7) << sh;
+#pragma unroll
+        for (int s = 0; s < W::NI; s++) {
+            const bool mine = is && seen == (uint32_t)s;
+            w.isel[s] = mine ? (0x0c0c0c00u | (uint32_t)i) : w.isel[s]; // byte i of {word 1, word 0} -> byte 0
+            w.ihot[s][q] |= mine ? (0x80u << sh) : 0u;
+        }
+        seen += is;
+    }
+    w.jd = 0;
+    w.jobs_obs[0] = w.jobs_obs[1] = 0;
+#pragma unroll
+    for (int j = 0; j < W::J; j++) {
+        const uint32_t cell = st.job(j);
+        w.jb[j] = cell * k01;
+        w.jd |= ((e.jd >> j) & 1u) << (8 * j);
+        w.jobs_obs[j / 2] |= ((cell & 15u) | ((cell >> 4) << 8)) << (16 * (j & 1));
+    }
+}
+
+template <class S, class Store>
+__device__ __forceinline__ void from_swar(const Consts &c, const Swar<S> &w, Store &st, Env &e) {
+    using W = Swar<S>;
+    e.alive = 0;
+    e.jd = 0;
+#pragma unroll
+    for (int i = 0; i < W::A; i++) {
+        const int q = i / 4, sh = 8 * (i & 3);
+        st.set_xy(i, (w.xy[q] >> sh) & 0xffu);
+        e.alive |= ((w.al[q] >> sh) & 1u) << i;
+    }
+#pragma unroll
+    for (int j = 0; j < W::J; j++) e.jd |= ((w.jd >> (8 * j)) & 1u) << j;
+}
+
+// imposter flag (0 / 1) of agent i
+template <class S>
+__device__ __forceinline__ uint32_t swar_is_imp(const Swar<S> &w, int i) { return (w.im80[i / 4] >> (8 * (i & 3) + 7)) & 1u; }
+template <class S>
+__device__ __forceinline__ uint32_t swar_imp_bits(const Swar<S> &w) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < Swar<S>::A; i++) m |= swar_is_imp(w, i) << i;
+    return m;
+}
+
+// base.py:326-330 on the production stream (see sample_actions_env): the action bytes, packed like every per-agent value
+template <class S, int POS = -1>
+__device__ __forceinline__ void sample_actions_swar(const Consts &c, const Swar<S> &w, PhiloxRng &rng, ActionStream &as, uint64_t tick,
+                                                    uint32_t (&act)[Swar<S>::NW]) {
+    using W = Swar<S>;
+    const uint64_t Wt = (uint64_t)S::kAw.W;
+    uint32_t word = 0;
+#pragma unroll
+    for (int q = 0; q < W::NW; q++) act[q] = 0;
+#pragma unroll
+    for (int i = 0; i < W::A; i++) {
+        const int k = S::kAw.word[i];
+        if (i == 0 || k != S::kAw.word[i - 1])
+            word = POS >= 0 ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * Wt, (POS >= 0 ? POS : 0) * S::kAw.W + k)
+                            : as.word(rng, tick * Wt + (uint64_t)k);
+        const uint64_t p = (uint64_t)word * (uint64_t)(S::nr_crew(c) + swar_is_imp(w, i)); // imposters have one more action
+        act[i / 4] |= (uint32_t)(p >> 32) << (8 * (i & 3));
+        word = (uint32_t)p;
+    }
+    as.rem = word;
+}
+template <class S>
+__device__ __forceinline__ void sample_actions_swar(const Consts &c, const Swar<S> &w, TapeRng &rng, uint32_t (&act)[Swar<S>::NW]) {
+    using W = Swar<S>;
+#pragma unroll
+    for (int q = 0; q < W::NW; q++) act[q] = 0;
+#pragma unroll
+    for (int i = 0; i < W::A; i++) act[i / 4] |= rng.bounded(S::nr_crew(c) + swar_is_imp(w, i)) << (8 * (i & 3));
+}
+
+// ranks (byte = rank | 0x80) from a turn order (4 bits per turn): the numpy-parity path shuffles an order list
+template <class S, class ORD>
+__device__ __forceinline__ void ranks_from_order(ORD order, uint32_t (&R)[Swar<S>::NW]) {
+    using W = Swar<S>;
+    uint64_t r = 0;
+#pragma unroll
+    for (int k = 0; k < W::A; k++) r |= (uint64_t)(0x80u | (uint32_t)k) << (8u * nibble(order, k));
+    R[0] = (uint32_t)r;
+    if (W::NW > 1) R[W::NW - 1] = (uint32_t)(r >> 32);
+}
+template <class S>
+__device__ __forceinline__ void identity_ranks(uint32_t (&R)[Swar<S>::NW]) {
+    R[0] = 0x83828180u;
+    if (Swar<S>::NW > 1) R[Swar<S>::NW - 1] = 0x87868584u;
+}
+
+// One step.  act: role-relative action bytes (valid for their roles); R: turn ranks (byte = rank | 0x80).
+// Rewards go to rr[] (float32: the compiled-in kernels are only selected when every reward constant is float-exact).
+template <class S, class RNG>
+__device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar<S> &w, Env &e, RNG &rng, const uint32_t (&act)[Swar<S>::NW],
+                                          const uint32_t (&R)[Swar<S>::NW], float (&rr)[Swar<S>::A], bool &done, bool &trunc) {
+    using W = Swar<S>;
+    constexpr int A = W::A, J = W::J, NW = W::NW, NI = W::NI;
+    constexpr uint32_t kLive[2] = {A >= 4 ? 0xffffffffu : (1u << (8 * (A & 3))) - 1u, A >= 8 ? 0xffffffffu : (A > 4 ? (1u << (8 * (A & 3))) - 1u : 0u)};
+    e.m_steps += 1; // base.py:366
+    rng.align();
+
+    // ---- action classes (0x80 per agent): alive agents only (base.py:477) --------------------------------------------------
+    uint32_t al80[NW], kill80[NW], fix80[NW], sab80[NW], mv80[NW], rows[NW];
+#pragma unroll
+    for (int q = 0; q < NW; q++) {
+        const uint32_t a = act[q];
+        const uint32_t g5 = (a + 0x7b7b7b7bu) & k80, g6 = (a + 0x7a7a7a7au) & k80; // action index >= 5 / >= 6
+        al80[q] = (w.al[q] << 7) & kLive[q] & k80;
+        if (W::kBase) { // crew: 5 = FIX; imposter: 5 = SABOTAGE, 6 = KILL (base.py:82-99)
+            kill80[q] = g6 & al80[q];
+            const uint32_t j5 = g5 & ~g6 & al80[q];
+            sab80[q] = j5 & w.im80[q];
+            fix80[q] = j5 & ~w.im80[q];
+        } else { // pred_prey.py:4-19: imposter 5 = KILL, no job actions
+            kill80[q] = g5 & al80[q];
+            sab80[q] = fix80[q] = 0;
+        }
+        mv80[q] = ~g5 & al80[q];
+        rows[q] = a - (g6 >> 7); // row of the (action, cell) table: 0..4 = the move actions, 5 = identity (KILL index 6 -> 5)
+    }
+    // ---- destinations: one lookup per agent in the (action, cell) table (move() + _is_valid_position(), base.py:69-79, 548-551)
+    uint32_t dest[NW];
+    {
+        uint32_t d[A];
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            // address = row << 8 | cell: byte i of `rows` and of `xy`
+            const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(i & 3)) << 8) | (uint32_t)(i & 3);
+            d[i] = T.move[__builtin_amdgcn_perm(rows[i / 4], w.xy[i / 4], sel)];
+        }
+#pragma unroll
+        for (int q = 0; q < NW; q++) dest[q] = 0;
+#pragma unroll
+        for (int i = 0; i < A; i++) dest[i / 4] |= d[i] << (8 * (i & 3));
+    }
+    // positions if every living mover moved (kills below may cancel a victim's move)
+    uint32_t newt[NW];
+#pragma unroll
+    for (int q = 0; q < NW; q++) newt[q] = sel_bytes(ff_from80(mv80[q]), dest[q], w.xy[q]);
+
+    // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
+    uint32_t kc80[NW], pend80[NW]; // killers that landed a kill; victims killed before their own turn
+#pragma unroll
+    for (int q = 0; q < NW; q++) kc80[q] = pend80[q] = 0;
+    {
+        uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot: kill flag (0x80 / 0), rank | 0x80, cell
+#pragma unroll
+        for (int s = 0; s < NI; s++) {
+            const uint32_t hi = NW > 1 ? NW - 1 : 0;
+            kb[s] = __builtin_amdgcn_perm(NW > 1 ? kill80[hi] : 0u, kill80[0], w.isel[s]);
+            rb[s] = __builtin_amdgcn_perm(NW > 1 ? R[hi] : 0u, R[0], w.isel[s]);
+            cb[s] = __builtin_amdgcn_perm(NW > 1 ? w.xy[hi] : 0u, w.xy[0], w.isel[s]);
+        }
+        bool second_first = false; // two imposters: the one with the earlier turn kills first
+        if (NI == 2) second_first = kb[1] != 0u && (kb[0] == 0u || rb[1] < rb[0]);
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+            const int s0 = it, s1 = NI - 1 - it; // slot if the natural order holds / if it is swapped
+            const uint32_t kbi = second_first ? kb[s1] : kb[s0], rbi = second_first ? rb[s1] : rb[s0], cbi = second_first ? cb[s1] : cb[s0];
+            const bool attempt = kbi != 0u;
+            if (__builtin_amdgcn_ballot_w64(attempt) != 0ull) {
+                const uint32_t tb = bcast_byte0(rbi & 0x7fu), cbb = bcast_byte0(cbi);
+                uint32_t ge80[NW], cand[NW];
+                uint32_t nc = 0;
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    ge80[q] = (R[q] - tb) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
+                    const uint32_t pos = sel_bytes(ff_from80(ge80[q]), w.xy[q], newt[q]);
+                    const uint32_t crew80 = (w.al[q] << 7) & ~w.im80[q] & kLive[q]; // living crew NOW (base.py:535-542)
+                    cand[q] = attempt ? (zero80(pos ^ cbb) & crew80) : 0u;
+                    nc += (uint32_t)__popc(cand[q]);
+                }
+                uint32_t r = 0; // base.py:497: uniform among the candidates, ascending agent index
+                if (RNG::kNumpy) {
+                    if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc); // numpy draws nothing for a single candidate
+                } else { // production protocol: one word per kill, its value only matters with several candidates
+                    if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc);
+                    else rng.cur += (nc == 1u) ? 1ull : 0ull;
+                }
+                uint32_t v80[NW]; // the victim: r-th candidate
+                {
+                    uint32_t c0 = cand[0], c1 = NW > 1 ? cand[NW - 1] : 0u;
+                    for (uint32_t k = 0; k < r; k++) { // (rare: several candidates)
+                        const bool lo = c0 != 0u;
+                        c0 = lo ? (c0 & (c0 - 1u)) : c0;
+                        c1 = lo ? c1 : (c1 & (c1 - 1u));
+                    }
+                    v80[0] = c0 & (0u - c0);
+                    if (NW > 1) v80[NW - 1] = c0 != 0u ? 0u : (c1 & (0u - c1));
+                }
+                const bool hit = nc != 0u;
+                e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    w.al[q] &= ~(v80[q] >> 7);                                      // base.py:511
+                    const uint32_t hot = second_first ? w.ihot[s1][q] : w.ihot[s0][q];
+                    kc80[q] |= hit ? hot : 0u;                                      // base.py:514-515 (the victim's slot ends as dead_penalty)
+                    pend80[q] |= v80[q] & ge80[q];                                  // killed before its own turn: it never acts
+                }
+            }
+        }
+    }
+    // final positions: a victim that had not acted yet stays where it was
+#pragma unroll
+    for (int q = 0; q < NW; q++) w.xy[q] = sel_bytes(ff_from80(pend80[q]), w.xy[q], newt[q]);
+
+    // ---- FIX (base.py:518-524) / SABOTAGE (527-533): first job on the agent's own cell (544-546; job cells are distinct) ------
+    uint32_t fc80[NW], sc80[NW];
+#pragma unroll
+    for (int q = 0; q < NW; q++) fc80[q] = sc80[q] = 0;
+    if (W::kBase && J > 0) {
+        uint32_t ja80[NW], xy0[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            ja80[q] = (fix80[q] | sab80[q]) & ~pend80[q];
+            // job actors did not move: w.xy is still their cell (movers are excluded by ja80)
+            xy0[q] = w.xy[q];
+        }
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            uint32_t on[NW];
+            uint32_t any = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                on[q] = zero80(xy0[q] ^ w.jb[j]) & ja80[q];
+                any |= on[q];
+            }
+            if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int q = 0; q < NW; q++) cnt += (uint32_t)__popc(on[q]);
+                uint32_t dj = (w.jd >> (8 * j)) & 1u;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt > 1u) != 0ull, 0)) {
+                    // several agents work on this job in one step: in turn order (base.py:377-382)
+                    for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
+                        const uint32_t tb = (turn | 0x80u) * k01;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) {
+                            const uint32_t me = zero80(R[q] ^ tb) & on[q]; // the actor whose turn it is, if it works on this job
+                            const bool is_sab = (me & w.im80[q]) != 0u, is_fix = (me & ~w.im80[q]) != 0u;
+                            const bool f = is_fix && dj == 0u, sb = is_sab && dj != 0u;
+                            dj = f ? 1u : (sb ? 0u : dj);
+                            e.m_fix += f ? 1u : 0u;
+                            e.m_sab += sb ? 1u : 0u;
+                            fc80[q] |= f ? me : 0u;
+                            sc80[q] |= sb ? me : 0u;
+                        }
+                    }
+                } else {
+                    uint32_t imp_on = 0;
+#pragma unroll
+                    for (int q = 0; q < NW; q++) imp_on |= on[q] & w.im80[q];
+                    const bool f = any != 0u && imp_on == 0u && dj == 0u, sb = imp_on != 0u && dj != 0u;
+                    dj = f ? 1u : (sb ? 0u : dj);
+                    e.m_fix += f ? 1u : 0u;
+                    e.m_sab += sb ? 1u : 0u;
+#pragma unroll
+                    for (int q = 0; q < NW; q++) {
+                        fc80[q] |= f ? on[q] : 0u;
+                        sc80[q] |= sb ? on[q] : 0u;
+                    }
+                }
+                w.jd = (w.jd & ~(1u << (8 * j))) | (dj << (8 * j));
+            }
+        }
+    }
+
+    // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
+    uint32_t wsel = 0; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
+    {
+        int alive_imp = 0, alive_all = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            alive_all += __popc(w.al[q] & kLive[q] & k01);
+            alive_imp += __popc((w.al[q] << 7) & w.im80[q] & kLive[q]);
+        }
+        const int done_jobs = __popc(w.jd);
+        done = false;
+        if (!W::kBase) {
+            if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; wsel = 16u; }
+            else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; wsel = 32u; }
+        } else {
+            if (alive_imp == 0 || done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; wsel = 16u; }
+            else if (alive_all - alive_imp <= alive_imp) { done = true; e.flags |= FLAG_IMP_WON; wsel = 32u; }
+        }
+    }
+    // ---- rewards: assignments -> _merge_rewards (base.py:553-563) -> zero fill (389-390), one lookup per agent in the
+    // host-evaluated table [win][index < n_imposters][dead][assignment code]; byte = 4 * table index
+    {
+        uint32_t idx4[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const uint32_t code4 = (kc80[q] >> 5) | (fc80[q] >> 4) | (sc80[q] >> 5) | (sc80[q] >> 4); // RC_KILL 1, RC_FIX 2, RC_SAB 3, times 4
+            const uint32_t dead16 = ((w.al[q] & k01) ^ k01) << 4;
+            // indices [:n_imposters], NOT the imposter mask (base.py:559)
+            constexpr uint32_t neg32[2] = {(NI >= 1 ? 0x20u : 0u) | (NI >= 2 ? 0x2000u : 0u), 0u};
+            idx4[q] = code4 + dead16 + neg32[q > 0 ? 1 : 0] + (wsel << 2) * k01;
+        }
+#pragma unroll
+        for (int i = 0; i < A; i++) rr[i] = *reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(T.rew) + ((idx4[i / 4] >> (8 * (i & 3))) & 0xffu));
+    }
+    // base.py:392-395: t saturates at max_time_steps - 1
+    trunc = false;
+    if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;
+    else e.t += 1u;
+}
+
+// flatten_state (base.py:234-235) of the byte-parallel state as packed dwords: positions, alive, job cells, job status
+template <class S>
+__device__ __forceinline__ void raw_row_swar(const Swar<S> &w, uint32_t (&row)[(S::kRawF + 3) / 4]) {
+    using W = Swar<S>;
+    constexpr int A = W::A, J = W::J, F = S::kRawF;
+    uint8_t b[(F + 3) / 4 * 4];
+    // assembled bytewise from a handful of words; the compiler folds the static byte moves into v_perm / shifts
+    uint32_t pos[2 * W::NW];
+#pragma unroll
+    for (int q = 0; q < W::NW; q++) {
+        const uint32_t x = w.xy[q] & 0x0f0f0f0fu, y = (w.xy[q] >> 4) & 0x0f0f0f0fu;
+        pos[2 * q] = __builtin_amdgcn_perm(y, x, 0x05010400u);     // x0 y0 x1 y1
+        pos[2 * q + 1] = __builtin_amdgcn_perm(y, x, 0x07030602u); // x2 y2 x3 y3
+    }
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 2 * A; i++) b[k++] = (uint8_t)(pos[i / 4] >> (8 * (i & 3)));
+#pragma unroll
+    for (int i = 0; i < A; i++) b[k++] = (uint8_t)((w.al[i / 4] >> (8 * (i & 3))) & 1u);
+    if (J > 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * J; i++) b[k++] = (uint8_t)(w.jobs_obs[i / 4] >> (8 * (i & 3)));
+#pragma unroll
+        for (int j = 0; j < J; j++) b[k++] = (uint8_t)((w.jd >> (8 * j)) & 1u);
+    }
+#pragma unroll
+    for (; k < (F + 3) / 4 * 4; k++) b[k] = 0;
+#pragma unroll
+    for (int d = 0; d < (F + 3) / 4; d++)
+        row[d] = (uint32_t)b[4 * d] | ((uint32_t)b[4 * d + 1] << 8) | ((uint32_t)b[4 * d + 2] << 16) | ((uint32_t)b[4 * d + 3] << 24);
+}
+
+} // namespace susnet

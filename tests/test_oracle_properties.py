@@ -219,7 +219,7 @@ def test_large_games_keep_every_word_below_the_bias_cap(oracle_mod):
     env0 = ob.envs[0]
     A = 12
     words = list(env0.aw_word[:2 * A - 1])
-    ranges = [7] * A + list(range(A, 1, -1))
+    ranges = [7] * A + list(range(2, A + 1))  # action draws, then the placement draws k = 1 .. A-1 (range k + 1)
     assert words == sorted(words) and words[0] == 0 and env0.aw_W == words[-1] + 1 and env0.aw_tpw == 1
     for k in range(env0.aw_W):
         prod = 1
