@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -391,6 +392,20 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
                     c.rew_tab[t * 16 + neg * 8 + dd * 4 + code] = (float)r;
                 }
     c.seed = cfg->seed; c.env_id_base = cfg->env_id_base;
+    { // 1v1 ImposterTrainingGround on a grid without walls, every reachable reward an integer in [-127, 127]: susnet_duel.h
+        bool ok = e->float_exact && A == 2 && J == 0 && cfg->variant == SUSNET_VARIANT_ITG && !c.shuffle_imp && c.n_valid == N * N;
+        c.duel_lut[0] = c.duel_lut[1] = 0;
+        for (int idx = 0; idx < 8 && ok; idx++) {
+            const int hit = idx & 1, dead0 = (idx >> 1) & 1, dead1 = (idx >> 2) & 1;
+            const int t = dead1 ? 2 : 0; // no jobs: only the imposter can win, when no crew member is alive (pred_prey.py:94-97)
+            const float r[2] = {c.rew_tab[t * 16 + 8 + dead0 * 4 + (hit ? (int)RC_KILL : 0)], c.rew_tab[t * 16 + 0 + dead1 * 4 + (hit ? (int)RC_KILL : 0)]};
+            for (int a = 0; a < 2; a++) {
+                if (!(r[a] >= -127.0f && r[a] <= 127.0f && r[a] == (float)(int)r[a]) || (r[a] == 0.0f && std::signbit(r[a]))) ok = false;
+                else c.duel_lut[a] |= (uint64_t)(uint8_t)(int8_t)(int)r[a] << (8 * idx);
+            }
+        }
+        c.duel_fast = ok ? 1 : 0;
+    }
 
     // state blob layout (every array 256-byte aligned; row stride Bp)
     uint64_t off = 0;
@@ -665,7 +680,7 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
 extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream) {
     if (int rc = check_bound(env)) return rc;
     if (!io || io->n_ticks < 1) return fail(SUSNET_E_INVALID, "n_ticks must be >= 1");
-    if (env->cfg.rng_mode != SUSNET_RNG_PHILOX) return fail(SUSNET_E_INVALID, "susnet_rollout needs the PHILOX stream");
+    const bool tape = env->cfg.rng_mode == SUSNET_RNG_TAPE;
     RolloutArgs a;
     a.n_ticks = io->n_ticks;
     a.tick_base = env->ticks;
@@ -678,6 +693,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
     const int spec = pick_spec(env->c, env->float_exact);
+    if (a.record && tape) return fail(SUSNET_E_INVALID, "susnet_rollout: no packed record on a TAPE handle");
     if (a.record) {
         if (a.actions || a.rewards || a.done || a.trunc || o.mode != SUSNET_OBS_NONE)
             return fail(SUSNET_E_INVALID, "susnet_rollout: record is an alternative to the separate outputs, not an addition");
@@ -711,6 +727,8 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
                     : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
                                                             : OUT_ANY;
+    if (tape && out != OUT_TRAJ_RAW8)
+        return fail(SUSNET_E_INVALID, "susnet_rollout on a TAPE handle stores the full trajectory with the raw uint8 observation (nothing else)");
     const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);
@@ -724,18 +742,18 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             if (o.out) o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (uint64_t)o.tick_stride;
         }
         switch (spec) {
-        case 2: launch_rollout<SpecCfg2>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 3: launch_rollout<SpecCfg3>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 4: launch_rollout<SpecCfg4>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 6: launch_rollout<SpecTag5>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 12: launch_rollout<SpecA<2>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 13: launch_rollout<SpecA<3>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 14: launch_rollout<SpecA<4>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 15: launch_rollout<SpecA<5>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 16: launch_rollout<SpecA<6>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 17: launch_rollout<SpecA<7>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 18: launch_rollout<SpecA<8>>(out, g, blk, sh, st, env->c, env->s, a, o); break;
-        default: launch_rollout<GenericSpec>(out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 2: launch_rollout<SpecCfg2>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 3: launch_rollout<SpecCfg3>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 4: launch_rollout<SpecCfg4>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 6: launch_rollout<SpecTag5>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 12: launch_rollout<SpecA<2>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 13: launch_rollout<SpecA<3>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 14: launch_rollout<SpecA<4>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 15: launch_rollout<SpecA<5>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 16: launch_rollout<SpecA<6>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 17: launch_rollout<SpecA<7>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        case 18: launch_rollout<SpecA<8>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
+        default: launch_rollout<GenericSpec>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         }
         if (env->c.dev_tick) hipLaunchKernelGGL(k_bump_tick, dim3(1), dim3(1), 0, st, env->s.dev_tick, (uint64_t)a.n_ticks);
         HIP_TRY(hipGetLastError());

@@ -71,6 +71,9 @@ struct Consts {
     // assignments -> _merge_rewards -> zero fill (base.py:514-515,523,532,553-563,389-390) evaluated on the host
     float rew_tab[48];
     uint64_t seed, env_id_base;
+    // 1v1 no-walls fast path (susnet_duel.h): reward bytes over {kill landed, imposter dead, crew dead} per agent
+    uint64_t duel_lut[2];
+    int32_t duel_fast, duel_pad;
 };
 enum : int { RW_KILL = 0, RW_FIX = 1, RW_SAB = 2, RW_TSR = 3, RW_END = 4, RW_DEAD = 5, RW_VOTE = 6 };
 template <class RT> __device__ __forceinline__ RT rw(const Consts &c, int k);

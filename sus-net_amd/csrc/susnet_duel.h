@@ -1,0 +1,103 @@
+// susnet_duel.h -- the 1v1 ImposterTrainingGround game on a grid WITHOUT walls (BASELINE.json configs[1], the configuration
+// the headline metric is quoted on) as straight-line register arithmetic: no LDS lookup, no branch on the stepping path.
+//
+// Reference behaviour (paths relative to the reference repo root):
+//   ImposterTrainingGround          src/environment/pred_prey.py:20-99 (one imposter = agent 0, fixed order, no jobs here)
+//   step / _agent_step / move       src/environment/base.py:332-407, 462-533, 69-79, 548-551
+//   _merge_rewards + zero fill      src/environment/base.py:553-563, 389-390
+//
+// State of one environment (one lane): the four coordinates as bytes of ONE register, biased by +1 so that a step off the
+// grid shows up as a byte value 0 or n + 1 (never a borrow into the neighbouring byte):
+//   pq = (x0 + 1) | (y0 + 1) << 8 | (x1 + 1) << 16 | (y1 + 1) << 24
+// A move adds a signed byte from an 6-entry table selected by the action (v_perm: one instruction looks both agents' deltas
+// up); on a grid without walls _is_valid_position() only checks the bounds, so an invalid move is exactly "the changed
+// byte left [1, n]" and is undone bytewise.  Rewards: with both orders of events fixed (agent 0 acts first) a tick's
+// reward pair is a function of three bits {kill landed, imposter dead, crew dead}; the host evaluates the reference's
+// assign -> merge -> zero-fill chain for the 8 combinations per agent (from the same table the other kernels index in LDS)
+// and the kernel looks the result up in a byte table held in registers (selected only when all of them are integers in
+// [-127, 127]; otherwise the handle runs the table kernels).
+#pragma once
+
+#include "susnet_device.h"
+#include "susnet_obs.h"
+
+namespace susnet {
+
+struct Duel {
+    uint32_t pq;    // biased coordinates, see above
+    uint32_t al;    // bit 0 imposter alive, bit 1 crew member alive
+};
+
+// wave-uniform constants of a launch (scalar registers)
+struct DuelConsts {
+    uint32_t hi_probe;  // byte + hi_probe has bit 7 set  <=>  byte == n + 1   (0x7f - n in every byte)
+    uint32_t lut0_lo, lut0_hi, lut1_lo, lut1_hi; // reward bytes: index = kill landed | imposter dead << 1 | crew dead << 2
+    uint32_t max_t_m1;
+};
+__device__ __forceinline__ DuelConsts make_duel_consts(const Consts &c) {
+    DuelConsts k;
+    k.hi_probe = (0x7fu - (uint32_t)c.N) * k01;
+    k.lut0_lo = (uint32_t)c.duel_lut[0]; k.lut0_hi = (uint32_t)(c.duel_lut[0] >> 32);
+    k.lut1_lo = (uint32_t)c.duel_lut[1]; k.lut1_hi = (uint32_t)(c.duel_lut[1] >> 32);
+    k.max_t_m1 = (uint32_t)(c.max_t - 1);
+    return k;
+}
+
+template <class Store>
+__device__ __forceinline__ void to_duel(const Store &st, const Env &e, Duel &d) {
+    const uint32_t c0 = st.xy(0), c1 = st.xy(1);
+    d.pq = ((c0 & 15u) | ((c0 >> 4) << 8) | ((c1 & 15u) << 16) | ((c1 >> 4) << 24)) + k01;
+    d.al = e.alive & 3u;
+}
+template <class Store>
+__device__ __forceinline__ void from_duel(const Duel &d, Store &st, Env &e) {
+    const uint32_t p = d.pq - k01;
+    st.set_xy(0, (p & 15u) | (((p >> 8) & 15u) << 4));
+    st.set_xy(1, ((p >> 16) & 15u) | (((p >> 24) & 15u) << 4));
+    e.alive = d.al;
+}
+
+// One step with role-relative actions a0 in [0, 6) (5 = KILL, pred_prey.py:12-19) and a1 in [0, 5).
+// Out: rewards as float32 bit patterns, done, truncated.  e: t, flags, info counters; cur: the env's event-stream cursor
+// (production protocol: a landed kill takes one word -- its value is never needed with a single candidate).
+template <bool NUMPY>
+__device__ __forceinline__ void duel_step(const DuelConsts &k, Duel &d, Env &e, uint64_t &cur, uint32_t a0, uint32_t a1, float &r0, float &r1,
+                                          uint32_t &done, uint32_t &trunc) {
+    e.m_steps += 1; // base.py:366
+    // KILL first (agent 0 acts first, base.py:377-382 with a fixed order): both alive, same cell (base.py:490-515)
+    const uint32_t same = ((d.pq >> 16) == (d.pq & 0xffffu)) ? 1u : 0u;
+    const uint32_t hit = (a0 == 5u ? 1u : 0u) & same & (d.al == 3u ? 1u : 0u);
+    d.al &= ~(hit << 1);                 // base.py:511
+    e.m_kv += hit;                       // IMP_KILLED_CREW, base.py:508
+    if (!NUMPY) cur += (uint64_t)hit;    // (numpy draws nothing for a single candidate, base.py:497)
+    // moves (base.py:484-487): table of (dx, dy) per action -- STAY, UP (y + 1), DOWN, LEFT (x - 1), RIGHT, KILL (no move)
+    const uint32_t selx = a0 | (a1 << 16) | 0x0c000c00u;       // byte 0 <- table[a0], byte 2 <- table[a1]
+    // (v_perm: selector values 0..3 pick bytes of the SECOND operand, 4..7 of the first)
+    // a step of -1 is held as 0x7f: byte + 0x7f, then bit 7 flipped, is byte - 1 without a carry into the neighbouring byte
+    const uint32_t dx = __builtin_amdgcn_perm(0x00000001u, 0x7f000000u, selx); // dx by action: 0 0 0 -1 | +1 0
+    const uint32_t dy = __builtin_amdgcn_perm(0x00000000u, 0x007f0100u, selx); // dy by action: 0 +1 -1 0 | 0 0
+    uint32_t delta = dx | (dy << 8);
+    // dead agents do not act (base.py:477); a crew member killed this tick never gets its turn
+    const uint32_t live = (0u - (d.al & 1u)) & 0x0000ffffu | (0u - (d.al >> 1)) & 0xffff0000u;
+    delta &= live;
+    const uint32_t q = (d.pq + delta) ^ ((delta << 1) & k80); // bytes in [0, n + 1]
+    // undo a step off the grid: byte == 0 or byte == n + 1 (_is_valid_position, base.py:548-551: bounds only, no walls here)
+    const uint32_t bad80 = ((q + k.hi_probe) | ~((q | k80) - k01)) & k80;
+    const uint32_t badff = (bad80 - (bad80 >> 7)) | bad80;
+    d.pq = (d.pq & badff) | (q & ~badff);
+    // win (pred_prey.py:78-99 with no jobs): the imposter wins when no crew member is alive
+    const uint32_t dead0 = (d.al & 1u) ^ 1u, dead1 = (d.al >> 1) ^ 1u;
+    done = dead1;
+    e.flags |= dead1 << 2;               // FLAG_IMP_WON (metrics.update, pred_prey.py:96)
+    // rewards: byte tables over {kill landed, imposter dead, crew dead}
+    const uint32_t idx = hit | (dead0 << 1) | (dead1 << 2);
+    const int32_t b0 = (int32_t)(int8_t)__builtin_amdgcn_perm(k.lut0_hi, k.lut0_lo, idx | 0x0c0c0c00u);
+    const int32_t b1 = (int32_t)(int8_t)__builtin_amdgcn_perm(k.lut1_hi, k.lut1_lo, idx | 0x0c0c0c00u);
+    r0 = (float)b0;
+    r1 = (float)b1;
+    // base.py:392-395: t saturates at max_time_steps - 1
+    trunc = e.t == k.max_t_m1 ? 1u : 0u;
+    e.t += trunc ^ 1u;
+}
+
+} // namespace susnet

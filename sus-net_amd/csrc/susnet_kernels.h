@@ -10,6 +10,7 @@
 #include "susnet_device.h"
 #include "susnet_obs.h"
 #include "susnet_swar.h"
+#include "susnet_duel.h"
 
 namespace susnet {
 
@@ -98,7 +99,36 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         RNG rng = make_rng<RNG>(c, s, b);
         bool done = false, trunc = false;
         uint32_t bits = 0;
-        if constexpr (UseSwar<S>::value) {
+        constexpr bool kDuelSpec = !S::kGeneric && S::kA == 2 && S::kJ == 0 && S::kVar == SUSNET_VARIANT_ITG && S::kStaticRoles && S::kFixedOrder;
+        bool stepped = false;
+        if constexpr (kDuelSpec) {
+            if (c.duel_fast) { // no walls, byte-sized rewards: the register-arithmetic step (susnet_duel.h)
+                stepped = true;
+                const int32_t a0 = (int32_t)st.act(0), a1 = (int32_t)st.act(1);
+                if (a0 >= 8 || a1 >= 8) bits |= SUSNET_ERRBIT_ASSERT;            // base.py:360-362
+                else if (a0 < 0 || a0 >= 6 || a1 < 0 || a1 >= 5) bits |= SUSNET_ERRBIT_INDEX; // base.py:379-382
+                if (bits) {
+                    a.rewards.put(0, b, 0.0f);
+                    a.rewards.put(1, b, 0.0f);
+                } else {
+                    const DuelConsts k = make_duel_consts(c);
+                    Duel d;
+                    to_duel(st, e, d);
+                    clear_info_if_fresh(e);
+                    rng.align();
+                    float r0, r1;
+                    uint32_t dn, tr;
+                    duel_step<RNG::kNumpy>(k, d, e, rng.cur, (uint32_t)a0, (uint32_t)a1, r0, r1, dn, tr);
+                    from_duel(d, st, e);
+                    a.rewards.put(0, b, r0);
+                    a.rewards.put(1, b, r1);
+                    done = dn != 0u;
+                    trunc = tr != 0u;
+                }
+            }
+        }
+        if (stepped) {
+        } else if constexpr (UseSwar<S>::value) {
             // the index-order byte-parallel step (susnet_swar.h): validate like base.py:357-362 / 379-382, then repack
             using W = Swar<S>;
             const uint32_t space_n = 8u;
@@ -182,7 +212,7 @@ struct RecordLayout {
     static constexpr int kBytesTail = (S::kA > 0 ? S::kA : 0) + 2 + (S::kRawF > 0 ? S::kRawF : 0);
     static constexpr int kDwords = (S::kA > 0 ? S::kA : 0) + (kBytesTail + 3) / 4;
 };
-template <class S, int OUT>
+template <class S, int OUT, class RNG = PhiloxRng>
 __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
     const int tid = threadIdx.x;
@@ -202,14 +232,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
     wave_lds_fence();
     Env e = {};
-    PhiloxRng rng;
-    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
+    RNG rng = make_rng<RNG>(c, s, active ? b : 0);
     ActionStream as;
     as.init();
-    if (active) {
-        load_env<S>(c, s, st, b, e);
-        rng.cur = s.rng[b];
-    }
+    if (active) load_env<S>(c, s, st, b, e);
     // trajectory mode with register-direct observation rows has no cooperative (all-lane) work past this point:
     // idle lanes of a ragged last wave leave, and the tick loop runs without per-block exec masking
     if (((OUT == OUT_TRAJ_RAW8 && S::kRawF > 0) || OUT == OUT_TRAJ || OUT == OUT_RECORD) && !active) return;
@@ -277,10 +303,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             sample_actions_env<S, PAR>(c, st, e, rng, as, tick_base + (uint64_t)tick);
             // shuffled order: the tick's shuffle draws follow its action draws in the stream
             OrderOf<S> ow = (OrderOf<S>)0xFEDCBA9876543210ull;
-            if (S::order_random(c)) {
-                uint32_t R[rank_words(S::kA)];
-                ranks_from_stream<S, PAR>(c, S::imp(c, e.imp), rng, as, tick_base + (uint64_t)tick, true, R);
-                order_from_ranks<S>(c, R, ow);
+            if constexpr (!RNG::kNumpy) { // (numpy parity: step_env shuffles from the env's own words)
+                if (S::order_random(c)) {
+                    uint32_t R[rank_words(S::kA)];
+                    ranks_from_stream<S, PAR>(c, S::imp(c, e.imp), rng, as, tick_base + (uint64_t)tick, true, R);
+                    order_from_ranks<S>(c, R, ow);
+                }
             }
             STAMP(1);
             uint32_t av[S::kA > 0 ? S::kA : 1];
@@ -378,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // word layout is compiled in, 12 for the 1v1 game (three ticks per word).  Inside a group every block generation and
     // word selection is static; ticks before the first group boundary of a launch and after its last full group run
     // through the run-time flavour.
-    constexpr int kGroup = (S::kGeneric || OUT == OUT_ANY) ? 0 : (S::kA == 2 ? 4 * kDuelTicksPerWord : (S::kStaticAw ? 4 : 0));
+    constexpr int kGroup = (S::kGeneric || OUT == OUT_ANY || RNG::kNumpy) ? 0 : (S::kA == 2 ? 4 * kDuelTicksPerWord : (S::kStaticAw ? 4 : 0));
     int tick = 0;
     while (tick < a.n_ticks) {
         if (kGroup > 0 && tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) % (uint64_t)(kGroup > 0 ? kGroup : 1)) == 0ull) {
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
 #endif
     if (active) {
         store_env<S>(c, s, st, b, e, true);
-        s.rng[b] = rng.cur;
+        finish_rng(s, b, rng);
         life.flush(c, s, b);
     }
 }
@@ -420,7 +448,7 @@ __device__ __forceinline__ void store_packed_bytes(const D &d, const uint32_t *w
 
 // Fused random rollout of the byte-parallel (SWAR) configurations: the same contract as k_rollout, the state held as
 // packed bytes (susnet_swar.h) for the whole launch.  OUT_RECORD is not offered for these configurations.
-template <class S, int OUT>
+template <class S, int OUT, class RNG = PhiloxRng>
 __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, RolloutArgs a, ObsArgs o) {
     using W = Swar<S>;
     constexpr int A = W::A, NW = W::NW;
@@ -437,14 +465,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
     wave_lds_fence();
     Env e = {};
-    PhiloxRng rng;
-    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0);
+    RNG rng = make_rng<RNG>(c, s, active ? b : 0);
     ActionStream as;
     as.init();
-    if (active) {
-        load_env<S>(c, s, st, b, e);
-        rng.cur = s.rng[b];
-    }
+    if (active) load_env<S>(c, s, st, b, e);
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
     if ((kTraj || OUT == OUT_NONE) && !active) return; // no cooperative work past this point in these modes
     W w;
@@ -479,9 +503,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         }
         if (active) {
             uint32_t act[NW], R[NW];
-            sample_actions_swar<S, POS>(c, w, rng, as, tick_base + (uint64_t)tick, act);
-            if (S::kOrd > 0) ranks_from_stream<S, POS>(c, 0u, rng, as, tick_base + (uint64_t)tick, true, R);
-            else identity_ranks<S>(R);
+            if constexpr (RNG::kNumpy) { // numpy parity: base.py:326-330, then np.random.shuffle (base.py:372-374) from the env's own words
+                sample_actions_swar<S>(c, w, rng, act);
+                identity_ranks<S>(R);
+                if (S::kOrd > 0) {
+                    OrderOf<S> ord = (OrderOf<S>)0xFEDCBA9876543210ull;
+                    shuffle_nibbles<false>(rng, ord, A);
+                    ranks_from_order<S>(ord, R);
+                }
+            } else {
+                sample_actions_swar<S, POS>(c, w, rng, as, tick_base + (uint64_t)tick, act);
+                if (S::kOrd > 0) ranks_from_stream<S, POS>(c, 0u, rng, as, tick_base + (uint64_t)tick, true, R);
+                else identity_ranks<S>(R);
+            }
             if (kTraj) store_packed_bytes<A>(da, act);
             else if (OUT == OUT_ANY && pa != nullptr) store_packed_bytes<A>(PtrDst{pa}, act);
             float rr[A];
@@ -521,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
         }
     };
-    constexpr int kGroup = OUT == OUT_ANY ? 0 : 4; // groups of 4 ticks start on a Philox block boundary of the action stream
+    constexpr int kGroup = (OUT == OUT_ANY || RNG::kNumpy) ? 0 : 4; // groups of 4 ticks start on a Philox block boundary of the action stream
     int tick = 0;
     while (tick < a.n_ticks) {
         if (kGroup > 0 && tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) & 3ull) == 0ull) {
@@ -535,9 +569,123 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     if (active) {
         from_swar<S>(c, w, st, e);
         store_env<S>(c, s, st, b, e, true);
-        s.rng[b] = rng.cur;
+        finish_rng(s, b, rng);
         life.flush(c, s, b);
     }
+}
+
+// Fused random rollout of the 1v1 no-walls game (susnet_duel.h): the headline kernel.  Same contract as k_rollout for the
+// modes OUT_NONE / OUT_TRAJ / OUT_TRAJ_RAW8; RNG = the production stream or caller-supplied words (numpy parity).
+template <class RNG, int OUT>
+__global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, RolloutArgs a, ObsArgs o) {
+    using S = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>;
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x;
+    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3; // XCD-aware mapping (see k_rollout)
+    const uint32_t per = nblk >> 3, rem = nblk & 7u;
+    const uint32_t wave_id = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    const int64_t b0 = (int64_t)wave_id * c.epw, b = b0 + tid;
+    const bool active = tid < c.epw && b < c.B;
+    typename StoreFor<S>::type st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
+    Env e = {};
+    if (!active) return; // no cooperative work past this point
+    load_env<S>(c, s, st, b, e);
+    RNG rng = make_rng<RNG>(c, s, b);
+    ActionStream as;
+    as.init();
+    Duel d;
+    to_duel(st, e, d);
+    const DuelConsts k = make_duel_consts(c);
+    uint64_t tick_base = a.tick_base;
+    if (c.dev_tick) {
+        const uint64_t t = *s.dev_tick;
+        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
+    }
+    LifeAcc life;
+    life.clear();
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
+    const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+    const uint64_t B = (uint64_t)c.B;
+    BufDst da = make_buf_dst(a.actions, nt * 2u * B, (uint32_t)b * 2u);
+    BufDst dr = make_buf_dst(a.rewards, nt * 8u * B, (uint32_t)b * 8u);
+    BufDst dd = make_buf_dst(a.done, nt * B, (uint32_t)b);
+    BufDst dt = make_buf_dst(a.trunc, nt * B, (uint32_t)b);
+    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)b * 6u);
+    const uint32_t slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    if (a.n_ticks > 0) {
+        clear_info_if_fresh(e); // once per launch instead of once per tick
+        rng.align();            // the first step aligns the event-stream cursor; later steps find it aligned (see below)
+    }
+    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
+        constexpr int POS = decltype(par)::value;
+        if (kTraj) { // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index, nothing loop-carried
+            const uint32_t t32 = (uint32_t)tick;
+            da.so = t32 * (2u * slab_d); dr.so = t32 * (8u * slab_d); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
+        }
+        uint32_t a0, a1;
+        if constexpr (RNG::kNumpy) { // base.py:326-330 with numpy's own words
+            a0 = rng.bounded(6u);
+            a1 = rng.bounded(5u);
+        } else { // production stream: three ticks per word, 30 = 6 * 5 out of the word per tick (see sample_actions_env)
+            const uint64_t gt = tick_base + (uint64_t)tick;
+            uint32_t w;
+            if (POS >= 0) {
+                constexpr int q = POS >= 0 ? POS / kDuelTicksPerWord : 0, sl = POS >= 0 ? POS % kDuelTicksPerWord : 0;
+                if (POS == 0) as.gen(rng, gt / (uint64_t)(4 * kDuelTicksPerWord));
+                w = sl == 0 ? as.at(q) : as.rem;
+            } else {
+                const uint32_t sl = (uint32_t)(gt % (uint64_t)kDuelTicksPerWord);
+                w = as.word(rng, gt / (uint64_t)kDuelTicksPerWord);
+                w *= sl >= 1u ? kDuelRange : 1u;
+                w *= sl >= 2u ? kDuelRange : 1u;
+            }
+            // hi32(w * 30) = 5 * a0 + a1 with a0 = hi32(w * 6), a1 = hi32(lo32(w * 6) * 5): the nested digits from ONE multiply
+            const uint64_t p = (uint64_t)w * (uint64_t)kDuelRange;
+            const uint32_t pair = (uint32_t)(p >> 32);
+            as.rem = (uint32_t)p;
+            a0 = (pair * 13u) >> 6; // pair / 5 for pair < 30
+            a1 = pair - 5u * a0;
+        }
+        if (kTraj) da.st16(0u, a0 | (a1 << 8));
+        float r0, r1;
+        uint32_t done, trunc;
+        duel_step<RNG::kNumpy>(k, d, e, rng.cur, a0, a1, r0, r1, done, trunc);
+        if (kTraj) {
+            dr.st64(0u, __float_as_uint(r0), __float_as_uint(r1));
+            dd.st8(0u, done);
+            dt.st8(0u, trunc);
+        }
+        if (__builtin_expect((done | trunc) != 0u, 0)) {
+            life.add_episode(e, trunc != 0u);
+            reset_env<S>(c, T, st, tid, e, rng);
+            to_duel(st, e, d);
+            // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed.
+            // The next step will align the cursor: done right here unless this was the launch's last tick (then the stored
+            // cursor is the reset's, as if no step had followed)
+            if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+            else { zero_metrics(e); rng.align(); }
+        }
+        if (OUT == OUT_TRAJ_RAW8) { // flatten_state: x0 y0 x1 y1 alive0 alive1
+            dobs.st32(0u, d.pq - k01);
+            dobs.st16(4u, (d.al & 1u) | ((d.al & 2u) << 7));
+        }
+    };
+    constexpr int kGroup = RNG::kNumpy ? 0 : 4 * kDuelTicksPerWord;
+    int tick = 0;
+    while (tick < a.n_ticks) {
+        if (kGroup > 0 && tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) % (uint64_t)(kGroup > 0 ? kGroup : 1)) == 0ull) {
+            static_for<0, (kGroup > 0 ? kGroup : 1)>([&](auto pos) __attribute__((always_inline)) { tick_body(tick + decltype(pos)::value, pos); });
+            tick += kGroup;
+        } else {
+            tick_body(tick, std::integral_constant<int, -1>{});
+            tick++;
+        }
+    }
+    from_duel(d, st, e);
+    store_env<S>(c, s, st, b, e, true);
+    finish_rng(s, b, rng);
+    life.flush(c, s, b);
 }
 
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
@@ -553,15 +701,29 @@ template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
+// tape: the handle draws from caller-supplied words (numpy parity) instead of the production stream; offered for the
+// populate()-shaped trajectory mode only (OUT_TRAJ_RAW8)
 template <class SPEC>
-void launch_rollout(int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
+void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
+    constexpr bool kDuelSpec = !SPEC::kGeneric && SPEC::kA == 2 && SPEC::kJ == 0 && SPEC::kVar == SUSNET_VARIANT_ITG && SPEC::kStaticRoles && SPEC::kFixedOrder;
+    if constexpr (kDuelSpec) {
+        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8)) { // susnet_duel.h
+            if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+            else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+            else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
+            else hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+            return;
+        }
+    }
     if constexpr (UseSwar<SPEC>::value) {
-        if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+        if (tape) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
         else hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
     } else {
-        if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+        if (tape) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_RECORD) {
@@ -577,10 +739,10 @@ void launch_step(bool tape, dim3 g, dim3 blk, size_t sh, hipStream_t st, const C
     else hipLaunchKernelGGL((k_step<PhiloxRng, SPEC>), g, blk, sh, st, c, s, a, o);
 }
 #define SUSNET_DECLARE(SPEC)                                                                                              \
-    extern template void launch_rollout<SPEC>(int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
+    extern template void launch_rollout<SPEC>(bool, int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
     extern template void launch_step<SPEC>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
 #define SUSNET_INSTANTIATE(SPEC)                                                                                          \
-    template void launch_rollout<SPEC>(int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
+    template void launch_rollout<SPEC>(bool, int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
     template void launch_step<SPEC>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
 
 } // namespace susnet

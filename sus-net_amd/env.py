@@ -553,7 +553,7 @@ class BatchedFourRoomEnv:
 
     def rollout_into(self, n_ticks: int, bufs) -> None:
         """One fused launch of ``n_ticks`` (<= the buffers' capacity) ticks; asynchronous on the current stream."""
-        assert self.rng_kind == "philox", "rollout() uses the Philox stream"
+        # (numpy / tape handles: the full trajectory with the raw uint8 observation only -- susnet_rollout refuses anything else)
         assert 1 <= n_ticks <= bufs["n_ticks"]
         io = bufs.get("_io")  # the argument block is built once per buffer set (this call is on the launch-bound path)
         if io is None:

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 passes for the driver-shaped bench command of each config.
-#   usage: tools/profile_gpu.sh [cfg2 cfg3 cfg4 tag5 ...]      (default: all four)
-# Output under gpurun_out/prof/<config>/.  --kernel-trace --stats in one run; each PMC group in its own run (never
+#   usage: [PROF_TAG=r02x] tools/profile_gpu.sh [cfg2 cfg3 cfg4 tag5 ...]      (default: all four)
+# Output under gpurun_out/prof_$PROF_TAG/<config>/ (a fresh directory per tag: gpurun MERGES into the local gpurun_out/).  --kernel-trace --stats in one run; each PMC group in its own run (never
 # combined with other trace domains).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 CONFIGS="${*:-cfg2 cfg3 cfg4 tag5}"
 for CFG in $CONFIGS; do
-  OUT=gpurun_out/prof/$CFG
+  OUT=gpurun_out/prof_${PROF_TAG:-cur}/$CFG
   rm -rf "$OUT" && mkdir -p "$OUT"
   BENCH="python3 bench.py --config $CFG --no-cpu-baseline --no-secondary --steps 20 --warmup 5"
   if [ "$CFG" = cfg2 ]; then FULL="python3 bench.py --config cfg2 --no-cpu-baseline --steps 20 --warmup 5"; else FULL="$BENCH"; fi

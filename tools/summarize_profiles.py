@@ -1,5 +1,5 @@
 """Condense gpurun_out/prof/<config>/* (rocprofv3 CSV, tools/profile_gpu.sh) into small tracked files under profiles/.
-usage: python tools/summarize_profiles.py r02"""
+usage: python tools/summarize_profiles.py r02 [gpurun_out/prof_r02]"""
 import collections
 import csv
 import glob
@@ -9,7 +9,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-root = "gpurun_out/prof"
+root = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 summary = {}
 for cdir in sorted(glob.glob(f"{root}/*")):
@@ -46,7 +46,7 @@ for cdir in sorted(glob.glob(f"{root}/*")):
         per[os.path.basename(d)] = out
     # derived per wave-tick figures of the fused rollout kernel (SQ_* cycle counters tick in quad-cycles)
     try:
-        roll = lambda grp: next(v for k, v in per[grp].items() if k.startswith("void k_rollout"))
+        roll = lambda grp: next(v for k, v in per[grp].items() if "k_rollout" in k)
         s1, s2 = roll("pmc_sq1"), roll("pmc_sq2")
         waves = s1["SQ_WAVES"]["mean_per_launch"]
         ticks = 512
