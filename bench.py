@@ -182,8 +182,9 @@ def main():
     ap.add_argument("--obs", default="raw", choices=["none", "raw", "flat", "planes"])
     ap.add_argument("--ticks", type=int, default=512, help="ticks per fused launch (= per bench step in fused mode)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--packed", type=int, default=0, help="fused + raw obs: 1 = one packed record per env-step (compiled-in "
-                    "configurations), 0 = separate trajectory tensors (default; faster on cfg2)")
+    ap.add_argument("--packed", type=int, default=-1, help="fused + raw obs: 1 = one packed record per env-step (compiled-in configurations: "
+                    "the same fields, one or a few wide stores per lane instead of one narrow store per tensor), 0 = separate "
+                    "trajectory tensors, -1 (default) = packed where the configuration has it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -260,7 +261,7 @@ def main():
             step_obs = pkg.ObsConfig("flat", POLICY_COMPONENTS)
         env = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=step_obs)
         env.reset()
-        packed = (mode == "fused" and obs_mode == "raw" and args.packed == 1 and env.record_layout() is not None)
+        packed = (mode == "fused" and obs_mode == "raw" and args.packed != 0 and env.record_layout() is not None)
         if args.packed == 1 and mode == "fused" and obs_mode == "raw":
             assert packed, "this configuration has no packed record mode"
         used_packed[0] = packed if mode == "fused" and obs_mode == args.obs else used_packed[0]

@@ -666,7 +666,7 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
     if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
     const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c, env->float_exact) : 0;
-    if (spec != 2 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode (the byte-parallel configurations have none)
+    if (spec != 2 && spec != 3 && spec != 4 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode
     const int A = env->c.A, F = env->layout.obs_raw_size;
     out->off_rewards = 0;
     out->off_actions = 4 * A;

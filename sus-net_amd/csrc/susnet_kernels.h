@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     as.init();
     if (active) load_env<S>(c, s, st, b, e);
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
-    if ((kTraj || OUT == OUT_NONE) && !active) return; // no cooperative work past this point in these modes
+    if ((kTraj || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
     W w;
     to_swar<S>(c, st, e, w);
     uint64_t tick_base = a.tick_base;
@@ -494,6 +494,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
     BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * kRawF));
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    constexpr bool kRec = OUT == OUT_RECORD; // one packed record per env-step: rewards f32[A] | actions u8[A] | done | truncated | raw obs u8[F] | 0-padding
+    constexpr int kRecDwords = RecordLayout<S>::kDwords;
+    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
+    const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
     if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
     auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
         constexpr int POS = decltype(par)::value;
@@ -501,6 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
+        if (kRec) drec.so = (uint32_t)tick * slab_rec;
         if (active) {
             uint32_t act[NW], R[NW];
             if constexpr (RNG::kNumpy) { // numpy parity: base.py:326-330, then np.random.shuffle (base.py:372-374) from the env's own words
@@ -542,6 +547,27 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 uint32_t row[(kRawF + 3) / 4];
                 raw_row_swar<S>(w, row);
                 store_packed_bytes<kRawF>(dobs, row);
+            }
+            if (kRec) { // (byte moves between statically known positions: the compiler folds them into v_perm / v_alignbyte)
+                uint32_t row[(kRawF + 3) / 4];
+                raw_row_swar<S>(w, row);
+                constexpr int kNB = A + 2 + kRawF;
+                uint8_t by[(kNB + 3) / 4 * 4];
+#pragma unroll
+                for (int i = 0; i < A; i++) by[i] = (uint8_t)(act[i / 4] >> (8 * (i & 3)));
+                by[A] = done ? 1 : 0;
+                by[A + 1] = trunc ? 1 : 0;
+#pragma unroll
+                for (int f = 0; f < kRawF; f++) by[A + 2 + f] = (uint8_t)(row[f / 4] >> (8 * (f & 3)));
+#pragma unroll
+                for (int q = kNB; q < (kNB + 3) / 4 * 4; q++) by[q] = 0;
+                uint32_t rec[kRecDwords];
+#pragma unroll
+                for (int i = 0; i < A; i++) rec[i] = __float_as_uint(rr[i]);
+#pragma unroll
+                for (int q = 0; q < (kNB + 3) / 4; q++)
+                    rec[A + q] = (uint32_t)by[4 * q] | ((uint32_t)by[4 * q + 1] << 8) | ((uint32_t)by[4 * q + 2] << 16) | ((uint32_t)by[4 * q + 3] << 24);
+                store_dwords<kRecDwords>(drec, rec);
             }
             if (OUT == OUT_ANY) {
                 pa = pa ? pa + AB : pa;
@@ -605,8 +631,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     LifeAcc life;
     life.clear();
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
+    constexpr bool kRec = OUT == OUT_RECORD; // one 20-byte record per env-step: rewards | actions done truncated | x0 y0 x1 y1 | alive0 alive1 0 0
     const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     const uint64_t B = (uint64_t)c.B;
+    BufDst drec = make_buf_dst(a.record, nt * 20u * B, (uint32_t)b * 20u);
     BufDst da = make_buf_dst(a.actions, nt * 2u * B, (uint32_t)b * 2u);
     BufDst dr = make_buf_dst(a.rewards, nt * 8u * B, (uint32_t)b * 8u);
     BufDst dd = make_buf_dst(a.done, nt * B, (uint32_t)b);
@@ -623,6 +651,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * (2u * slab_d); dr.so = t32 * (8u * slab_d); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
+        if (kRec) drec.so = (uint32_t)tick * (20u * slab_d);
         uint32_t a0, a1;
         if constexpr (RNG::kNumpy) { // base.py:326-330 with numpy's own words
             a0 = rng.bounded(6u);
@@ -670,6 +699,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             dobs.st32(0u, d.pq - k01);
             dobs.st16(4u, (d.al & 1u) | ((d.al & 2u) << 7));
         }
+        if (kRec) {
+            drec.st128(0u, __float_as_uint(r0), __float_as_uint(r1), a0 | (a1 << 8) | (done << 16) | (trunc << 24), d.pq - k01);
+            drec.st32(16u, (d.al & 1u) | ((d.al & 2u) << 7));
+        }
     };
     constexpr int kGroup = RNG::kNumpy ? 0 : 4 * kDuelTicksPerWord;
     int tick = 0;
@@ -707,8 +740,9 @@ template <class SPEC>
 void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
     constexpr bool kDuelSpec = !SPEC::kGeneric && SPEC::kA == 2 && SPEC::kJ == 0 && SPEC::kVar == SUSNET_VARIANT_ITG && SPEC::kStaticRoles && SPEC::kFixedOrder;
     if constexpr (kDuelSpec) {
-        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8)) { // susnet_duel.h
+        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD)) { // susnet_duel.h
             if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+            else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_NONE>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
             else hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
@@ -720,6 +754,7 @@ void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t
         else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
+        else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
         else hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
     } else {
         if (tape) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
