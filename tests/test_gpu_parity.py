@@ -176,6 +176,73 @@ def test_hip_matches_reference_crc_streams(pkg, name, kernels, monkeypatch):
     assert bad.size == 0, f"{name}: first mismatch at (seed index, step) = {bad[0].tolist()}"
 
 
+@pytest.mark.parametrize("name", crc_names())
+def test_fused_rollout_on_numpy_tapes_matches_reference_crc_streams(pkg, oracle_mod, name):
+    """The FUSED rollout kernels (the ones bench.py times: byte-parallel / duel / per-turn, whichever the configuration
+    selects) fed numpy's own MT19937 words: ONE launch of 96 ticks per fixture -- sample_actions, step, in-launch reset all
+    draw from the tape with numpy semantics, so env b reproduces the reference seeded with seed b.  Every tick's actions,
+    rewards, done, truncated and post-reset raw observation must equal the oracle's MT19937 run (itself equal to the
+    reference on these very seeds, tests/test_oracle_checksums.py), and for every step that did not end an episode the CRC
+    of the step record rebuilt from the kernel's outputs (info counters taken from the oracle: the trajectory does not carry
+    them) must equal the reference's."""
+    import zlib
+
+    g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
+    meta = g["meta"]
+    seeds, S = meta["seeds"], meta["n_steps"]
+    B = len(seeds)
+    tagging = meta["class"] == "tagging"
+    env = env_from_meta(pkg, meta, B, rng="numpy", tape_words=1 << 14, auto_reset=True, check_errors=False)
+    env._reseed(seeds)
+    env.reset()
+    traj = env.rollout(S, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    torch.cuda.synchronize()
+    env.poll_errors()
+    acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
+    ob = oracle_mod.OracleBatch(oracle_mod.config_from_fixture_meta(meta), B)
+    ob.seed_mt(seeds)
+    ob.reset()
+    A, J = env.n_agents, env.n_jobs
+    interval = ob.envs[0].cfg.tag_reset_interval
+    got = np.zeros((B, S), dtype=np.uint32)
+    for s in range(S):
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(acts[s], oa, err_msg=f"{name} actions tick {s}")
+        orew, odone, otrunc, rc = ob.step(oa)
+        assert rc == 0
+        assert np.array_equal(rews[s].astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
+        np.testing.assert_array_equal(dones[s], odone.astype(bool), err_msg=f"{name} done tick {s}")
+        np.testing.assert_array_equal(truncs[s], otrunc.astype(bool), err_msg=f"{name} truncated tick {s}")
+        met = ob.export()["metrics"]
+        ended = (odone | otrunc).astype(bool)
+        ob.reset(mask=ended)
+        np.testing.assert_array_equal(obs[s], ob.obs_raw_u8(), err_msg=f"{name} raw obs tick {s}")
+        for b in range(B):
+            if ended[b]:
+                got[b, s] = g["crc"][b, s]  # the terminal state is gone after the in-launch reset (checked through the oracle above)
+                continue
+            row = obs[s, b].astype(np.int64)
+            k = 0
+            pos = row[k:k + 2 * A].reshape(A, 2); k += 2 * A
+            alive = row[k:k + A]; k += A
+            jd = np.zeros(0, dtype=np.int64)
+            if J > 0 or tagging:
+                k += 2 * J
+                jd = row[k:k + J]; k += J
+            used = counts = left = None
+            if tagging:
+                used = row[k:k + A]; k += A
+                counts = row[k:k + A]; k += A
+                left = int(row[k])
+            rec = step_record_bytes(actions=acts[s, b], pos=pos, alive=alive, jobdone=jd, rewards=rews[s, b].astype(np.float64),
+                                    done=dones[s, b], trunc=truncs[s, b], metrics=met[b, :13], used=used, counts=counts, timer_left=left)
+            got[b, s] = zlib.crc32(rec)
+    bad = np.argwhere(got != g["crc"])
+    assert bad.size == 0, f"{name}: first mismatch at (seed index, step) = {bad[0].tolist()}"
+    # words consumed: the kernel's cursors equal the oracle's MT19937 word counts
+    np.testing.assert_array_equal(np_(env.rng_cursor()).astype(np.uint64), ob.export()["cursor"], err_msg=f"{name} words consumed")
+
+
 @pytest.mark.parametrize("family", [f for f in sorted(FAMILIES) if f.startswith("itg_1v1_")])
 def test_production_1v1_kernel_steps_reference_states(pkg, family):
     """The kernel bench.py's headline number runs (k_step / k_rollout<PhiloxRng, Spec<2,0,ITG,...>>: branch-free duel) against
