@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SUSNET_ABI_VERSION 1
+#define SUSNET_ABI_VERSION 2
 
 #define SUSNET_MAX_AGENTS 16
 #define SUSNET_MAX_JOBS 16
@@ -233,8 +233,9 @@ int susnet_bind_tape(susnet_env *env, const uint32_t *tape, int64_t words_per_en
 int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void *stream);
 /* PHILOX mode draws agent actions from a second stream indexed by the number of steps the handle has taken
  * ("tick"; advanced by susnet_step / susnet_rollout, NOT by susnet_sample_actions -- sampling twice before a
- * step returns the same actions).  Set and/or read it (either pointer may be NULL). */
-int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get);
+ * step returns the same actions).  Set and/or read it (either pointer may be NULL).  With the counter in device memory
+ * (susnet_device_tick) both are ordered on `stream`; reading synchronises `stream`. */
+int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get, void *stream);
 
 int susnet_reset(susnet_env *env, const uint8_t *mask /* [B] or NULL = all */, const susnet_obs_spec *obs,
                  void *stream);
@@ -266,10 +267,11 @@ int susnet_reduce_lifetime(susnet_env *env, int64_t *out_device, void *stream);
 
 /* Graph-replayable launches.  By default the step counter that indexes the production action stream (susnet_tick)
  * travels as a kernel argument, so a captured launch would replay with a stale value.  enable = 1 moves the counter
- * into device memory (inside the bound state blob): sample_actions / step / rollout read it there, and step / rollout
- * are followed by a one-thread launch that advances it (no workgroup ever sees a half-advanced value), so a hipGraph captured from these calls (e.g. {susnet_sample_actions; susnet_step}) can be replayed any
- * number of times.  enable = 0 reads it back.  susnet_tick() keeps working in both modes (it synchronises in device
- * mode).  Synchronises `stream`. */
+ * into device memory (inside the bound state blob), ONE COPY PER ENVIRONMENT: sample_actions / step / rollout read the
+ * env's own copy and step / rollout advance it in the same kernel (the lane that owns the env; no extra launch, no word
+ * one workgroup writes while another reads), so a hipGraph captured from these calls (e.g. {susnet_sample_actions;
+ * susnet_step}) can be replayed any number of times.  enable = 0 reads it back (synchronises `stream`).  susnet_tick()
+ * keeps working in both modes. */
 int susnet_device_tick(susnet_env *env, int32_t enable, void *stream);
 
 /* Synchronises `stream`, reads and clears the device error word. Returns 0 or the most severe

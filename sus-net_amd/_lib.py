@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libsusnet_hip.so"
 LIB_PATH = os.environ.get("SUSNET_LIB_PATH", os.path.join(PKG_DIR, LIB_NAME))  # override: A/B experiments only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_AGENTS, MAX_JOBS, MAX_GRID, N_METRICS, N_LIFETIME = 16, 16, 16, 13, 12
 
 VARIANT_BASE, VARIANT_ITG, VARIANT_TAGGING = 0, 1, 2
@@ -144,7 +144,7 @@ def lib():
     L.susnet_bind_state.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.susnet_bind_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.susnet_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
-    L.susnet_tick.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
+    L.susnet_tick.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), C.c_void_p]
     L.susnet_reset.argtypes = [C.c_void_p, C.c_void_p, P(ObsSpec), C.c_void_p]
     L.susnet_sample_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.susnet_step.argtypes = [C.c_void_p, P(StepIO), C.c_void_p]

@@ -63,15 +63,18 @@ __global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out,
     RNG rng = make_rng<RNG>(c, s, b);
     ActionStream as;
     as.init();
-    if (c.dev_tick) tick = *s.dev_tick;
+    if (c.dev_tick) tick = uniform64(s.tickw[b]);
     sample_actions_env<S>(c, st, e, rng, as, tick);
     for (int i = 0; i < c.A; i++) store_action(out, dtype, (int64_t)i * sa + b * sb, st.act(i));
     finish_rng(s, b, rng);
 }
 
-// Device-resident step counter (susnet_device_tick): advanced by its own one-thread launch AFTER the kernel(s) that read
-// it, so that no workgroup can ever observe a half-advanced tick -- no atomics or fences on the stepping kernels.
-__global__ void k_bump_tick(uint64_t *tick, uint64_t n) { *tick += n; }
+// Device-resident step counter (susnet_device_tick): one copy per environment, read and advanced by the lane that owns the
+// environment inside the stepping kernels themselves -- no launch of its own, no word that one workgroup writes while another reads.
+__global__ void k_fill_tick(Consts c, State s, uint64_t tick) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < c.Bp) s.tickw[b] = tick;
+}
 
 __global__ __launch_bounds__(kBlock) void k_observe(Consts c, State s, ObsArgs o) {
     using S = GenericSpec;
@@ -269,10 +272,9 @@ struct susnet_env {
     bool bound = false;
     bool float_exact = false;
     uint64_t ticks = 0; // steps taken (index of the production action stream)
-    uint64_t ticks_staging = 0;
     susnet_layout layout;
     uint64_t off_err, off_agent, off_job, off_jobdone, off_t, off_timer, off_flags, off_rng, off_msteps, off_mfix, off_msab,
-        off_mkv, off_life;
+        off_mkv, off_life, off_tickw;
 };
 
 static thread_local std::string g_err;
@@ -424,6 +426,7 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     e->off_msab = take(4 * Bp);
     e->off_mkv = take(4 * Bp);
     e->off_life = take(4 * Bp * SUSNET_N_LIFETIME);
+    e->off_tickw = take(8 * Bp);
     susnet_layout &L = e->layout;
     L.state_bytes = off;
     L.state_align = 256;
@@ -455,7 +458,6 @@ extern "C" int susnet_bind_state(susnet_env *env, void *blob, uint64_t bytes, vo
     const uint32_t *tape = s.tape;
     int64_t tape_len = s.tape_len;
     s.err = reinterpret_cast<uint32_t *>(p + env->off_err);
-    s.dev_tick = reinterpret_cast<uint64_t *>(p + env->off_err + 192); // (the diagnostic build's stamps end at byte 144)
     s.agent = reinterpret_cast<uint16_t *>(p + env->off_agent);
     s.job = reinterpret_cast<uint8_t *>(p + env->off_job);
     s.jobdone = reinterpret_cast<uint16_t *>(p + env->off_jobdone);
@@ -468,6 +470,7 @@ extern "C" int susnet_bind_state(susnet_env *env, void *blob, uint64_t bytes, vo
     s.m_sab = reinterpret_cast<uint32_t *>(p + env->off_msab);
     s.m_kv = reinterpret_cast<uint32_t *>(p + env->off_mkv);
     s.life = reinterpret_cast<uint32_t *>(p + env->off_life);
+    s.tickw = reinterpret_cast<uint64_t *>(p + env->off_tickw);
     s.tape = tape;
     s.tape_len = tape_len;
     HIP_TRY(hipMemsetAsync(blob, 0, env->layout.state_bytes, static_cast<hipStream_t>(stream)));
@@ -495,7 +498,7 @@ extern "C" int susnet_seed(susnet_env *env, uint64_t seed, uint64_t cursor, void
     env->c.seed = seed;
     env->cfg.seed = seed;
     env->ticks = 0;
-    if (env->c.dev_tick) HIP_TRY(hipMemsetAsync(env->s.dev_tick, 0, sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+    if (env->c.dev_tick) HIP_TRY(hipMemsetAsync(env->s.tickw, 0, sizeof(uint64_t) * (size_t)env->c.Bp, static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(k_fill_cursor, dim3((unsigned)((env->c.B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), env->c,
                        env->s, cursor);
     HIP_TRY(hipGetLastError());
@@ -656,7 +659,6 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     case 18: launch_step<SpecA<8>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     default: launch_step<GenericSpec>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     }
-    if (env->c.dev_tick) hipLaunchKernelGGL(k_bump_tick, dim3(1), dim3(1), 0, st, env->s.dev_tick, (uint64_t)1);
     HIP_TRY(hipGetLastError());
     env->ticks += 1;
     return SUSNET_OK;
@@ -755,7 +757,6 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         case 18: launch_rollout<SpecA<8>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         default: launch_rollout<GenericSpec>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         }
-        if (env->c.dev_tick) hipLaunchKernelGGL(k_bump_tick, dim3(1), dim3(1), 0, st, env->s.dev_tick, (uint64_t)a.n_ticks);
         HIP_TRY(hipGetLastError());
     }
     env->ticks += (uint64_t)io->n_ticks;
@@ -811,14 +812,27 @@ extern "C" int susnet_import_state(susnet_env *env, const susnet_state_view *vie
     return SUSNET_OK;
 }
 
-extern "C" int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get) {
+static void fill_tick(susnet_env *env, uint64_t tick, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_tick, dim3((unsigned)((env->c.Bp + 255) / 256)), dim3(256), 0, st, env->c, env->s, tick);
+}
+
+extern "C" int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get, void *stream) {
     if (!env) return fail(SUSNET_E_INVALID, "null handle");
+    hipStream_t st = static_cast<hipStream_t>(stream);
     if (set) {
         env->ticks = *set;
-        if (env->c.dev_tick) HIP_TRY(hipMemcpy(env->s.dev_tick, &env->ticks, sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (env->c.dev_tick) {
+            if (int rc = check_bound(env)) return rc;
+            fill_tick(env, env->ticks, st);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (get) {
-        if (env->c.dev_tick) HIP_TRY(hipMemcpy(&env->ticks, env->s.dev_tick, sizeof(uint64_t), hipMemcpyDeviceToHost)); // (synchronises)
+        if (env->c.dev_tick) { // ordered on the caller's stream like every other call of the handle; synchronises it
+            if (int rc = check_bound(env)) return rc;
+            HIP_TRY(hipMemcpyAsync(&env->ticks, env->s.tickw, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         *get = env->ticks;
     }
     return SUSNET_OK;
@@ -828,14 +842,12 @@ extern "C" int susnet_device_tick(susnet_env *env, int32_t enable, void *stream)
     if (int rc = check_bound(env)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (enable && !env->c.dev_tick) {
-        // the copy reads env->ticks_staging when it executes: a member, alive as long as the handle
-        env->ticks_staging = env->ticks;
-        HIP_TRY(hipMemcpyAsync(env->s.dev_tick, &env->ticks_staging, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        fill_tick(env, env->ticks, st);
+        HIP_TRY(hipGetLastError());
         env->c.dev_tick = 1;
     } else if (!enable && env->c.dev_tick) {
+        HIP_TRY(hipMemcpyAsync(&env->ticks, env->s.tickw, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(&env->ticks, env->s.dev_tick, sizeof(uint64_t), hipMemcpyDeviceToHost));
         env->c.dev_tick = 0;
     }
     return SUSNET_OK;

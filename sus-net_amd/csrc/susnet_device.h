@@ -83,7 +83,8 @@ template <> __device__ __forceinline__ float rw<float>(const Consts &c, int k) {
 // Device pointers into the caller's state blob (SoA, row stride Bp).
 struct State {
     uint32_t *err;      // [1] device error word
-    uint64_t *dev_tick; // [1] device-resident step counter (used when Consts::dev_tick; same 256-byte block as err)
+    uint64_t *tickw;    // [Bp] device-resident step counter, ONE COPY PER ENVIRONMENT (used when Consts::dev_tick): a lane reads
+                        // and advances its own word, so no launch ever reads a word another workgroup is writing
     uint16_t *agent;    // [A][Bp]
     uint8_t *job;       // [J][Bp]  x | y << 4 (constant within an episode)
     uint16_t *jobdone;  // [Bp] bitmask
@@ -1032,6 +1033,11 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
 
 // Register-resident flavour for the fused rollout (VGPRs are plentiful at one wave per SIMD): branch-free adds
 // at episode end, one flush per launch.
+// wave-uniform copy of a 64-bit value every lane holds identically
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
 struct LifeAcc {
     uint32_t v[10];
     __device__ __forceinline__ void clear() {

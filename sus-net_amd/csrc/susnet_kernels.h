@@ -99,6 +99,9 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         RNG rng = make_rng<RNG>(c, s, b);
         bool done = false, trunc = false;
         uint32_t bits = 0;
+        // step counter of the action stream: a kernel argument, or (graph-replayable launches) the env's own device word,
+        // identical in every env -- read here, advanced below by the same lane
+        const uint64_t step_tick = c.dev_tick ? uniform64(s.tickw[b]) : a.tick;
         constexpr bool kDuelSpec = !S::kGeneric && S::kA == 2 && S::kJ == 0 && S::kVar == SUSNET_VARIANT_ITG && S::kStaticRoles && S::kFixedOrder;
         bool stepped = false;
         if constexpr (kDuelSpec) {
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
                     } else {
                         ActionStream as;
                         as.init();
-                        ranks_from_stream<S>(c, S::imp(c, e.imp), rng, as, c.dev_tick ? *s.dev_tick : a.tick, false, R);
+                        ranks_from_stream<S>(c, S::imp(c, e.imp), rng, as, step_tick, false, R);
                     }
                 }
                 float rr[W::A];
@@ -175,13 +178,14 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
                     ActionStream as;
                     as.init();
                     uint32_t R[rank_words(S::kA)];
-                    ranks_from_stream<S>(c, S::imp(c, e.imp), rng, as, c.dev_tick ? *s.dev_tick : a.tick, false, R);
+                    ranks_from_stream<S>(c, S::imp(c, e.imp), rng, as, step_tick, false, R);
                     order_from_ranks<S>(c, R, ord);
                 }
             }
             bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc, nullptr, ord);
         }
         if (bits) atomicOr(s.err, bits);
+        if (c.dev_tick) s.tickw[b] = step_tick + 1ull;
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
         bool jobs_changed = false;
@@ -242,10 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // the step counter of the action stream: a kernel argument, or (graph-replayable launches) a device word that the
     // last workgroup to finish advances; either way wave-uniform, in scalar registers
     uint64_t tick_base = a.tick_base;
-    if (c.dev_tick) {
-        const uint64_t t = *s.dev_tick;
-        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
-    }
+    if (c.dev_tick) tick_base = uniform64(s.tickw[active ? b : b0]); // (every env holds the same count)
     LifeAcc life;
     life.clear();
     const int64_t AB = (int64_t)A * c.B;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
         store_env<S>(c, s, st, b, e, true);
         finish_rng(s, b, rng);
         life.flush(c, s, b);
+        if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     }
 }
 
@@ -474,10 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     W w;
     to_swar<S>(c, st, e, w);
     uint64_t tick_base = a.tick_base;
-    if (c.dev_tick) {
-        const uint64_t t = *s.dev_tick;
-        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
-    }
+    if (c.dev_tick) tick_base = uniform64(s.tickw[active ? b : b0]); // (every env holds the same count)
     LifeAcc life;
     life.clear();
     const int64_t AB = (int64_t)A * c.B;
@@ -597,6 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         store_env<S>(c, s, st, b, e, true);
         finish_rng(s, b, rng);
         life.flush(c, s, b);
+        if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     }
 }
 
@@ -624,10 +624,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     to_duel(st, e, d);
     const DuelConsts k = make_duel_consts(c);
     uint64_t tick_base = a.tick_base;
-    if (c.dev_tick) {
-        const uint64_t t = *s.dev_tick;
-        tick_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
-    }
+    if (c.dev_tick) tick_base = uniform64(s.tickw[active ? b : b0]); // (every env holds the same count)
     LifeAcc life;
     life.clear();
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
@@ -719,6 +716,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     store_env<S>(c, s, st, b, e, true);
     finish_rng(s, b, rng);
     life.flush(c, s, b);
+    if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
 }
 
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels

@@ -668,13 +668,15 @@ class BatchedFourRoomEnv:
     def tick(self) -> int:
         """Steps this handle has taken (index of the Philox action stream; see susnet_tick)."""
         v = C.c_uint64(0)
-        L.check(self.lib.susnet_tick(self._h, None, C.byref(v)))
+        with self._on_device():
+            L.check(self.lib.susnet_tick(self._h, None, C.byref(v), self._stream()))
         return int(v.value)
 
     @tick.setter
     def tick(self, value: int):
         v = C.c_uint64(int(value))
-        L.check(self.lib.susnet_tick(self._h, C.byref(v), None))
+        with self._on_device():
+            L.check(self.lib.susnet_tick(self._h, C.byref(v), None, self._stream()))
 
     def device_tick(self, enable: bool = True) -> None:
         """Keep the step counter of the action stream in device memory (``susnet_device_tick``): launches then carry no
@@ -683,7 +685,7 @@ class BatchedFourRoomEnv:
             L.check(self.lib.susnet_device_tick(self._h, int(bool(enable)), self._stream()))
 
     def capture_random_step(self, n_ticks: int = 1) -> "torch.cuda.CUDAGraph":
-        """hipGraph of ``n_ticks`` drop-in ticks ``a = env.sample_actions(); env.step(a)`` (two kernel nodes + the counter bump each): the
+        """hipGraph of ``n_ticks`` drop-in ticks ``a = env.sample_actions(); env.step(a)`` (two kernel nodes each): the
         launch-bound inner loop of a random-policy driver, replayable with ``graph.replay()``.  Outputs land in the env's persistent
         tensors (``sample_actions()`` buffer, ``step()``'s rewards / done / truncated / fused observation).  Needs
         ``check_errors=False, export_state=False`` (both would synchronise inside the capture)."""
@@ -704,8 +706,9 @@ class BatchedFourRoomEnv:
         return graph
 
     def graph_nodes_per_tick(self) -> int:
-        """Kernel nodes one captured drop-in tick holds (sample_actions + step + the step-counter bump)."""
-        return 3
+        """Kernel nodes one captured drop-in tick holds (sample_actions + step; the step kernel advances the device-resident
+        step counter itself)."""
+        return 2
 
     def rng_cursor(self) -> torch.Tensor:
         cur = torch.zeros(self.batch, dtype=torch.int64, device=self.device)
