@@ -15,6 +15,7 @@
  *                          + _agent_step 462-533, check_win_condition 409-460 (pred_prey.py:78-99),
  *                            _merge_rewards 553-563, EnvMetricHandler src/metrics.py:35-64
  *   susnet_rollout         ReplayBuffer.populate's loop    src/replay_memory.py:96-143 (minus the buffer)
+ *   susnet_ring_append     ReplayBuffer.add x (T x B)      src/replay_memory.py:50-73, with populate's sequence window (108-136)
  *   susnet_observe         flatten_state base.py:234; FlatFeaturizer / GlobalFeaturizer
  *                          src/features/model_ready.py:219-370, src/features/component.py:83-482
  *   susnet_featurize       SequenceStateFeaturizer.fit(state_sequence[B,T,S]) on windows / replay batches
@@ -191,7 +192,41 @@ typedef struct susnet_rollout_io {
     void *record;       /* alternative to ALL of the above (which must then be NULL): one packed record per env-step,
                          * [T][B][record_bytes] -- the same fields, laid out for one wide store per lane
                          * (susnet_record_layout); only for the compiled-in configurations */
+    /* replay feed (susnet_ring_append); both optional, both need obs = RAW / U8 next to the full trajectory */
+    uint8_t *term_obs;  /* out [T][B][obs_raw_size] u8, written ONLY at (tick, env) where the episode ended: the true
+                         * post-step state (the obs row of such a tick already holds the next episode's first state) */
+    uint16_t *roles;    /* out [T][B]: imposter bitmask (bit i = agent i) of the episode that acted at the tick */
 } susnet_rollout_io;
+
+/* Device replay ring fed from a fused rollout: the reference's ReplayBuffer tensors (src/replay_memory.py:33-44) written by
+ * ONE launch from the [T][B] trajectory of susnet_rollout, with ReplayBuffer.populate's semantics (replay_memory.py:96-143):
+ * row n = tick * B + env (the order B sequential `add` calls per tick would produce) lands at ring position (idx + n) %
+ * max_size; states[row] is the env's window of its last `trajectory_size` flattened states before the tick (after a reset:
+ * the episode's first state repeated, replay_memory.py:108-113), next_states[row] the window rolled by one with the TRUE
+ * post-step state appended (np.roll, replay_memory.py:120-127 -- also for a transition that ends its episode: term_obs),
+ * dones[row] = done (not truncated), imposters[row] = ascending agent indices of the acting episode's imposters.  If the
+ * launch holds more than max_size transitions only the last max_size are written.  `window` carries every env's window
+ * across launches: in = before the first tick, out = before the tick that follows the last one. */
+typedef struct susnet_ring_io {
+    int32_t n_ticks;            /* T of the rollout */
+    int32_t trajectory_size;    /* window length (ReplayBuffer.trajectory_size) */
+    const uint8_t *actions;     /* [T][B][A] u8 */
+    const float *rewards;       /* [T][B][A] */
+    const uint8_t *done;        /* [T][B] */
+    const uint8_t *truncated;   /* [T][B] */
+    const uint8_t *obs;         /* [T][B][S] raw u8: state after each tick (after the in-launch reset, if any) */
+    const uint8_t *term_obs;    /* [T][B][S] raw u8, read where done | truncated */
+    const uint16_t *roles;      /* [T][B], or NULL: the imposters are agents [0, n_imposters) */
+    uint8_t *window;            /* in/out [B][trajectory_size][S] u8 */
+    int64_t max_size, idx;      /* ring capacity (rows), position of the next row */
+    float *states;              /* [max_size][trajectory_size][S] */
+    float *next_states;         /* [max_size][trajectory_size][S] */
+    int64_t *ring_actions;      /* [max_size][A] */
+    float *ring_rewards;        /* [max_size][A] */
+    uint8_t *ring_dones;        /* [max_size][1] */
+    int16_t *ring_imposters;    /* [max_size][n_imposters] */
+} susnet_ring_io;
+int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, void *stream);
 
 /* Packed trajectory record of susnet_rollout_io.record: rewards f32[A] at byte 0, then actions u8[A], done u8,
  * truncated u8, raw observation u8[obs_raw_size] (flatten_state order), zero-padded to a multiple of 4 bytes.

@@ -32,7 +32,7 @@ EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
     "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_step",
     "susnet_rollout", "susnet_record_layout", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
-    "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors",
+    "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append",
 ]
 
 
@@ -77,6 +77,16 @@ class RolloutIO(C.Structure):
     _fields_ = [
         ("n_ticks", C.c_int32), ("actions", C.c_void_p), ("rewards", C.c_void_p), ("done", C.c_void_p),
         ("truncated", C.c_void_p), ("obs", C.POINTER(ObsSpec)), ("record", C.c_void_p),
+        ("term_obs", C.c_void_p), ("roles", C.c_void_p),
+    ]
+
+
+class RingIO(C.Structure):
+    _fields_ = [
+        ("n_ticks", C.c_int32), ("trajectory_size", C.c_int32), ("actions", C.c_void_p), ("rewards", C.c_void_p),
+        ("done", C.c_void_p), ("truncated", C.c_void_p), ("obs", C.c_void_p), ("term_obs", C.c_void_p), ("roles", C.c_void_p),
+        ("window", C.c_void_p), ("max_size", C.c_int64), ("idx", C.c_int64), ("states", C.c_void_p), ("next_states", C.c_void_p),
+        ("ring_actions", C.c_void_p), ("ring_rewards", C.c_void_p), ("ring_dones", C.c_void_p), ("ring_imposters", C.c_void_p),
     ]
 
 
@@ -158,6 +168,7 @@ def lib():
     L.susnet_reduce_lifetime.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.susnet_device_tick.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.susnet_poll_errors.argtypes = [C.c_void_p, P(C.c_uint32), C.c_void_p]
+    L.susnet_ring_append.argtypes = [C.c_void_p, P(RingIO), C.c_void_p]
     for name in EXPORTS:
         if name not in ("susnet_last_error", "susnet_destroy"):
             getattr(L, name).restype = C.c_int

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <string>
@@ -692,6 +693,8 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     a.trunc = io->truncated;
     a.record = static_cast<uint8_t *>(io->record);
     a.record_bytes = 0;
+    a.term_obs = io->term_obs;
+    a.roles = io->roles;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
     const int spec = pick_spec(env->c, env->float_exact);
@@ -713,7 +716,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool none_traj = !a.actions && !a.rewards && !a.done && !a.trunc;
     // trajectory mode addresses every output through a buffer descriptor with 32-bit offsets: a launch covers at most
     // as many ticks as keep every output array below 2 GiB; longer requests run as consecutive launches
-    const bool traj = all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8 && (o.tick_stride % 16) == 0;
+    const bool traj = all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8;
     const bool traj_noobs = all_traj && o.mode == SUSNET_OBS_NONE;
     const uint64_t AB = (uint64_t)env->c.A * (uint64_t)env->c.B;
     const uint64_t tick_bytes = a.record ? (uint64_t)env->c.B * (uint64_t)a.record_bytes : std::max<uint64_t>(4u * AB, (uint64_t)o.tick_stride);
@@ -729,6 +732,8 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
                     : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
                                                             : OUT_ANY;
+    if ((a.term_obs || a.roles) && !(all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8))
+        return fail(SUSNET_E_INVALID, "susnet_rollout: term_obs / roles go with the full trajectory and the raw uint8 observation");
     if (tape && out != OUT_TRAJ_RAW8)
         return fail(SUSNET_E_INVALID, "susnet_rollout on a TAPE handle stores the full trajectory with the raw uint8 observation (nothing else)");
     const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
@@ -742,6 +747,8 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             a.done += (uint64_t)chunk * (uint64_t)env->c.B;
             a.trunc += (uint64_t)chunk * (uint64_t)env->c.B;
             if (o.out) o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (uint64_t)o.tick_stride;
+            if (a.term_obs) a.term_obs += (uint64_t)chunk * (uint64_t)o.tick_stride;
+            if (a.roles) a.roles += (uint64_t)chunk * (uint64_t)env->c.B;
         }
         switch (spec) {
         case 2: launch_rollout<SpecCfg2>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
@@ -760,6 +767,121 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         HIP_TRY(hipGetLastError());
     }
     env->ticks += (uint64_t)io->n_ticks;
+    return SUSNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// replay ring (susnet_ring_append)
+// ---------------------------------------------------------------------------------------------------
+struct RingArgs {
+    susnet_ring_io io;
+    int64_t B, n0, n1; // envs; first / one-past-last transition (n = tick * B + env) this launch writes
+    int32_t A, S, n_imp;
+};
+// the flattened state an env's window holds at virtual tick u (= the state after tick u; u < 0: the carried-in window)
+__device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t u, int64_t b) {
+    const int Tw = r.io.trajectory_size;
+    if (u < 0) return r.io.window + ((size_t)b * Tw + (size_t)(Tw + u < 0 ? 0 : Tw + u)) * r.S; // window[Tw - 1] = state before tick 0
+    return r.io.obs + ((size_t)u * r.B + b) * r.S;
+}
+// One wave per 64 consecutive transitions.  Lane r gathers its row's Tw + 1 states (window + true next state) into an
+// LDS strip; the wave then expands the strips to float32 with coalesced stores (states = strip[0 .. Tw), next = strip[1 .. Tw]).
+__global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
+    extern __shared__ uint32_t smem[];
+    uint8_t *strip = reinterpret_cast<uint8_t *>(smem);
+    const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A;
+    const int64_t n_first = r.n0 + (int64_t)blockIdx.x * 64, n = n_first + lane;
+    const int rows = (int)((r.n1 - n_first) < 64 ? (r.n1 - n_first) : 64);
+    const int L = (Tw + 1) * S; // strip bytes per row
+    int64_t pos = 0;
+    if (lane < rows) {
+        const int64_t t = n / r.B, b = n % r.B;
+        pos = (r.io.idx + n) % r.io.max_size;
+        // most recent episode boundary before tick t within the window's reach: the episode's first state is obs[e]
+        int64_t e = -(1ll << 62);
+        for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
+            if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
+        uint8_t *mine = strip + (size_t)lane * L;
+        for (int k = 0; k < Tw; k++) { // replay_memory.py:108-113, 122-127
+            int64_t u = t - Tw + k;
+            if (u < e) u = e;
+            const uint8_t *src = ring_state(r, u, b);
+            for (int f = 0; f < S; f++) mine[k * S + f] = src[f];
+        }
+        const bool ended = (r.io.done[t * r.B + b] | r.io.truncated[t * r.B + b]) != 0;
+        const uint8_t *nxt = (ended ? r.io.term_obs : r.io.obs) + ((size_t)t * r.B + b) * S;
+        for (int f = 0; f < S; f++) mine[Tw * S + f] = nxt[f];
+        // the small per-row tensors
+        for (int i = 0; i < A; i++) {
+            r.io.ring_actions[pos * A + i] = (int64_t)r.io.actions[((size_t)t * r.B + b) * A + i];
+            r.io.ring_rewards[pos * A + i] = r.io.rewards[((size_t)t * r.B + b) * A + i];
+        }
+        r.io.ring_dones[pos] = r.io.done[t * r.B + b] ? 1 : 0; // replay_memory.py:131: done, not truncation
+        uint32_t m = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << r.n_imp) - 1u);
+        for (int k = 0; k < r.n_imp; k++) { // ascending agent indices
+            const int i = __ffs((int)m) - 1;
+            r.io.ring_imposters[pos * r.n_imp + k] = (int16_t)(i < 0 ? 0 : i);
+            m &= m - 1u;
+        }
+    }
+    wave_lds_fence();
+    // ring position of row 0 of this wave; rows are consecutive positions modulo max_size
+    const int64_t pos0 = (r.io.idx + n_first) % r.io.max_size;
+    const int TS = Tw * S;
+    const int total = rows * TS;
+    for (int g = lane; g < total; g += 64) {
+        const int row = g / TS, k = g - row * TS;
+        int64_t p = pos0 + row;
+        if (p >= r.io.max_size) p -= r.io.max_size;
+        const uint8_t *st = strip + (size_t)row * L;
+        r.io.states[(size_t)p * TS + k] = (float)st[k];
+        r.io.next_states[(size_t)p * TS + k] = (float)st[S + k];
+    }
+}
+// the carried window of every env after the launch: the window before the tick that follows the last one
+__global__ __launch_bounds__(64) void k_ring_window(RingArgs r) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= r.B) return;
+    const int Tw = r.io.trajectory_size, S = r.S;
+    const int64_t t = r.io.n_ticks;
+    int64_t e = -(1ll << 62);
+    for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
+        if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
+    // in place, slots ascending: slot k of the new window comes from obs, or (launches shorter than the window) from slot
+    // k + t > k of the old one, which has not been overwritten yet
+    uint8_t *dst = r.io.window + (size_t)b * Tw * S;
+    for (int k = 0; k < Tw; k++) {
+        int64_t u = t - Tw + k;
+        if (u < e) u = e;
+        const uint8_t *src = ring_state(r, u, b);
+        for (int f = 0; f < S; f++) dst[k * S + f] = src[f];
+    }
+}
+
+extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, void *stream) {
+    if (!env || !io) return fail(SUSNET_E_INVALID, "null argument");
+    if (io->n_ticks < 1 || io->trajectory_size < 1 || io->max_size < 1 || io->idx < 0 || io->idx >= io->max_size)
+        return fail(SUSNET_E_INVALID, "susnet_ring_append: n_ticks, trajectory_size, max_size must be positive and 0 <= idx < max_size");
+    if (!io->actions || !io->rewards || !io->done || !io->truncated || !io->obs || !io->term_obs || !io->window || !io->states ||
+        !io->next_states || !io->ring_actions || !io->ring_rewards || !io->ring_dones || !io->ring_imposters)
+        return fail(SUSNET_E_INVALID, "susnet_ring_append: null buffer");
+    if (!io->roles && env->c.shuffle_imp) return fail(SUSNET_E_INVALID, "susnet_ring_append: roles are drawn per episode here (shuffle_imposter_index): pass roles");
+    RingArgs r;
+    r.io = *io;
+    r.B = env->c.B;
+    r.A = env->c.A;
+    r.S = env->layout.obs_raw_size;
+    r.n_imp = env->c.n_imp;
+    const int64_t total = (int64_t)io->n_ticks * r.B;
+    r.n0 = total > io->max_size ? total - io->max_size : 0; // (earlier rows would be overwritten by later ones of this same launch)
+    r.n1 = total;
+    const size_t sh = (size_t)64 * (size_t)(io->trajectory_size + 1) * (size_t)r.S;
+    if (sh > 64 * 1024) return fail(SUSNET_E_INVALID, "susnet_ring_append: trajectory_size x state size too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t waves = (r.n1 - r.n0 + 63) / 64;
+    hipLaunchKernelGGL(k_ring_append, dim3((unsigned)waves), dim3(64), sh, st, r);
+    hipLaunchKernelGGL(k_ring_window, dim3((unsigned)((r.B + 63) / 64)), dim3(64), 0, st, r);
+    HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }
 

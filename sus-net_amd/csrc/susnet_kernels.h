@@ -31,7 +31,18 @@ struct RolloutArgs {
     uint8_t *done, *trunc; // [T][B]
     uint8_t *record;       // packed mode: [T][B][record_bytes]
     int32_t record_bytes;
+    // replay feed (susnet_ring_append): what the fused trajectory does not hold on its own
+    uint8_t *term_obs;     // [T][B][F] raw uint8 rows, written ONLY where an episode ended: the true post-step (terminal) state
+    uint16_t *roles;       // [T][B] imposter bitmask of the episode that acted at the tick
 };
+
+// the raw uint8 observation row of one env at (tick, b) of a [T][B][F] array, byte by byte (rare path: episode ends)
+template <int F>
+__device__ __forceinline__ void store_row_bytes(uint8_t *base, int64_t tick, int64_t B, int64_t b, const uint8_t *row) {
+    uint8_t *p = base + (tick * B + b) * F;
+#pragma unroll
+    for (int f = 0; f < F; f++) p[f] = row[f];
+}
 
 // f(std::integral_constant<int, I>{}) for I = BEGIN .. END - 1
 template <int BEGIN, int END, class F>
@@ -350,8 +361,21 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 if (pt != nullptr) *pt = trunc ? 1 : 0;
             }
             STAMP(4);
+            if (a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)S::imp(c, e.imp);
             if (__builtin_expect(done || trunc, 0)) {
                 life.add_episode(e, trunc);
+                if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                    const int F = o.F;
+                    uint8_t *p = a.term_obs + ((int64_t)tick * c.B + b) * F;
+                    if constexpr (S::kRawF > 0) {
+                        uint8_t row[S::kRawF + 4];
+                        fill_raw<S>(c, st, e, row);
+#pragma unroll
+                        for (int f = 0; f < S::kRawF; f++) p[f] = row[f];
+                    } else {
+                        fill_raw<S>(c, st, e, p);
+                    }
+                }
                 reset_env<S>(c, T, st, tid, e, rng);
                 // info counters of a terminal step stay readable until the next step: only the launch's last
                 // tick can be observed, every other episode end zeroes them right away (wave-uniform branch)
@@ -534,8 +558,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 if (pd != nullptr) *pd = done ? 1 : 0;
                 if (pt != nullptr) *pt = trunc ? 1 : 0;
             }
+            if (a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)swar_imp_bits(w);
             if (__builtin_expect(done || trunc, 0)) {
                 life.add_episode(e, trunc);
+                if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                    uint32_t trow[(kRawF + 3) / 4];
+                    raw_row_swar<S>(w, trow);
+                    store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+                }
                 reset_env<S>(c, T, st, tid, e, rng);
                 to_swar<S>(c, st, e, w);
                 // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed
@@ -682,8 +712,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             dd.st8(0u, done);
             dt.st8(0u, trunc);
         }
+        if (a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)1u; // the imposter is agent 0 (pred_prey.py:52-66, shuffle off)
         if (__builtin_expect((done | trunc) != 0u, 0)) {
             life.add_episode(e, trunc != 0u);
+            if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                PtrDst tp{a.term_obs + ((int64_t)tick * c.B + b) * 6};
+                tp.st32(0u, d.pq - k01);
+                tp.st16(4u, (d.al & 1u) | ((d.al & 2u) << 7));
+            }
             reset_env<S>(c, T, st, tid, e, rng);
             to_duel(st, e, d);
             // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed.

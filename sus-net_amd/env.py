@@ -511,14 +511,18 @@ class BatchedFourRoomEnv:
         return lay if lay.record_bytes else None
 
     def alloc_rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None,
-                      packed: bool = False):
+                      packed: bool = False, replay_feed: bool = False):
         """Allocate (once) the trajectory buffers a fused rollout of up to ``n_ticks`` ticks writes:
         actions u8 [T, B, A], rewards f32 [T, B, A], done / truncated bool [T, B], obs [T, B, ...].
 
         ``packed=True`` (compiled-in configurations, full trajectory + raw uint8 observation only): ONE buffer
         ``record`` u8 [T, B, record_bytes] holding the same fields per env-step, which a lane writes with one or two wide
         stores; the returned ``actions / rewards / done / truncated / obs`` are strided VIEWS into it (same shapes and
-        dtypes as the separate tensors)."""
+        dtypes as the separate tensors).
+
+        ``replay_feed=True`` (full trajectory + raw uint8 observation): also ``term_obs`` u8 [T, B, S] -- written only where
+        an episode ended: its true terminal state -- and ``roles`` int16 [T, B] (imposter bitmask of the acting episode): what
+        ``DeviceReplayBuffer.populate_fused`` needs besides the trajectory."""
         T, A, B = int(n_ticks), self.n_agents, self.batch
         out = {"n_ticks": T}
         if packed:
@@ -549,6 +553,11 @@ class BatchedFourRoomEnv:
             out["obs"] = o1 if T > 1 else o1.unsqueeze(0)
             if o2 is not None:
                 out["obs_non_spatial"] = o2 if T > 1 else o2.unsqueeze(0)
+        if replay_feed:
+            assert set(store) == {"actions", "rewards", "done", "truncated"} and obs is not None and obs.mode == "raw" \
+                and obs.dtype == torch.uint8, "replay_feed=True goes with the full trajectory and the raw uint8 observation"
+            out["term_obs"] = torch.zeros(T, B, self.flattened_state_size, dtype=torch.uint8, device=self.device)
+            out["roles"] = torch.zeros(T, B, dtype=torch.int16, device=self.device)
         return out
 
     def rollout_into(self, n_ticks: int, bufs) -> None:
@@ -566,6 +575,8 @@ class BatchedFourRoomEnv:
                         setattr(io, name, bufs[name].data_ptr())
                 if "_obs_spec" in bufs:
                     io.obs = C.pointer(bufs["_obs_spec"])
+                if "term_obs" in bufs:
+                    io.term_obs, io.roles = bufs["term_obs"].data_ptr(), bufs["roles"].data_ptr()
             bufs["_io"] = io
         io.n_ticks = int(n_ticks)
         with self._on_device():

@@ -10,7 +10,12 @@ time and everything lives on the env's device.  ``populate`` is the batched form
 window of its last T flattened states (O1 layout, written by the step kernel's fused raw observation); a fresh
 episode's window is filled with its first state, as the reference does after ``reset``.
 
-This module is host glue over torch tensors (no kernels of its own).
+Two ways to fill the ring:
+* ``populate_fused``: the native path -- fused rollout launches (``susnet_rollout`` with its replay feed) followed by ONE
+  ``susnet_ring_append`` launch each, which writes all six reference tensors for T x B transitions from the trajectory with
+  exactly ``ReplayBuffer.populate``'s window / terminal-state semantics (pinned against the reference's own buffers,
+  tests/golden/replay_*.npz).
+* ``populate`` / ``add_batch``: per-tick torch glue over the step API (kept for callers that step the env themselves).
 """
 from __future__ import annotations
 
@@ -66,6 +71,49 @@ class DeviceReplayBuffer:
         i = torch.randint(0, self.size, (batch_size,), device=self.states.device)
         return Batch(states=self.states[i], actions=self.actions[i], rewards=self.rewards[i], next_states=self.next_states[i],
                      imposters=self.imposters[i], dones=self.dones[i])
+
+    @torch.no_grad()
+    def populate_fused(self, env, num_steps: int, ticks_per_launch: int = 256) -> int:
+        """``ReplayBuffer.populate`` (src/replay_memory.py:96-143) for B environments in lockstep, on the device:
+        ``env.reset()``, then ``num_steps`` ticks of the fused random rollout, appended to the ring by ``susnet_ring_append``.
+        Row order = tick-major, env-minor (what B sequential ``add`` calls per tick produce); with ``batch=1`` and
+        ``rng='numpy'`` the ring equals the reference's for the same numpy seed.  ``env`` must auto-reset."""
+        import ctypes as C
+
+        from . import _lib as L
+        from .env import ObsConfig
+
+        assert env.auto_reset, "populate_fused needs an auto-resetting env (episodes restart inside the launch)"
+        assert env.flattened_state_size == self.state_size and env.n_agents == self.n_agents and env.n_imposters == self.n_imposters
+        T, B, S = self.trajectory_size, env.batch, self.state_size
+        raw8 = ObsConfig("raw", dtype=torch.uint8)
+        env.reset()
+        first = env.observe(raw8)
+        window = first.unsqueeze(1).repeat(1, T, 1).contiguous()  # replay_memory.py:108-113: the first state T times
+        n_launch = max(1, min(int(ticks_per_launch), int(num_steps)))
+        bufs = env.alloc_rollout(n_launch, obs=raw8, replay_feed=True)
+        io = L.RingIO()
+        io.trajectory_size = T
+        io.actions, io.rewards = bufs["actions"].data_ptr(), bufs["rewards"].data_ptr()
+        io.done, io.truncated = bufs["done"].data_ptr(), bufs["truncated"].data_ptr()
+        io.obs, io.term_obs, io.roles = bufs["obs"].data_ptr(), bufs["term_obs"].data_ptr(), bufs["roles"].data_ptr()
+        io.window = window.data_ptr()
+        io.max_size = self.max_size
+        io.states, io.next_states = self.states.data_ptr(), self.next_states.data_ptr()
+        io.ring_actions, io.ring_rewards = self.actions.data_ptr(), self.rewards.data_ptr()
+        io.ring_dones, io.ring_imposters = self.dones.data_ptr(), self.imposters.data_ptr()
+        done_ticks = 0
+        while done_ticks < num_steps:
+            n = min(n_launch, num_steps - done_ticks)
+            env.rollout_into(n, bufs)
+            io.n_ticks, io.idx = n, self.idx
+            with torch.cuda.device(env.device):
+                L.check(env.lib.susnet_ring_append(env._h, C.byref(io), env._stream()))
+            self.idx = (self.idx + n * B) % self.max_size
+            self.size = min(self.size + n * B, self.max_size)
+            done_ticks += n
+        torch.cuda.current_stream(env.device).synchronize()  # (the trajectory buffers die with this call)
+        return num_steps * B
 
     @torch.no_grad()
     def populate(self, env, num_steps: int) -> int:

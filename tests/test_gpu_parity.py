@@ -985,6 +985,79 @@ def test_windowed_spatialdqn_policy_rollout(pkg, oracle_mod):
     assert explored > 0
 
 
+def replay_names():
+    import glob
+    import os
+
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "replay_*.npz")))
+
+
+@pytest.mark.parametrize("name", replay_names())
+def test_native_replay_ring_matches_reference_populate(pkg, name):
+    """susnet_ring_append fed by the fused rollout against the REFERENCE's own `ReplayBuffer.populate` tensors
+    (tests/golden/generate_replay.py: unmodified src/replay_memory.py on the unmodified env after np.random.seed): one env,
+    numpy's words as the tape, several launches (the window is carried across them; one fixture wraps the ring)."""
+    g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
+    meta = g["meta"]
+    T, max_size, num_steps = meta["trajectory_size"], meta["max_size"], meta["num_steps"]
+    env = env_from_meta(pkg, meta, 1, rng="numpy", tape_words=1 << 16, auto_reset=True, check_errors=False)
+    env._reseed([meta["seed"]])
+    buf = pkg.DeviceReplayBuffer(max_size, meta["state_size"], T, meta["n_agents"], meta["n_imposters"], device=env.device)
+    assert buf.populate_fused(env, num_steps, ticks_per_launch=256) == num_steps
+    env.poll_errors()
+    assert (buf.idx, buf.size) == (meta["idx"], meta["size"])
+    n = buf.size
+    np.testing.assert_array_equal(np_(buf.states[:n]), g["states"].astype(np.float32), err_msg="states")
+    np.testing.assert_array_equal(np_(buf.next_states[:n]), g["next_states"].astype(np.float32), err_msg="next_states")
+    np.testing.assert_array_equal(np_(buf.actions[:n]), g["actions"].astype(np.int64), err_msg="actions")
+    assert np_(buf.rewards[:n]).view(np.uint32).tolist() == g["rewards"].view(np.uint32).tolist(), "rewards"
+    np.testing.assert_array_equal(np_(buf.dones[:n]), g["dones"].astype(bool), err_msg="dones")
+    # (the reference keeps numpy's draw order of the imposter indices, the ring stores them ascending)
+    np.testing.assert_array_equal(np_(buf.imposters[:n]), np.sort(g["imposters"], axis=1), err_msg="imposters")
+
+
+def test_native_replay_ring_batched_matches_a_host_rebuild(pkg):
+    """Many envs, odd launch lengths, a ring smaller than the run: every row the ring holds equals what replaying the
+    trajectory on the host with ReplayBuffer.populate's rules gives (window roll, first state repeated after a reset, true
+    terminal next state, `done` only), at position (rows added so far) % max_size."""
+    B, T, max_size = 300, 3, 4000
+    env = pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False)
+    S, A = env.flattened_state_size, env.n_agents
+    buf = pkg.DeviceReplayBuffer(max_size, S, T, A, 1, device=env.device)
+    # host model: same env / seed stepped through the fused rollout in the same launch pattern
+    env2 = pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False)
+    raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
+    env2.reset()
+    first = np_(env2.observe(raw8))
+    window = np.repeat(first[:, None, :], T, axis=1).astype(np.float32)
+    rows = []
+    pattern = [5, 1, 2, 7, 9]
+    for n in pattern:
+        bufs = env2.alloc_rollout(n, obs=raw8, replay_feed=True)
+        env2.rollout_into(n, bufs)
+        torch.cuda.synchronize()
+        acts, rews, dn, tr, obs, tob, roles = (np_(bufs[k]) for k in ("actions", "rewards", "done", "truncated", "obs", "term_obs", "roles"))
+        for t in range(n):
+            ended = dn[t] | tr[t]
+            nxt_state = np.where(ended[:, None], tob[t], obs[t]).astype(np.float32)
+            nxt = np.roll(window, -1, axis=1)
+            nxt[:, -1] = nxt_state
+            imp = np.array([[i for i in range(A) if (int(roles[t, b]) >> i) & 1] for b in range(B)])
+            for b in range(B):
+                rows.append((window[b].copy(), acts[t, b].astype(np.int64), rews[t, b], nxt[b].copy(), bool(dn[t, b]), imp[b]))
+            fresh = np.repeat(obs[t][:, None, :], T, axis=1).astype(np.float32)
+            window = np.where(ended[:, None, None], fresh, nxt)
+    added = buf.populate_fused(env, sum(pattern), ticks_per_launch=9)  # launches of 9, 9, 6 ticks: same trajectory, other chunking
+    assert added == B * sum(pattern) == len(rows)
+    assert buf.size == max_size and buf.idx == len(rows) % max_size
+    st, nx, ac, rw, dd, im = (np_(x) for x in (buf.states, buf.next_states, buf.actions, buf.rewards, buf.dones, buf.imposters))
+    for k in range(len(rows) - max_size, len(rows)):
+        p = k % max_size
+        w, a, r, nw, d, i = rows[k]
+        assert np.array_equal(st[p], w) and np.array_equal(nx[p], nw), f"row {k} windows"
+        assert np.array_equal(ac[p], a) and np.array_equal(rw[p], r) and bool(dd[p, 0]) == d and np.array_equal(im[p], i), f"row {k}"
+
+
 def test_device_replay_populate(pkg):
     """Batched ReplayBuffer.populate (src/replay_memory.py:96-143): window roll, ring layout, episode boundaries."""
     B, T = 256, 3
