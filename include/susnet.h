@@ -95,6 +95,9 @@ extern "C" {
 #define SUSNET_OBS_RAW 1    /* flatten_state: [x0,y0,..., alive.., jobxy.., jobdone.. (, used, counts, timer_left)] */
 #define SUSNET_OBS_FLAT 2   /* concatenation of flat components, FlatFeaturizer */
 #define SUSNET_OBS_PLANES 3 /* GlobalFeaturizer: spatial [A+2][N][N] + non_spatial [A(+A)+J] */
+#define SUSNET_OBS_PERSP 4  /* PerspectiveFeaturizer (model_ready.py:82-216): per agent i the planes with the agent channels in
+                               the order i, 0, .., i-1, i+1, .., A-1 (then the two job channels): spatial [A][A+2][N][N];
+                               non_spatial [A][A(+A)+J] = alive (and tag counts) in that same agent order, then job status */
 
 /* flat components (src/features/component.py) */
 #define SUSNET_F_ONEHOT_POS 0
@@ -163,8 +166,8 @@ typedef struct susnet_obs_spec {
     int32_t dtype;                /* SUSNET_F32 (reference layouts) or SUSNET_U8 (compact) */
     int32_t n_components;         /* FLAT only */
     int32_t components[16];       /* SUSNET_F_* in concatenation order */
-    void *out;                    /* [B][obs_size]; PLANES: spatial [B][A+2][N][N] */
-    void *out2;                   /* PLANES: non_spatial [B][A(+A)+J]; else NULL */
+    void *out;                    /* [B][obs_size]; PLANES: spatial [B][A+2][N][N]; PERSP: [B][A][A+2][N][N] */
+    void *out2;                   /* PLANES: non_spatial [B][A(+A)+J]; PERSP: [B][A][A(+A)+J]; else NULL */
 } susnet_obs_spec;
 
 typedef struct susnet_step_io {

@@ -19,7 +19,7 @@ VARIANT_BASE, VARIANT_ITG, VARIANT_TAGGING = 0, 1, 2
 RNG_TAPE, RNG_PHILOX = 1, 2
 U8, I32, I64, F32, F64 = 0, 1, 2, 3, 4
 LAYOUT_AB, LAYOUT_BA = 0, 1
-OBS_NONE, OBS_RAW, OBS_FLAT, OBS_PLANES = 0, 1, 2, 3
+OBS_NONE, OBS_RAW, OBS_FLAT, OBS_PLANES, OBS_PERSP = 0, 1, 2, 3, 4
 E_INVALID, E_HIP, E_STATE, E_ACTION_ASSERT, E_ACTION_INDEX, E_TAPE, E_ROW = -1, -2, -3, -4, -5, -6, -7
 
 FLAT_COMPONENTS = {"onehot_pos": 0, "coord_pos": 1, "alive_crew": 2, "l1_crew": 3, "closest_crew": 4,

@@ -538,14 +538,21 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
         }
         o.F = F;
         o.words1 = img_words(kBlock * F, 8);
-    } else if (spec->mode == SUSNET_OBS_PLANES) {
+    } else if (spec->mode == SUSNET_OBS_PLANES || spec->mode == SUSNET_OBS_PERSP) {
         o.F = (c.A + 2) * c.N * c.N;
         o.F2 = c.A + c.J + (c.variant == SUSNET_VARIANT_TAGGING ? c.A : 0);
         o.words1 = img_words(kBlock * o.F, 1);
         o.words2 = img_words(kBlock * o.F2, 8);
+        o.Fi = o.F;
+        o.F2i = o.F2;
+        if (spec->mode == SUSNET_OBS_PERSP) { // every agent's rotated copy of the same images
+            o.F *= c.A;
+            o.F2 *= c.A;
+        }
     } else {
         return fail(SUSNET_E_INVALID, "unknown obs mode");
     }
+    if (o.mode != SUSNET_OBS_PLANES && o.mode != SUSNET_OBS_PERSP) { o.Fi = o.F; o.F2i = o.F2; }
     if (!o.out) return fail(SUSNET_E_INVALID, "obs.out is null");
     if ((uintptr_t)o.out % 16 || (o.out2 && (uintptr_t)o.out2 % 16)) return fail(SUSNET_E_INVALID, "obs buffers must be 16-byte aligned");
     o.tick_stride = ticks_batch * o.F;
@@ -901,8 +908,8 @@ extern "C" int susnet_featurize(susnet_env *env, const void *rows, int32_t rows_
                                 void *stream) {
     if (int rc = check_bound(env)) return rc; // the device error word lives in the bound state blob
     if (!rows || n_rows < 0) return fail(SUSNET_E_INVALID, "rows is null / n_rows negative");
-    if (!obs || (obs->mode != SUSNET_OBS_FLAT && obs->mode != SUSNET_OBS_PLANES))
-        return fail(SUSNET_E_INVALID, "susnet_featurize: obs mode must be FLAT or PLANES");
+    if (!obs || (obs->mode != SUSNET_OBS_FLAT && obs->mode != SUSNET_OBS_PLANES && obs->mode != SUSNET_OBS_PERSP))
+        return fail(SUSNET_E_INVALID, "susnet_featurize: obs mode must be FLAT, PLANES or PERSP");
     if (rows_dtype != SUSNET_U8 && rows_dtype != SUSNET_I32 && rows_dtype != SUSNET_I64 && rows_dtype != SUSNET_F32 &&
         rows_dtype != SUSNET_F64)
         return fail(SUSNET_E_INVALID, "rows dtype must be U8 / I32 / I64 / F32 / F64");

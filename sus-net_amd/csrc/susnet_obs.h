@@ -24,6 +24,7 @@ struct ObsArgs {
     int32_t ncomp;
     int32_t comp[16];
     int32_t F, F2;          // elements per env of out / out2
+    int32_t Fi, F2i;        // elements per env of the LDS images (= F, F2 except PERSP: the planes image feeds A rotated copies)
     int32_t words1, words2; // LDS staging words of segment 1 / 2 (whole wave)
     void *out, *out2;
     int64_t tick_stride, tick_stride2; // rollout: elements between consecutive ticks
@@ -241,6 +242,55 @@ __device__ __forceinline__ void expand_f32(const uint32_t *img, int total, float
     }
 }
 
+// PerspectiveFeaturizer (model_ready.py:175-216): agent i sees the agent channels in the order i, 0, .., i-1, i+1, .., A-1
+__device__ __forceinline__ int persp_source(int i, int pos) { return pos == 0 ? i : (pos <= i ? pos - 1 : pos); }
+
+// planes BIT image [rows][C][NN] -> [rows][A][C][NN] with every agent's channel order; float32 or uint8 output, 4 elements
+// per lane per pass (their positions decoded once, then walked)
+template <class OUT_T>
+__device__ __forceinline__ void expand_persp_planes(const uint32_t *img, int rows, int A, int C, int NN, OUT_T *dst, int lane) {
+    const int per_row = A * C * NN, total = rows * per_row, Fi = C * NN;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & (4 * sizeof(OUT_T) - 1)) == 0;
+    for (int g = lane * 4; g < total; g += kWave * 4) {
+        int row = g / per_row, r = g - row * per_row;
+        int i = r / Fi, r2 = r - i * Fi;
+        int ch = r2 / NN, cell = r2 - ch * NN;
+        OUT_T v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int src = ch < A ? persp_source(i, ch) : ch;
+            const int bit = row * Fi + src * NN + cell;
+            v[k] = (OUT_T)((img[bit >> 5] >> (bit & 31)) & 1u);
+            if (++cell == NN) { // next channel / agent / row
+                cell = 0;
+                if (++ch == C) { ch = 0; if (++i == A) { i = 0; row++; } }
+            }
+        }
+        if (vec_ok && g + 3 < total) {
+            if constexpr (sizeof(OUT_T) == 4) *reinterpret_cast<float4 *>(dst + g) = make_float4(v[0], v[1], v[2], v[3]);
+            else *reinterpret_cast<uint32_t *>(dst + g) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        } else {
+            for (int k = 0; k < 4 && g + k < total; k++) dst[g + k] = v[k];
+        }
+    }
+}
+// non-spatial BYTE image [rows][nb * A + J] -> [rows][A][nb * A + J]: the per-agent blocks (alive, tag counts) in agent i's order
+template <class OUT_T>
+__device__ __forceinline__ void expand_persp_bytes(const uint32_t *img, int rows, int A, int F2i, int nb, OUT_T *dst, int lane) {
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(img);
+    const int per_row = A * F2i, total = rows * per_row;
+    for (int g = lane; g < total; g += kWave) {
+        const int row = g / per_row, r = g - row * per_row;
+        const int i = r / F2i, k = r - i * F2i;
+        int src = k;
+        if (k < nb * A) {
+            const int blk = k / A, pos = k - blk * A;
+            src = blk * A + persp_source(i, pos);
+        }
+        dst[g] = (OUT_T)bytes[row * F2i + src];
+    }
+}
+
 // BITS image, uint8 output
 __device__ __forceinline__ void expand_bits_u8(const uint32_t *img, int total, uint8_t *dst, int lane) {
     for (int g = lane * 4; g < total; g += kWave * 4) {
@@ -260,18 +310,31 @@ __device__ __forceinline__ void write_obs(const Consts &c, const ObsArgs &o, con
     if (__builtin_expect(o.mode == SUSNET_OBS_NONE, 0)) return;
     uint32_t *seg1 = T.stage;
     uint32_t *seg2 = T.stage + o.words1;
-    const bool planes = o.mode == SUSNET_OBS_PLANES;
+    const bool persp = o.mode == SUSNET_OBS_PERSP;
+    const bool planes = o.mode == SUSNET_OBS_PLANES || persp;
     if (__builtin_expect(o.mode != SUSNET_OBS_RAW, 0)) { // RAW rows are fully overwritten; the others start from zeros
         for (int w = tid; w < o.words1 + o.words2; w += kWave) seg1[w] = 0u;
         wave_lds_fence();
     }
     if (active) {
-        uint8_t *row = reinterpret_cast<uint8_t *>(seg1) + tid * o.F;
+        uint8_t *row = reinterpret_cast<uint8_t *>(seg1) + tid * o.Fi;
         if (__builtin_expect(o.mode == SUSNET_OBS_RAW, 1)) fill_raw<S>(c, st, e, row);
         else if (o.mode == SUSNET_OBS_FLAT) fill_flat<S>(c, o, T, st, e, row);
-        else fill_planes<S>(c, st, e, seg1, tid * o.F, reinterpret_cast<uint8_t *>(seg2) + tid * o.F2);
+        else fill_planes<S>(c, st, e, seg1, tid * o.Fi, reinterpret_cast<uint8_t *>(seg2) + tid * o.F2i);
     }
     wave_lds_fence();
+    if (__builtin_expect(persp, 0)) { // every agent's rotated copy of the planes / of the per-agent non-spatial blocks
+        const int A = S::A(c), NN = c.N * c.N, nb = S::tagging(c) ? 2 : 1;
+        if (o.dtype == SUSNET_F32) {
+            expand_persp_planes(seg1, nrows, A, A + 2, NN, reinterpret_cast<float *>(o.out) + tick * o.tick_stride + b0 * o.F, tid);
+            if (o.out2) expand_persp_bytes(seg2, nrows, A, o.F2i, nb, reinterpret_cast<float *>(o.out2) + tick * o.tick_stride2 + b0 * o.F2, tid);
+        } else {
+            expand_persp_planes(seg1, nrows, A, A + 2, NN, reinterpret_cast<uint8_t *>(o.out) + tick * o.tick_stride + b0 * o.F, tid);
+            if (o.out2) expand_persp_bytes(seg2, nrows, A, o.F2i, nb, reinterpret_cast<uint8_t *>(o.out2) + tick * o.tick_stride2 + b0 * o.F2, tid);
+        }
+        wave_lds_fence();
+        return;
+    }
     const int total1 = nrows * o.F;
     if (__builtin_expect(o.dtype == SUSNET_F32, 0)) {
         float *d1 = reinterpret_cast<float *>(o.out) + tick * o.tick_stride + b0 * o.F;

@@ -99,12 +99,12 @@ class ObsConfig:
     """Which fused observation the kernels write next to every step / reset / rollout tick.
 
     mode: ``None`` | ``"raw"`` (``flatten_state``) | ``"flat"`` (FlatFeaturizer over ``components``) |
-    ``"planes"`` (GlobalFeaturizer).  dtype ``torch.float32`` reproduces the reference tensors,
+    ``"planes"`` (GlobalFeaturizer) | ``"persp"`` (PerspectiveFeaturizer: every agent's rotated channel order, fused).  dtype ``torch.float32`` reproduces the reference tensors,
     ``torch.uint8`` stores the same integers in a quarter of the bytes.
     """
 
     def __init__(self, mode: Optional[str] = None, components: Sequence[str] = (), dtype=torch.float32):
-        assert mode in (None, "raw", "flat", "planes"), mode
+        assert mode in (None, "raw", "flat", "planes", "persp"), mode
         assert dtype in (torch.float32, torch.uint8, torch.int8)
         self.mode, self.components, self.dtype = mode, list(components), dtype
         if mode == "flat":
@@ -113,7 +113,7 @@ class ObsConfig:
 
     @property
     def code(self):
-        return {None: L.OBS_NONE, "raw": L.OBS_RAW, "flat": L.OBS_FLAT, "planes": L.OBS_PLANES}[self.mode]
+        return {None: L.OBS_NONE, "raw": L.OBS_RAW, "flat": L.OBS_FLAT, "planes": L.OBS_PLANES, "persp": L.OBS_PERSP}[self.mode]
 
 
 class BatchedFourRoomEnv:
@@ -295,9 +295,10 @@ class BatchedFourRoomEnv:
         L.check(rc)
         lead = (rows,) if rows is not None else ((ticks, self.batch) if ticks > 1 else (self.batch,))
         A, N = self.n_agents, self.n_rows
-        shape1 = (*lead, A + 2, N, N) if oc.mode == "planes" else (*lead, f1.value)
+        shape1 = (*lead, A + 2, N, N) if oc.mode == "planes" else (*lead, A, A + 2, N, N) if oc.mode == "persp" else (*lead, f1.value)
+        shape2 = (*lead, A, f2.value // A) if oc.mode == "persp" else (*lead, f2.value)
         out = torch.zeros(shape1, dtype=oc.dtype, device=self.device)
-        out2 = torch.zeros((*lead, f2.value), dtype=oc.dtype, device=self.device) if f2.value else None
+        out2 = torch.zeros(shape2, dtype=oc.dtype, device=self.device) if f2.value else None
         spec.out = out.data_ptr()
         spec.out2 = out2.data_ptr() if out2 is not None else None
         return spec, out, out2
@@ -607,7 +608,7 @@ class BatchedFourRoomEnv:
         ``flattened_state_size``) instead of the env's own state: the reference's
         ``SequenceStateFeaturizer.fit(state_sequence[B, T, S])`` (src/features/model_ready.py:41-57) for a window
         or a replay batch.  Returns tensors with the same leading dimensions as ``states``."""
-        assert obs.mode in ("flat", "planes"), "featurize() produces the flat / planes feature layouts"
+        assert obs.mode in ("flat", "planes", "persp"), "featurize() produces the flat / planes / perspective feature layouts"
         assert states.shape[-1] == self.flattened_state_size, (
             f"expected rows of {self.flattened_state_size} values, got {states.shape[-1]}")
         assert states.dtype in self._ROW_DTYPES, f"unsupported state dtype {states.dtype}"

@@ -116,26 +116,24 @@ class GlobalFeaturizer:
         return out
 
 
-class PerspectiveFeaturizer(GlobalFeaturizer):
-    @staticmethod
-    def _orders(A: int, C: int, agent_idx: int):
-        # model_ready.py:184-193 mutates ONE order list across the loop: after iteration i it reads
-        # [i, 0, 1, ..., i-1, i+1, ...]
-        channels = list(range(C))
-        agents = list(range(A))
-        channels[0] = agents[0] = agent_idx
-        for k in range(1, agent_idx + 1):
-            channels[k] = agents[k] = k - 1
-        return channels, agents
+class PerspectiveFeaturizer:
+    """model_ready.py:82-216.  The kernels write every agent's view directly (observation mode ``"persp"``: the agent
+    channels in the order i, 0, .., i-1, i+1, .., A-1 -- what the reference's mutated order list reads after iteration i,
+    model_ready.py:184-193 -- and the per-agent non-spatial blocks in that same order), so ``generate_featurized_states``
+    only slices."""
+
+    def __init__(self, env):
+        self.env = env
+        self.config = ObsConfig("persp")
+        self.spatial = self.non_spatial = None  # [B, T, A, C, N, N], [B, T, A, F2]
+
+    def fit(self, state_sequence=None) -> None:
+        if state_sequence is None:
+            sp, non = self.env.observe(self.config)
+            self.spatial, self.non_spatial = sp.unsqueeze(1), non.unsqueeze(1)
+        else:
+            assert state_sequence.dim() == 3, "state_sequence is [B, T, S] (model_ready.py:44)"
+            self.spatial, self.non_spatial = self.env.featurize(state_sequence, self.config)
 
     def generate_featurized_states(self):
-        A = self.env.n_agents
-        C = self.spatial.shape[2]
-        out = []
-        for agent_idx in range(A):  # model_ready.py:175-216
-            ch, ag = self._orders(A, C, agent_idx)
-            nb = (self.non_spatial.shape[2] - self.env.n_jobs) // A  # per-agent blocks: alive (, tag_counts)
-            blocks = [self.non_spatial[:, :, k * A:(k + 1) * A][:, :, ag] for k in range(nb)]
-            rest = self.non_spatial[:, :, nb * A:]
-            out.append((self.spatial[:, :, ch].clone(), torch.cat(blocks + [rest], dim=2)))
-        return out
+        return [(self.spatial[:, :, i], self.non_spatial[:, :, i]) for i in range(self.env.n_agents)]
