@@ -20,6 +20,7 @@
  *                          src/features/model_ready.py:219-370, src/features/component.py:83-482
  *   susnet_featurize       SequenceStateFeaturizer.fit(state_sequence[B,T,S]) on windows / replay batches
  *                          src/features/model_ready.py:41-57, 254-289, 338-354 (callers: src/train.py:345-347)
+ *   susnet_scent           ImposterScentFeaturizer.extract_features   src/features/component.py:336-380
  *   susnet_seed / _tick    np.random.seed(seed)            src/environment/base.py:126,267 (production stream)
  *   susnet_device_tick     (new) step counter in device memory: captured launches replay as a hipGraph
  *   susnet_bind_tape       (numpy's own MT19937 words: decisions equal the reference's for that seed)
@@ -295,6 +296,10 @@ int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *
  * environments are not touched. */
 int susnet_featurize(susnet_env *env, const void *rows, int32_t rows_dtype, int64_t n_rows, const susnet_obs_spec *obs,
                      void *stream);
+
+/* ImposterScentFeaturizer (src/features/component.py:336-380; the one real-valued feature of the reference) of n_rows
+ * FLATTENED states (layout and dtypes as susnet_featurize): out [n_rows][4] float32, 16-byte aligned. */
+int susnet_scent(susnet_env *env, const void *rows, int32_t rows_dtype, int64_t n_rows, float *out, void *stream);
 
 int susnet_export_state(susnet_env *env, const susnet_state_view *view, void *stream);
 int susnet_import_state(susnet_env *env, const susnet_state_view *view, void *stream);

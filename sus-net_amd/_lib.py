@@ -32,7 +32,7 @@ EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
     "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_step",
     "susnet_rollout", "susnet_record_layout", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
-    "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append",
+    "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append", "susnet_scent",
 ]
 
 
@@ -169,6 +169,7 @@ def lib():
     L.susnet_device_tick.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.susnet_poll_errors.argtypes = [C.c_void_p, P(C.c_uint32), C.c_void_p]
     L.susnet_ring_append.argtypes = [C.c_void_p, P(RingIO), C.c_void_p]
+    L.susnet_scent.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         if name not in ("susnet_last_error", "susnet_destroy"):
             getattr(L, name).restype = C.c_int

@@ -777,6 +777,41 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     return SUSNET_OK;
 }
 
+// ImposterScentFeaturizer (src/features/component.py:336-380), the one real-valued component: for every living agent other
+// than agent 0 ("the imposter", component.py:350), (n - dx) / n and (n - dy) / n -- Python floats, i.e. float64, rounded to
+// float32 when added to the float32 accumulator -- go to one of four float32 sums [x > 0, x <= 0, y > 0, y <= 0], in agent order.
+__global__ __launch_bounds__(64) void k_scent(Consts c, const void *rows, int dtype, int64_t n_rows, int S_row, float *out) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= n_rows) return;
+    const int A = c.A;
+    const int64_t base = b * S_row;
+    const double n = (double)c.N;
+    const int ix = row_value(rows, dtype, base), iy = row_value(rows, dtype, base + 1);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 1; i < A; i++) {
+        if (row_value(rows, dtype, base + 2 * A + i) == 0) continue; // alive_agents[i]
+        const int dx = row_value(rows, dtype, base + 2 * i) - ix, dy = row_value(rows, dtype, base + 2 * i + 1) - iy;
+        const float xs = (float)((n - (double)dx) / n), ys = (float)((n - (double)dy) / n);
+        if (xs > 0.0f) acc[0] = __fadd_rn(acc[0], xs);
+        else acc[1] = __fadd_rn(acc[1], xs);
+        if (ys > 0.0f) acc[2] = __fadd_rn(acc[2], ys);
+        else acc[3] = __fadd_rn(acc[3], ys);
+    }
+    *reinterpret_cast<float4 *>(out + 4 * b) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+extern "C" int susnet_scent(susnet_env *env, const void *rows, int32_t rows_dtype, int64_t n_rows, float *out, void *stream) {
+    if (!env || !rows || !out || n_rows < 0) return fail(SUSNET_E_INVALID, "susnet_scent: null argument / negative n_rows");
+    if (rows_dtype != SUSNET_U8 && rows_dtype != SUSNET_I32 && rows_dtype != SUSNET_I64 && rows_dtype != SUSNET_F32 && rows_dtype != SUSNET_F64)
+        return fail(SUSNET_E_INVALID, "rows dtype must be U8 / I32 / I64 / F32 / F64");
+    if ((uintptr_t)out % 16) return fail(SUSNET_E_INVALID, "susnet_scent: out must be 16-byte aligned");
+    if (n_rows == 0) return SUSNET_OK;
+    hipLaunchKernelGGL(k_scent, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), env->c, rows, (int)rows_dtype,
+                       n_rows, (int)env->layout.obs_raw_size, out);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // replay ring (susnet_ring_append)
 // ---------------------------------------------------------------------------------------------------

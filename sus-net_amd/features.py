@@ -9,7 +9,7 @@ kernel (``env.featurize`` -> ``susnet_featurize``); ``fit()`` with no argument o
 one ``(spatial, non_spatial)`` pair per agent with the reference shapes and channel / column orders.
 
 * ``FlatFeaturizer``        model_ready.py:309-370   -> ``(zeros[B, T, 1], feats[B, T, F])`` per agent
-  (+ ``imposter_scent``: component.py:336-380, the one real-valued component, as device-tensor arithmetic)
+  (+ ``imposter_scent``: component.py:336-380, the one real-valued component: the ``susnet_scent`` kernel)
 * ``GlobalFeaturizer``      model_ready.py:219-306   -> ``(spatial[B, T, A+2, N, N], [alive, job_status, onehot(agent)])``
 * ``PerspectiveFeaturizer`` model_ready.py:82-216    -> per-agent channel rotation (self first) of the same planes
 """
@@ -23,29 +23,25 @@ from .env import ObsConfig
 
 
 def imposter_scent(env, raw: torch.Tensor) -> torch.Tensor:
-    """``ImposterScentFeaturizer`` (src/features/component.py:336-380) over flattened states ``raw[..., S]``: for every
-    alive agent other than agent 0, ``(N - dx) / N`` and ``(N - dy) / N`` (Python floats, i.e. float64) are accumulated
-    into a float32 4-vector ``[x>0, x<=0, y>0, y<=0]`` in agent order.  Device-tensor arithmetic in exactly that
-    order and precision (the only real-valued feature of the reference; the HIP writers carry small integers)."""
-    A, N = env.n_agents, env.n_rows
-    r = raw.to(torch.float64)
-    x, y, alive = r[..., 0:2 * A:2], r[..., 1:2 * A:2], r[..., 2 * A:3 * A] != 0
-    out = torch.zeros(*raw.shape[:-1], 4, dtype=torch.float32, device=raw.device)
-    for i in range(1, A):
-        xs = ((N - (x[..., i] - x[..., 0])) / N).to(torch.float32)
-        ys = ((N - (y[..., i] - y[..., 0])) / N).to(torch.float32)
-        zero = torch.zeros_like(xs)
-        out[..., 0] += torch.where(alive[..., i] & (xs > 0), xs, zero)
-        out[..., 1] += torch.where(alive[..., i] & ~(xs > 0), xs, zero)
-        out[..., 2] += torch.where(alive[..., i] & (ys > 0), ys, zero)
-        out[..., 3] += torch.where(alive[..., i] & ~(ys > 0), ys, zero)
-    return out
+    """``ImposterScentFeaturizer`` (src/features/component.py:336-380) over flattened states ``raw[..., S]`` (any of the
+    dtypes ``env.featurize`` accepts): ``[..., 4]`` float32 from the ``susnet_scent`` kernel -- the reference's float64
+    quotients rounded to float32 and summed in float32, in agent order."""
+    import ctypes as C
+
+    from . import _lib as L
+
+    rows = raw.to(env.device).reshape(-1, raw.shape[-1]).contiguous()
+    assert rows.dtype in env._ROW_DTYPES, f"unsupported state dtype {rows.dtype}"
+    out = torch.empty(rows.shape[0], 4, dtype=torch.float32, device=env.device)
+    with torch.cuda.device(env.device):
+        L.check(env.lib.susnet_scent(env._h, rows.data_ptr(), env._ROW_DTYPES[rows.dtype], rows.shape[0], out.data_ptr(), env._stream()))
+    return out.reshape(*raw.shape[:-1], 4)
 
 
 class FlatFeaturizer:
     """Concatenation of flat components (CompositeFeaturizer + FlatFeaturizer, model_ready.py:309-370).  Every component
     of src/features/component.py that works in the reference is accepted; all but ``"scent"`` are written by the HIP
-    kernels, ``"scent"`` (real-valued, unused by the reference's notebooks) is torch arithmetic on the same device."""
+    kernels' byte images, ``"scent"`` (real-valued, unused by the reference's notebooks) by its own small kernel."""
 
     def __init__(self, env, components: Sequence[str]):
         self.env = env
