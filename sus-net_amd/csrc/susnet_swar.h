@@ -53,6 +53,7 @@ struct Swar {
     uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes (constant within an episode)
     uint32_t jobs_obs[2];      // x0 y0 x1 y1 | x2 y2 x3 y3 of the job cells (observation bytes; constant within an episode)
     uint32_t jd;               // completed: 0x01 per job
+    uint32_t nact[A];          // len(agent_action_map[i]) (constant within an episode)
 };
 
 // (Env bitmasks + packed store) -> byte-parallel form.  Runs once per launch and after each reset.
@@ -76,6 +77,7 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
         w.al[q] |= ((e.alive >> i) & 1u) << sh;
         const uint32_t is = (imp >> i) & 1u;
         w.im80[q] |= (is << 7) << sh;
+        w.nact[i] = S::nr_crew(c) + is; // imposters have one more action (base.py:82-99, pred_prey.py:4-19)
 #pragma unroll
         for (int s = 0; s < W::NI; s++) {
             const bool mine = is && seen == (uint32_t)s;
@@ -136,7 +138,7 @@ __device__ __forceinline__ void sample_actions_swar(const Consts &c, const Swar<
         if (i == 0 || k != S::kAw.word[i - 1])
             word = POS >= 0 ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * Wt, (POS >= 0 ? POS : 0) * S::kAw.W + k)
                             : as.word(rng, tick * Wt + (uint64_t)k);
-        const uint64_t p = (uint64_t)word * (uint64_t)(S::nr_crew(c) + swar_is_imp(w, i)); // imposters have one more action
+        const uint64_t p = (uint64_t)word * (uint64_t)w.nact[i];
         act[i / 4] |= (uint32_t)(p >> 32) << (8 * (i & 3));
         word = (uint32_t)p;
     }
@@ -148,7 +150,7 @@ __device__ __forceinline__ void sample_actions_swar(const Consts &c, const Swar<
 #pragma unroll
     for (int q = 0; q < W::NW; q++) act[q] = 0;
 #pragma unroll
-    for (int i = 0; i < W::A; i++) act[i / 4] |= rng.bounded(S::nr_crew(c) + swar_is_imp(w, i)) << (8 * (i & 3));
+    for (int i = 0; i < W::A; i++) act[i / 4] |= rng.bounded(w.nact[i]) << (8 * (i & 3));
 }
 
 // ranks (byte = rank | 0x80) from a turn order (4 bits per turn): the numpy-parity path shuffles an order list
@@ -205,7 +207,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         for (int i = 0; i < A; i++) {
             // address = row << 8 | cell: byte i of `rows` and of `xy`
             const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(i & 3)) << 8) | (uint32_t)(i & 3);
-            d[i] = T.move[__builtin_amdgcn_perm(rows[i / 4], w.xy[i / 4], sel)];
+            d[i] = lds_move_lookup(__builtin_amdgcn_perm(rows[i / 4], w.xy[i / 4], sel));
         }
 #pragma unroll
         for (int q = 0; q < NW; q++) dest[q] = 0;
@@ -249,23 +251,26 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                     cand[q] = attempt ? (zero80(pos ^ cbb) & crew80) : 0u;
                     nc += (uint32_t)__popc(cand[q]);
                 }
-                uint32_t r = 0; // base.py:497: uniform among the candidates, ascending agent index
-                if (RNG::kNumpy) {
-                    if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc); // numpy draws nothing for a single candidate
-                } else { // production protocol: one word per kill, its value only matters with several candidates
-                    if (__builtin_expect(nc > 1u, 0)) r = rng.bounded(nc);
-                    else rng.cur += (nc == 1u) ? 1ull : 0ull;
-                }
-                uint32_t v80[NW]; // the victim: r-th candidate
-                {
-                    uint32_t c0 = cand[0], c1 = NW > 1 ? cand[NW - 1] : 0u;
-                    for (uint32_t k = 0; k < r; k++) { // (rare: several candidates)
-                        const bool lo = c0 != 0u;
-                        c0 = lo ? (c0 & (c0 - 1u)) : c0;
-                        c1 = lo ? c1 : (c1 & (c1 - 1u));
+                // base.py:497: uniform among the candidates (ascending agent index).  With one candidate -- nearly always --
+                // the victim is the lowest set flag; several candidates (rare) are handled behind a wave-uniform branch.
+                uint32_t v80[NW];
+                v80[0] = cand[0] & (0u - cand[0]);
+                if (NW > 1) v80[NW - 1] = cand[0] != 0u ? 0u : (cand[NW - 1] & (0u - cand[NW - 1]));
+                const uint64_t word_pos = rng.cur; // production protocol: one word per landed kill, its value only matters with several candidates
+                if (!RNG::kNumpy) rng.cur += nc != 0u ? 1ull : 0ull;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(nc > 1u) != 0ull, 0)) {
+                    if (nc > 1u) {
+                        if (!RNG::kNumpy) rng.cur = word_pos; // (the draw below takes the word and advances the cursor itself)
+                        const uint32_t r = rng.bounded(nc); // numpy draws nothing for a single candidate: only here
+                        uint32_t c0 = cand[0], c1 = NW > 1 ? cand[NW - 1] : 0u;
+                        for (uint32_t k = 0; k < r; k++) {
+                            const bool lo = c0 != 0u;
+                            c0 = lo ? (c0 & (c0 - 1u)) : c0;
+                            c1 = lo ? c1 : (c1 & (c1 - 1u));
+                        }
+                        v80[0] = c0 & (0u - c0);
+                        if (NW > 1) v80[NW - 1] = c0 != 0u ? 0u : (c1 & (0u - c1));
                     }
-                    v80[0] = c0 & (0u - c0);
-                    if (NW > 1) v80[NW - 1] = c0 != 0u ? 0u : (c1 & (0u - c1));
                 }
                 const bool hit = nc != 0u;
                 e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
@@ -345,7 +350,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     }
 
     // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
-    uint32_t wsel = 0; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
+    uint32_t wsel; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
     {
         int alive_imp = 0, alive_all = 0;
 #pragma unroll
@@ -354,14 +359,17 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             alive_imp += __popc((w.al[q] << 7) & w.im80[q] & kLive[q]);
         }
         const int done_jobs = __popc(w.jd);
-        done = false;
+        bool crew_won, imp_won; // (selects, no branches: every lane evaluates both rules)
         if (!W::kBase) {
-            if (J != 0 && done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; wsel = 16u; }
-            else if (alive_all - alive_imp == 0) { done = true; e.flags |= FLAG_IMP_WON; wsel = 32u; }
+            crew_won = J != 0 && done_jobs == J;
+            imp_won = !crew_won && alive_all - alive_imp == 0;
         } else {
-            if (alive_imp == 0 || done_jobs == J) { done = true; e.flags |= FLAG_CREW_WON; wsel = 16u; }
-            else if (alive_all - alive_imp <= alive_imp) { done = true; e.flags |= FLAG_IMP_WON; wsel = 32u; }
+            crew_won = alive_imp == 0 || done_jobs == J;
+            imp_won = !crew_won && alive_all - alive_imp <= alive_imp;
         }
+        done = crew_won || imp_won;
+        e.flags |= (crew_won ? FLAG_CREW_WON : 0u) | (imp_won ? FLAG_IMP_WON : 0u);
+        wsel = crew_won ? 16u : (imp_won ? 32u : 0u);
     }
     // ---- rewards: assignments -> _merge_rewards (base.py:553-563) -> zero fill (389-390), one lookup per agent in the
     // host-evaluated table [win][index < n_imposters][dead][assignment code]; byte = 4 * table index
@@ -376,7 +384,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             idx4[q] = code4 + dead16 + neg32[q > 0 ? 1 : 0] + (wsel << 2) * k01;
         }
 #pragma unroll
-        for (int i = 0; i < A; i++) rr[i] = *reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(T.rew) + ((idx4[i / 4] >> (8 * (i & 3))) & 0xffu));
+        for (int i = 0; i < A; i++) rr[i] = lds_reward_lookup((idx4[i / 4] >> (8 * (i & 3))) & 0xffu);
     }
     // base.py:392-395: t saturates at max_time_steps - 1
     trunc = false;

@@ -151,3 +151,85 @@ def test_device_code_has_no_scratch_memory_traffic(pkg, tmp_path):
         scratch = [ln for ln in asm.splitlines() if "scratch_" in ln]
         assert not scratch, f"{obj.name}: {len(scratch)} scratch instructions, e.g. {scratch[:3]}"
     assert muls > 1000, "disassembly looks empty"
+
+
+def _vgprs(operand):
+    """'v12' -> {12}, 'v[4:7]' -> {4..7}, anything else -> empty."""
+    import re
+
+    m = re.fullmatch(r"v(\d+)", operand)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def store_data_hazards(asm, window=2):
+    """Vector writes to the data registers of a > 64-bit store within `window` wait states after it.
+
+    The store reads its data over several cycles; gfx950 needs two wait states before a VALU instruction may overwrite
+    them (measured: record dwords of lanes 12-15 / 28-31 carried the next tick's values).  The compiler inserts the
+    `s_nop` only when the store's scalar-offset field is a constant, which is why BufDst::st128 keeps it 0."""
+    import re
+
+    lines = []
+    for ln in asm.splitlines():
+        ln = ln.split("//")[0].strip()
+        if ln and not ln.endswith(":") and not ln.startswith((".", ";", "/")):
+            lines.append(ln)
+    # data operand: first for buffer stores, second (after the address) for global / flat stores
+    wide = re.compile(r"^(?:buffer_store_(?:dwordx[34]|format_xyzw?)\s+|(?:global|flat)_store_dwordx[34]\s+[^,]+,\s*)(v\[\d+:\d+\])")
+    bad = []
+    for i, ln in enumerate(lines):
+        m = wide.match(ln)
+        if not m:
+            continue
+        data = _vgprs(m.group(1))
+        waited = 0
+        for nxt in lines[i + 1 : i + 1 + window]:
+            if waited >= window or nxt.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")):
+                break
+            mn = re.match(r"^s_nop\s+(\d+)", nxt)
+            if mn:
+                waited += int(mn.group(1)) + 1
+                continue
+            if nxt.startswith("v_"):
+                ops = nxt.split(None, 1)[1].split(",") if " " in nxt else []
+                if ops and _vgprs(ops[0].strip()) & data:
+                    bad.append((ln, nxt))
+            waited += 1
+    return bad
+
+
+def test_store_data_hazard_checker_flags_the_measured_case():
+    asm = "\n".join(
+        [
+            "\tbuffer_store_dwordx4 v[178:181], v91, s[76:79], s6 offen   // 0001: E07C1000",
+            "\tv_alignbit_b32 v179, v53, v52, 24   // 0002: D1CE00B3",
+        ]
+    )
+    assert len(store_data_hazards(asm)) == 1
+    ok = asm.replace("\tv_alignbit", "\ts_nop 1\n\tv_alignbit")
+    assert store_data_hazards(ok) == []
+    assert store_data_hazards("global_store_dwordx4 v[2:3], v[4:7], off\nv_lshl_add_u64 v[2:3], v[2:3], 0, s[16:17]") == []
+    assert len(store_data_hazards("global_store_dwordx4 v[2:3], v[4:7], off\nv_mov_b32_e32 v7, 0")) == 1
+
+
+def test_device_code_never_overwrites_wide_store_data_too_early(pkg, tmp_path):
+    import shutil
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = tmp_path / "libsusnet_hip.so"
+    shutil.copy(pkg._lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    stores = 0
+    for obj in [p for p in tmp_path.iterdir() if "gfx950" in p.name]:
+        asm = subprocess.run([objdump, "-d", str(obj)], check=True, capture_output=True, text=True).stdout
+        stores += asm.count("_store_dwordx4")
+        bad = store_data_hazards(asm)
+        assert not bad, f"{obj.name}: {len(bad)} wide-store data hazards, e.g. {bad[:3]}"
+    assert stores > 100, "disassembly looks empty"
