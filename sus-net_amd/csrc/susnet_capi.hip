@@ -70,6 +70,42 @@ __global__ __launch_bounds__(kBlock) void k_sample(Consts c, State s, void *out,
     finish_rng(s, b, rng);
 }
 
+// sample_actions() on the production stream.  The action stream is indexed by (env id, tick) alone, so all the kernel needs of
+// an environment is its roles (which agents draw from the imposter's action list) and the tick: no LDS tables, no state load
+// beyond the role bit of the agent words, the draws go straight to the output.  (One launch per tick is latency-bound: the
+// generic k_sample above spends three dependent memory round trips before its first draw.)
+struct ActionSink {
+    void *out;
+    int32_t dtype;
+    int64_t sa, k0;
+    __device__ __forceinline__ void set_act(int i, uint32_t a) const { store_action(out, dtype, (int64_t)i * sa + k0, a); }
+};
+__global__ __launch_bounds__(kBlock) void k_sample_philox(Consts c, State s, void *out, int32_t dtype, int64_t sa, int64_t sb, uint64_t tick) {
+    using S = GenericSpec;
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; // (< Bp: rows are padded, every lane may load)
+    warm_kernargs<sizeof(Consts) + sizeof(State) + 40>();
+    uint32_t roles = (1u << c.n_imp) - 1u; // fixed roles: the first n_imposters agents (base.py:286-290 without the shuffle)
+    if (c.shuffle_imp) {                   // else bit 9 of every agent word; loads first, no branch between them
+        uint32_t w[SUSNET_MAX_AGENTS];
+#pragma unroll
+        for (int i = 0; i < SUSNET_MAX_AGENTS; i++) w[i] = (uint32_t)s.agent[(size_t)(i < c.A ? i : c.A - 1) * c.Bp + b];
+        roles = 0;
+#pragma unroll
+        for (int i = 0; i < SUSNET_MAX_AGENTS; i++) roles |= (i < c.A ? (w[i] >> 9) & 1u : 0u) << i;
+    }
+    uint64_t tick_word = tick;
+    if (c.dev_tick) tick_word = s.tickw[b];
+    if (b >= c.B) return;
+    Env e = {};
+    e.imp = roles;
+    PhiloxRng rng;
+    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0ull);
+    ActionStream as;
+    as.init();
+    ActionSink sink = {out, dtype, sa, b * sb};
+    sample_actions_env<S>(c, sink, e, rng, as, uniform64(tick_word));
+}
+
 // Device-resident step counter (susnet_device_tick): one copy per environment, read and advanced by the lane that owns the
 // environment inside the stepping kernels themselves -- no launch of its own, no word that one workgroup writes while another reads.
 __global__ void k_fill_tick(Consts c, State s, uint64_t tick) {
@@ -619,7 +655,7 @@ extern "C" int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t
     if (env->cfg.rng_mode == SUSNET_RNG_TAPE)
         hipLaunchKernelGGL(k_sample<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb, env->ticks);
     else
-        hipLaunchKernelGGL(k_sample<PhiloxRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb, env->ticks);
+        hipLaunchKernelGGL(k_sample_philox, grid_for(env), dim3(kBlock), 0, st, env->c, env->s, actions_out, dtype, sa, sb, env->ticks);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }

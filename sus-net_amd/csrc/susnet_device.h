@@ -24,6 +24,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -79,6 +80,38 @@ enum : int { RW_KILL = 0, RW_FIX = 1, RW_SAB = 2, RW_TSR = 3, RW_END = 4, RW_DEA
 template <class RT> __device__ __forceinline__ RT rw(const Consts &c, int k);
 template <> __device__ __forceinline__ double rw<double>(const Consts &c, int k) { return c.dr[k]; }
 template <> __device__ __forceinline__ float rw<float>(const Consts &c, int k) { return c.fr[k]; }
+
+// Kernel arguments are read with scalar loads where they are first needed; the argument block here is ~2.5 KB (Consts carries
+// the tables), i.e. 40 cache lines of 64 B, and every first touch of a line is a miss that the wave waits for on its own
+// (the compiler does not hoist the loads above branches).  A kernel that runs once per tick pays those misses back to back:
+// measured ~1 us of a 4 us step.  warm_kernargs<BYTES>() touches every line that holds scalars (not the table image, which
+// is read with vector loads) in ONE batch at the top of the kernel, so the later loads hit the scalar cache.
+constexpr int kTableImageBegin = 0x70, kTableImageEnd = 0x70 + 4 * (16 + 64 + 384); // grid_rows .. move_tab (static_assert below)
+template <int OFF, int END>
+struct KernargToucher {
+    static constexpr bool kInTables = OFF >= ((kTableImageBegin + 63) & ~63) && OFF + 64 <= (kTableImageEnd & ~63);
+    template <class P>
+    static __device__ __forceinline__ void issue(P p, uint32_t *sink) {
+        if constexpr (OFF < END) {
+            if constexpr (!kInTables) asm volatile("s_load_dword %0, %1, %2" : "=s"(sink[OFF / 64]) : "s"(p), "n"(OFF));
+            KernargToucher<OFF + 64, END>::issue(p, sink);
+        }
+    }
+    // (after the wait: keeps every destination register reserved until its load has landed)
+    static __device__ __forceinline__ void retire(const uint32_t *sink) {
+        if constexpr (OFF < END) {
+            if constexpr (!kInTables) asm volatile("" ::"s"(sink[OFF / 64]));
+            KernargToucher<OFF + 64, END>::retire(sink);
+        }
+    }
+};
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    uint32_t sink[(BYTES + 63) / 64];
+    KernargToucher<0, BYTES>::issue(__builtin_amdgcn_kernarg_segment_ptr(), sink);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    KernargToucher<0, BYTES>::retire(sink);
+}
 
 // Device pointers into the caller's state blob (SoA, row stride Bp).
 struct State {
@@ -382,20 +415,44 @@ template <>
 struct StoreFor<GenericSpec> { using type = LdsStore; };
 
 // Fill the wave-shared tables (all 64 lanes take part) and carve the rest of the dynamic LDS.
-// STEP_TABLES: also load the move and reward tables (kernels that step); the others only need grid + spawn cells
-template <class S, bool STEP_TABLES = true>
-__device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
+// STEP_TABLES: also load the move and reward tables (kernels that step); the others only need grid + spawn cells.
+// Two phases, so that a launch-latency-bound kernel (one step per launch) can put its state and action loads between them and
+// pay ONE memory round trip for everything: issue() reads the tables from the kernel-argument segment into registers with
+// unconditional loads (a lane past a table's end re-reads its last word: no branch, hence no wait, between the loads),
+// commit() writes them to LDS.
+template <bool STEP_TABLES>
+struct TableLoad {
+    uint32_t g0, g1, mv[6], rw, cp;
+    __device__ __forceinline__ void issue(const Consts &c, const int32_t *comp, int tid) {
+        const uint32_t *img = c.grid_rows; // grid_rows[16] and valid_xy[64] are adjacent, in LDS order
+        static_assert(offsetof(Consts, valid_xy) == offsetof(Consts, grid_rows) + 4 * SUSNET_MAX_GRID, "table image");
+        static_assert(offsetof(Consts, grid_rows) == kTableImageBegin && offsetof(Consts, dr) == kTableImageEnd, "warm_kernargs skips the table image");
+        g0 = img[tid];
+        g1 = img[64 + (tid & 15)];
+        if (STEP_TABLES) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) mv[k] = c.move_tab[k * kBlock + tid];
+            rw = __float_as_uint(c.rew_tab[tid < 48 ? tid : 47]);
+        }
+        cp = comp ? (uint32_t)comp[tid & 15] : 0u;
+    }
+    __device__ __forceinline__ void commit(uint32_t *smem, int tid, bool with_comp) const {
+        smem[tid] = g0;
+        smem[64 + (tid & 15)] = g1;
+        if (with_comp) smem[80 + (tid & 15)] = cp;
+        if (STEP_TABLES) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) smem[96 + k * kBlock + tid] = mv[k];
+            smem[480 + (tid < 48 ? tid : 47)] = rw;
+        }
+    }
+};
+template <class S>
+__device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
     Tables T;
-    if (tid < SUSNET_MAX_GRID) smem[tid] = c.grid_rows[tid];
-    smem[16 + tid] = c.valid_xy[tid];
     T.grid = smem;
     T.valid = reinterpret_cast<const uint8_t *>(smem + 16);
     T.comp = smem + 80;
-    if (STEP_TABLES) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) smem[96 + k * kBlock + tid] = c.move_tab[k * kBlock + tid];
-        if (tid < 48) reinterpret_cast<float *>(smem + 480)[tid] = c.rew_tab[tid];
-    }
     T.move = reinterpret_cast<const uint8_t *>(smem + 96);
     T.rew = reinterpret_cast<const float *>(smem + 480);
     uint32_t *rest = smem + kTableWords;
@@ -403,9 +460,20 @@ __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
     T.perm = reinterpret_cast<uint8_t *>(rest);
     T.stage = rest;
+    return T;
+}
+__device__ __forceinline__ void wave_lds_publish() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class S, bool STEP_TABLES = true>
+__device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
+    Tables T = carve_lds<S>(c, smem, tid, st);
+    TableLoad<STEP_TABLES> tl;
+    tl.issue(c, nullptr, tid);
+    tl.commit(smem, tid, false);
+    wave_lds_publish();
     return T;
 }
 

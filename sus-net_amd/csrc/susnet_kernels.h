@@ -85,6 +85,29 @@ __device__ __forceinline__ void store_action(void *p, int dtype, int64_t k, uint
     else reinterpret_cast<int64_t *>(p)[k] = (int64_t)a;
 }
 
+// All A actions of one env: the dtype test is wave-uniform and made ONCE, so the loads of a branch are issued back to back
+// (a per-agent test put a wait between every two of them).
+template <class S, class Store>
+__device__ __forceinline__ void load_actions(const Consts &c, const StepArgs &a, int64_t b, Store &st) {
+    const int A = S::A(c);
+    const int64_t k0 = b * a.act_sb;
+    auto clamp = [](int64_t v) -> uint32_t {
+        if (v < 0) v = -1;
+        if (v > 0x7ffffff0ll) v = 0x7ffffff0ll;
+        return (uint32_t)(int32_t)v;
+    };
+    if (a.act_dtype == SUSNET_I64) {
+#pragma unroll
+        for (int i = 0; i < A; i++) st.set_act(i, clamp(reinterpret_cast<const int64_t *>(a.actions)[(int64_t)i * a.act_sa + k0]));
+    } else if (a.act_dtype == SUSNET_I32) {
+#pragma unroll
+        for (int i = 0; i < A; i++) st.set_act(i, clamp(reinterpret_cast<const int32_t *>(a.actions)[(int64_t)i * a.act_sa + k0]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < A; i++) st.set_act(i, clamp(reinterpret_cast<const uint8_t *>(a.actions)[(int64_t)i * a.act_sa + k0]));
+    }
+}
+
 template <class RNG>
 __device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG &rng) {
     s.rng[b] = rng.cur;
@@ -98,21 +121,28 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
     const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
     const bool active = b < c.B;
     typename StoreFor<S>::type st;
-    Tables T = setup_lds<S>(c, smem, tid, st);
-    if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
-    wave_lds_fence();
+    Tables T = carve_lds<S>(c, smem, tid, st);
+    warm_kernargs<sizeof(Consts) + sizeof(State) + sizeof(StepArgs) + sizeof(ObsArgs)>();
+    // One step per launch is latency-bound: every load the step needs is issued here, back to back and without a branch
+    // between them (state rows are padded to Bp, so lanes past B read their own padding; their action index is clamped),
+    // and only then are the tables written to LDS -- one memory round trip instead of one per table, per agent, per field.
+    TableLoad<true> tl;
+    tl.issue(c, o.comp, tid);
     Env e = {};
+    load_env<S>(c, s, st, b, e);
+    load_actions<S>(c, a, active ? b : 0, st);
+    RNG rng = make_rng<RNG>(c, s, b);
+    // step counter of the action stream: a kernel argument, or (graph-replayable launches) the env's own device word,
+    // identical in every env -- read here, advanced below by the same lane
+    uint64_t tick_word = a.tick;
+    if (c.dev_tick) tick_word = s.tickw[b];
+    tl.commit(smem, tid, true);
+    wave_lds_fence();
     if (active) {
         const int A = S::A(c);
-        load_env<S>(c, s, st, b, e);
-#pragma unroll
-        for (int i = 0; i < A; i++) st.set_act(i, load_action(a.actions, a.act_dtype, (int64_t)i * a.act_sa + b * a.act_sb));
-        RNG rng = make_rng<RNG>(c, s, b);
         bool done = false, trunc = false;
         uint32_t bits = 0;
-        // step counter of the action stream: a kernel argument, or (graph-replayable launches) the env's own device word,
-        // identical in every env -- read here, advanced below by the same lane
-        const uint64_t step_tick = c.dev_tick ? uniform64(s.tickw[b]) : a.tick;
+        const uint64_t step_tick = uniform64(tick_word);
         constexpr bool kDuelSpec = !S::kGeneric && S::kA == 2 && S::kJ == 0 && S::kVar == SUSNET_VARIANT_ITG && S::kStaticRoles && S::kFixedOrder;
         bool stepped = false;
         if constexpr (kDuelSpec) {

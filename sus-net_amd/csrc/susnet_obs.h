@@ -47,11 +47,7 @@ __host__ __device__ inline int flat_component_size(int comp, int A, int N, int n
 // A workgroup is ONE wave and the LDS executes a wave's instructions in issue order, so hand-offs between
 // lanes need only a compiler-level ordering point -- in particular NOT a wait for outstanding global stores
 // (a workgroup-scope fence would emit s_waitcnt vmcnt(0) every tick).
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+__device__ __forceinline__ void wave_lds_fence() { wave_lds_publish(); }
 
 // ---- row fill (owning lane); `row` = this env's F bytes inside the packed image -----------------------
 __device__ __forceinline__ void put_b(uint8_t *row, int f, int v) { row[f] = (uint8_t)(int8_t)v; }
