@@ -193,7 +193,7 @@ static int pick_spec(const Consts &c, bool float_exact) {
     if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG && !c.order_random && !c.shuffle_imp && c.n_imp == 1) return 2;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 1) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 2) return 4;
-    if (c.A == 5 && c.J == 5 && c.variant == SUSNET_VARIANT_TAGGING && c.order_random) return 6;
+    if (c.A == 5 && c.J == 5 && c.variant == SUSNET_VARIANT_TAGGING && c.order_random && c.n_imp == 1) return 6;
     if (c.A >= 2 && c.A <= 8 && c.J <= 8) return 10 + c.A; // SpecA<A>
     return 0;
 }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         } else if constexpr (UseSwar<S>::value) {
             // the index-order byte-parallel step (susnet_swar.h): validate like base.py:357-362 / 379-382, then repack
             using W = Swar<S>;
-            const uint32_t space_n = 8u;
+            const uint32_t space_n = 8u + (W::kTag ? (uint32_t)W::A : 0u); // base.py:360-362 / tagging.py:148-150
 #pragma unroll
             for (int i = 0; i < A; i++) {
                 const int32_t ai = (int32_t)st.act(i);
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 life.add_episode(e, trunc);
                 if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
                     uint32_t trow[(kRawF + 3) / 4];
-                    raw_row_swar<S>(w, trow);
+                    raw_row_swar<S>(w, trow, (uint32_t)c.tag_interval);
                     store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
                 }
                 reset_env<S>(c, T, st, tid, e, rng);
@@ -604,12 +604,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             }
             if (OUT == OUT_TRAJ_RAW8) {
                 uint32_t row[(kRawF + 3) / 4];
-                raw_row_swar<S>(w, row);
+                raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
                 store_packed_bytes<kRawF>(dobs, row);
             }
             if (kRec) { // (byte moves between statically known positions: the compiler folds them into v_perm / v_alignbyte)
                 uint32_t row[(kRawF + 3) / 4];
-                raw_row_swar<S>(w, row);
+                raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
                 constexpr int kNB = A + 2 + kRawF;
                 uint8_t by[(kNB + 3) / 4 * 4];
 #pragma unroll
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
 using SpecCfg2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>; // ImposterTrainingGround 1v1, no jobs, fixed order, imposter = agent 0 (any wall map)
 using SpecCfg3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1, -1, 1>; // FourRoomEnv 1v2, 4 jobs, random order (index-order SWAR step)
 using SpecCfg4 = Spec<8, 4, SUSNET_VARIANT_BASE, 1, -1, 2>; // FourRoomEnv 2v6, 4 jobs, random order (index-order SWAR step)
-using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
+using SpecTag5 = Spec<5, 5, SUSNET_VARIANT_TAGGING, 1, -1, 1>; // FourRoomEnvWithTagging 1v4, 5 jobs (notebooks/experiment.ipynb)
 // agent count compiled in, everything else read at run time (any variant / order / up to 8 jobs): the packed-VGPR
 // tables without a full specialisation
 template <int A_> using SpecA = Spec<A_, -1, -1, -1>;

@@ -1,12 +1,13 @@
-// susnet_swar.h -- index-order step for the compiled-in multi-agent games (3..8 agents, up to 4 jobs, FourRoomEnv /
-// ImposterTrainingGround rules): one lane per environment, every per-agent quantity a BYTE of a packed 32-bit word, the
-// whole step written as byte-parallel (SWAR) arithmetic over all agents at once.
+// susnet_swar.h -- index-order step for the compiled-in multi-agent games (3..8 agents, up to 8 jobs, FourRoomEnv /
+// ImposterTrainingGround / FourRoomEnvWithTagging rules): one lane per environment, every per-agent quantity a BYTE of a
+// packed 32-bit word, the whole step written as byte-parallel (SWAR) arithmetic over all agents at once.
 //
 // Reference behaviour (paths relative to the reference repo root):
 //   step             src/environment/base.py:332-407
 //   _agent_step      src/environment/base.py:462-533   (move / KILL / FIX / SABOTAGE)
 //   win conditions   src/environment/base.py:409-460, src/environment/pred_prey.py:78-99
 //   _merge_rewards   src/environment/base.py:553-563, zero fill 389-390
+//   tagging          src/environment/tagging.py:68-75,103-110 (tag actions), 148-213 (step), 180-207 (vote), 237-241 (reset)
 //
 // Why the agent loop of base.py:377-382 can be evaluated in INDEX order although the reference walks a shuffled order:
 //   * a move depends on nothing but the agent's own cell and action (base.py:484-487);
@@ -16,7 +17,9 @@
 //     with an earlier turn have moved, later ones have not) and its victim, if its own turn comes later, never acts.
 //     At most n_imposters kills per step: they are resolved in turn order, each over all agents at once, using the
 //     agents' turn RANKS (rank[i] < rank[killer] <=> agent i has already acted).
-// Everything else (win check, reward merge, truncation) is order-free.
+//   * a TAG action (tagging.py:103-110) moves nothing and reads one thing that depends on the order: whether its target is
+//     still alive at the tagger's turn -- i.e. alive after this step's kills, or killed by a killer whose turn comes later.
+// Everything else (vote, win check, reward merge, truncation) is order-free.
 #pragma once
 
 #include "susnet_device.h"
@@ -26,8 +29,9 @@ namespace susnet {
 
 template <class S>
 struct UseSwar {
-    static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kA <= 8 && S::kJ >= 0 && S::kJ <= 4 && S::kOrd >= 0 &&
-                                  (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG) && (S::kNI == 1 || S::kNI == 2);
+    static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kA <= 8 && S::kJ >= 0 && S::kJ <= 8 && S::kOrd >= 0 &&
+                                  (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG || S::kVar == SUSNET_VARIANT_TAGGING) &&
+                                  (S::kNI == 1 || S::kNI == 2);
 };
 
 // 0x80 flags -> 0xff bytes
@@ -42,18 +46,20 @@ __device__ __forceinline__ uint32_t sel_bytes(uint32_t m, uint32_t a, uint32_t b
 
 template <class S>
 struct Swar {
-    static constexpr int A = S::kA, J = S::kJ, NW = (S::kA + 3) / 4, NI = S::kNI > 0 ? S::kNI : 1;
-    static constexpr bool kBase = S::kVar == SUSNET_VARIANT_BASE;
-    static constexpr uint32_t kKillIdx = kBase ? 6u : 5u; // role-relative index of KILL (base.py:91-99 / pred_prey.py:12-19)
+    static constexpr int A = S::kA, J = S::kJ, NW = (S::kA + 3) / 4, NI = S::kNI > 0 ? S::kNI : 1, JW = S::kJ > 4 ? 2 : 1;
+    static constexpr bool kTag = S::kVar == SUSNET_VARIANT_TAGGING;
+    static constexpr bool kBase = S::kVar != SUSNET_VARIANT_ITG; // FourRoomEnv action lists (base.py:82-99); tagging.py appends the tag actions
     uint32_t xy[NW];           // cell x | y << 4, one byte per agent
     uint32_t al[NW];           // alive: 0x01 per agent
     uint32_t im80[NW];         // imposter: 0x80 per agent (constant within an episode)
     uint32_t isel[NI];         // v_perm selector that extracts imposter s's byte (zeros elsewhere)
     uint32_t ihot[NI][NW];     // 0x80 at imposter s's byte
     uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes (constant within an episode)
-    uint32_t jobs_obs[2];      // x0 y0 x1 y1 | x2 y2 x3 y3 of the job cells (observation bytes; constant within an episode)
-    uint32_t jd;               // completed: 0x01 per job
+    uint32_t jobs_obs[J > 4 ? 4 : 2]; // x0 y0 x1 y1 | x2 y2 x3 y3 | ... of the job cells (observation bytes; constant within an episode)
+    uint32_t jd[JW];           // completed: 0x01 per job
     uint32_t nact[A];          // len(agent_action_map[i]) (constant within an episode)
+    // tagging.py: used_tag_actions (0x01 per agent), tag_counts (one byte per agent), tag_reset_timer
+    uint32_t used[NW], cnt[NW], timer;
 };
 
 // (Env bitmasks + packed store) -> byte-parallel form.  Runs once per launch and after each reset.
@@ -62,7 +68,8 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
     using W = Swar<S>;
     const uint32_t imp = S::imp(c, e.imp);
 #pragma unroll
-    for (int q = 0; q < W::NW; q++) { w.xy[q] = 0; w.al[q] = 0; w.im80[q] = 0; }
+    for (int q = 0; q < W::NW; q++) { w.xy[q] = 0; w.al[q] = 0; w.im80[q] = 0; w.used[q] = 0; w.cnt[q] = 0; }
+    w.timer = e.timer;
 #pragma unroll
     for (int s = 0; s < W::NI; s++) {
         w.isel[s] = 0x0c0c0c0cu;
@@ -77,7 +84,11 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
         w.al[q] |= ((e.alive >> i) & 1u) << sh;
         const uint32_t is = (imp >> i) & 1u;
         w.im80[q] |= (is << 7) << sh;
-        w.nact[i] = S::nr_crew(c) + is; // imposters have one more action (base.py:82-99, pred_prey.py:4-19)
+        w.nact[i] = S::nr_crew(c) + is + (W::kTag ? (uint32_t)(W::A - 1) : 0u); // imposters have one more action (base.py:82-99, pred_prey.py:4-19); tagging.py:68-75
+        if (W::kTag) {
+            w.used[q] |= ((e.used >> i) & 1u) << sh;
+            w.cnt[q] |= st.cnt(i) << sh;
+        }
 #pragma unroll
         for (int s = 0; s < W::NI; s++) {
             const bool mine = is && seen == (uint32_t)s;
@@ -86,13 +97,15 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
         }
         seen += is;
     }
-    w.jd = 0;
-    w.jobs_obs[0] = w.jobs_obs[1] = 0;
+#pragma unroll
+    for (int q = 0; q < W::JW; q++) w.jd[q] = 0;
+#pragma unroll
+    for (int q = 0; q < (W::J > 4 ? 4 : 2); q++) w.jobs_obs[q] = 0;
 #pragma unroll
     for (int j = 0; j < W::J; j++) {
         const uint32_t cell = st.job(j);
         w.jb[j] = cell * k01;
-        w.jd |= ((e.jd >> j) & 1u) << (8 * j);
+        w.jd[j / 4] |= ((e.jd >> j) & 1u) << (8 * (j & 3));
         w.jobs_obs[j / 2] |= ((cell & 15u) | ((cell >> 4) << 8)) << (16 * (j & 1));
     }
 }
@@ -109,7 +122,17 @@ __device__ __forceinline__ void from_swar(const Consts &c, const Swar<S> &w, Sto
         e.alive |= ((w.al[q] >> sh) & 1u) << i;
     }
 #pragma unroll
-    for (int j = 0; j < W::J; j++) e.jd |= ((w.jd >> (8 * j)) & 1u) << j;
+    for (int j = 0; j < W::J; j++) e.jd |= ((w.jd[j / 4] >> (8 * (j & 3))) & 1u) << j;
+    if (W::kTag) {
+        e.used = 0;
+#pragma unroll
+        for (int i = 0; i < W::A; i++) {
+            const int q = i / 4, sh = 8 * (i & 3);
+            e.used |= ((w.used[q] >> sh) & 1u) << i;
+            st.set_cnt(i, (w.cnt[q] >> sh) & 15u);
+        }
+        e.timer = w.timer;
+    }
 }
 
 // imposter flag (0 / 1) of agent i
@@ -181,23 +204,33 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     rng.align();
 
     // ---- action classes (0x80 per agent): alive agents only (base.py:477) --------------------------------------------------
-    uint32_t al80[NW], kill80[NW], fix80[NW], sab80[NW], mv80[NW], rows[NW];
+    uint32_t al80[NW], kill80[NW], fix80[NW], sab80[NW], mv80[NW], rows[NW], tag80[NW];
 #pragma unroll
     for (int q = 0; q < NW; q++) {
         const uint32_t a = act[q];
         const uint32_t g5 = (a + 0x7b7b7b7bu) & k80, g6 = (a + 0x7a7a7a7au) & k80; // action index >= 5 / >= 6
         al80[q] = (w.al[q] << 7) & kLive[q] & k80;
-        if (W::kBase) { // crew: 5 = FIX; imposter: 5 = SABOTAGE, 6 = KILL (base.py:82-99)
+        tag80[q] = 0;
+        if (W::kTag) { // base lists + the tag actions behind them (tagging.py:68-75): crew 6.., imposter 7..
+            const uint32_t g7 = (a + 0x79797979u) & k80;
+            tag80[q] = (g7 | (g6 & ~w.im80[q])) & kLive[q]; // NOT masked by alive: tagging.py:103-110 never checks the actor
+            kill80[q] = g6 & ~g7 & w.im80[q] & al80[q];
+            const uint32_t j5 = g5 & ~g6 & al80[q];
+            sab80[q] = j5 & w.im80[q];
+            fix80[q] = j5 & ~w.im80[q];
+            rows[q] = sel_bytes(ff_from80(g5), 0x05050505u, a); // movers keep their row, everybody else reads the identity row
+        } else if (W::kBase) { // crew: 5 = FIX; imposter: 5 = SABOTAGE, 6 = KILL (base.py:82-99)
             kill80[q] = g6 & al80[q];
             const uint32_t j5 = g5 & ~g6 & al80[q];
             sab80[q] = j5 & w.im80[q];
             fix80[q] = j5 & ~w.im80[q];
+            rows[q] = a - (g6 >> 7); // row of the (action, cell) table: 0..4 = the move actions, 5 = identity (KILL index 6 -> 5)
         } else { // pred_prey.py:4-19: imposter 5 = KILL, no job actions
             kill80[q] = g5 & al80[q];
             sab80[q] = fix80[q] = 0;
+            rows[q] = a;
         }
         mv80[q] = ~g5 & al80[q];
-        rows[q] = a - (g6 >> 7); // row of the (action, cell) table: 0..4 = the move actions, 5 = identity (KILL index 6 -> 5)
     }
     // ---- destinations: one lookup per agent in the (action, cell) table (move() + _is_valid_position(), base.py:69-79, 548-551)
     uint32_t dest[NW];
@@ -221,8 +254,13 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 
     // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
     uint32_t kc80[NW], pend80[NW]; // killers that landed a kill; victims killed before their own turn
+    uint32_t vk80[NI][NW], gek80[NI][NW]; // per kill turn: the victim; the agents that had not acted yet (tagging only)
 #pragma unroll
     for (int q = 0; q < NW; q++) kc80[q] = pend80[q] = 0;
+#pragma unroll
+    for (int it = 0; it < NI; it++)
+#pragma unroll
+        for (int q = 0; q < NW; q++) vk80[it][q] = gek80[it][q] = 0;
     {
         uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot: kill flag (0x80 / 0), rank | 0x80, cell
 #pragma unroll
@@ -280,6 +318,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                     const uint32_t hot = second_first ? w.ihot[s1][q] : w.ihot[s0][q];
                     kc80[q] |= hit ? hot : 0u;                                      // base.py:514-515 (the victim's slot ends as dead_penalty)
                     pend80[q] |= v80[q] & ge80[q];                                  // killed before its own turn: it never acts
+                    if (W::kTag) { vk80[it][q] = v80[q]; gek80[it][q] = ge80[q]; }
                 }
             }
         }
@@ -313,7 +352,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                 uint32_t cnt = 0;
 #pragma unroll
                 for (int q = 0; q < NW; q++) cnt += (uint32_t)__popc(on[q]);
-                uint32_t dj = (w.jd >> (8 * j)) & 1u;
+                uint32_t dj = (w.jd[j / 4] >> (8 * (j & 3))) & 1u;
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt > 1u) != 0ull, 0)) {
                     // several agents work on this job in one step: in turn order (base.py:377-382)
                     for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
@@ -344,8 +383,81 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                         sc80[q] |= sb ? on[q] : 0u;
                     }
                 }
-                w.jd = (w.jd & ~(1u << (8 * j))) | (dj << (8 * j));
+                w.jd[j / 4] = (w.jd[j / 4] & ~(1u << (8 * (j & 3)))) | (dj << (8 * (j & 3)));
             }
+        }
+    }
+
+
+    // ---- tag actions (tagging.py:103-110) and the vote (tagging.py:180-207) ------------------------------------------------------
+    float team = 0.0f; // team reward: vote outcome, then the win reward (tagging.py:196, 209-213)
+    if (W::kTag) {
+        const uint32_t hi = NW > 1 ? NW - 1 : 0;
+        uint32_t tgt[NW], vt80[NW];
+        uint32_t any_new = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            // k-th OTHER agent ascending: target = action - len(role list), + 1 from the actor's own index on (tagging.py:68-75)
+            const uint32_t nrb = 0x06060606u + (w.im80[q] >> 7);
+            uint32_t t = ((act[q] | k80) - nrb) & k7f; // (meaningful where tag80 is set)
+            const uint32_t idxb = q == 0 ? 0x03020100u : 0x07060504u;
+            t += (((t | k80) - idxb) & k80) >> 7;
+            tgt[q] = t & 0x07070707u;
+        }
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            // the target's alive flag at the tagger's turn: alive now (after this step's kills) ...
+            uint32_t tal80 = __builtin_amdgcn_perm(NW > 1 ? w.al[hi] : 0u, w.al[0], tgt[q]) << 7;
+            // ... or killed this step by a killer whose turn comes AFTER the tagger's (the tagger had already acted)
+#pragma unroll
+            for (int it = 0; it < NI; it++)
+                tal80 |= __builtin_amdgcn_perm(NW > 1 ? vk80[it][hi] : 0u, vk80[it][0], tgt[q]) & ~gek80[it][q];
+            vt80[q] = tag80[q] & ~(w.used[q] << 7) & tal80 & k80; // first tag of the interval, living target
+            w.used[q] |= vt80[q] >> 7;
+            any_new |= vt80[q];
+        }
+        if (__builtin_amdgcn_ballot_w64(any_new != 0u) != 0ull) { // tag_counts[target] += 1 per counted tag
+            uint64_t cn = (uint64_t)w.cnt[0] | ((uint64_t)(NW > 1 ? w.cnt[hi] : 0u) << 32);
+#pragma unroll
+            for (int i = 0; i < A; i++) {
+                const uint32_t bit = (vt80[i / 4] >> (8 * (i & 3) + 7)) & 1u;
+                const uint32_t sh = ((tgt[i / 4] >> (8 * (i & 3))) & 7u) << 3;
+                cn += (uint64_t)bit << sh;
+            }
+            w.cnt[0] = (uint32_t)cn;
+            if (NW > 1) w.cnt[hi] = (uint32_t)(cn >> 32);
+        }
+#pragma unroll
+        for (int q = 0; q < NW; q++) w.cnt[q] &= ff_from80((w.al[q] << 7) & k80); // tagging.py:180: tag_counts *= alive_agents
+        w.timer += 1u;                                                               // tagging.py:182
+        const bool due = w.timer >= (uint32_t)c.tag_interval;
+        if (__builtin_amdgcn_ballot_w64(due) != 0ull) { // tagging.py:184-207
+            uint32_t best = 0, highest = w.cnt[0] & 0xffu;
+#pragma unroll
+            for (int i = 1; i < A; i++) { // np.argmax: first maximum
+                const uint32_t v = (w.cnt[i / 4] >> (8 * (i & 3))) & 0xffu;
+                const bool gt = v > highest;
+                highest = gt ? v : highest;
+                best = gt ? (uint32_t)i : best;
+            }
+            uint32_t alive_sum = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) alive_sum += (uint32_t)__popc(w.al[q] & kLive[q] & k01);
+            const bool out = due && highest >= ((alive_sum + 1u) >> 1);
+            const uint64_t hot = (uint64_t)(out ? 1u : 0u) << (8u * best);
+            const uint64_t im = (uint64_t)w.im80[0] | ((uint64_t)(NW > 1 ? w.im80[hi] : 0u) << 32);
+            const bool vimp = ((im >> (8u * best + 7u)) & 1ull) != 0ull;
+            w.al[0] &= ~(uint32_t)hot;
+            if (NW > 1) w.al[hi] &= ~(uint32_t)(hot >> 32);
+            const float vote = c.fr[RW_VOTE];
+            team += out ? vote * (vimp ? -1.0f : 1.0f) : 0.0f; // tagging.py:196, sign as coded
+            e.m_kv += out ? (vimp ? (1u << 16) : (1u << 24)) : 0u;
+#pragma unroll
+            for (int q = 0; q < NW; q++) { // tagging.py:237-241
+                w.cnt[q] = due ? 0u : w.cnt[q];
+                w.used[q] = due ? 0u : w.used[q];
+            }
+            w.timer = due ? 0u : w.timer;
         }
     }
 
@@ -358,7 +470,9 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             alive_all += __popc(w.al[q] & kLive[q] & k01);
             alive_imp += __popc((w.al[q] << 7) & w.im80[q] & kLive[q]);
         }
-        const int done_jobs = __popc(w.jd);
+        int done_jobs = 0;
+#pragma unroll
+        for (int q = 0; q < W::JW; q++) done_jobs += __popc(w.jd[q]);
         bool crew_won, imp_won; // (selects, no branches: every lane evaluates both rules)
         if (!W::kBase) {
             crew_won = J != 0 && done_jobs == J;
@@ -373,7 +487,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     }
     // ---- rewards: assignments -> _merge_rewards (base.py:553-563) -> zero fill (389-390), one lookup per agent in the
     // host-evaluated table [win][index < n_imposters][dead][assignment code]; byte = 4 * table index
-    {
+    if (!W::kTag) {
         uint32_t idx4[NW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
@@ -385,6 +499,25 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         }
 #pragma unroll
         for (int i = 0; i < A; i++) rr[i] = lds_reward_lookup((idx4[i / 4] >> (8 * (i & 3))) & 0xffu);
+    } else {
+        // tagging.py:162-213: every agent starts from time_step_reward (no zero fill afterwards), assignments overwrite, the team
+        // reward (vote, then win) is added, indices [:n_imposters] are negated, the dead get dead_penalty.  float32 is exact here:
+        // the compiled-in kernels are only selected when every constant is a small integer
+        const float end = c.fr[RW_END];
+        team += wsel == 16u ? end : (wsel == 32u ? -1.0f * end : 0.0f);
+        const float r_tsr = 1.0f * c.fr[RW_TSR], r_kill = c.fr[RW_KILL], r_fix = c.fr[RW_FIX], r_sab = -1.0f * c.fr[RW_SAB], r_dead = c.fr[RW_DEAD];
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            const int q = i / 4;
+            const uint32_t m = 0x80u << (8 * (i & 3));
+            float r = r_tsr;
+            r = (kc80[q] & m) ? r_kill : r;
+            r = (fc80[q] & m) ? r_fix : r;
+            r = (sc80[q] & m) ? r_sab : r;
+            r += team;
+            if (i < NI) r *= -1.0f;
+            rr[i] = (w.al[q] & (m >> 7)) ? r : r_dead;
+        }
     }
     // base.py:392-395: t saturates at max_time_steps - 1
     trunc = false;
@@ -394,7 +527,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 
 // flatten_state (base.py:234-235) of the byte-parallel state as packed dwords: positions, alive, job cells, job status
 template <class S>
-__device__ __forceinline__ void raw_row_swar(const Swar<S> &w, uint32_t (&row)[(S::kRawF + 3) / 4]) {
+__device__ __forceinline__ void raw_row_swar(const Swar<S> &w, uint32_t (&row)[(S::kRawF + 3) / 4], uint32_t tag_interval = 0u) {
     using W = Swar<S>;
     constexpr int A = W::A, J = W::J, F = S::kRawF;
     uint8_t b[(F + 3) / 4 * 4];
@@ -415,7 +548,14 @@ __device__ __forceinline__ void raw_row_swar(const Swar<S> &w, uint32_t (&row)[(
 #pragma unroll
         for (int i = 0; i < 2 * J; i++) b[k++] = (uint8_t)(w.jobs_obs[i / 4] >> (8 * (i & 3)));
 #pragma unroll
-        for (int j = 0; j < J; j++) b[k++] = (uint8_t)((w.jd >> (8 * j)) & 1u);
+        for (int j = 0; j < J; j++) b[k++] = (uint8_t)((w.jd[j / 4] >> (8 * (j & 3))) & 1u);
+    }
+    if (W::kTag) { // tagging.py:220-230: used_tag_actions, tag_counts, steps until the vote
+#pragma unroll
+        for (int i = 0; i < A; i++) b[k++] = (uint8_t)((w.used[i / 4] >> (8 * (i & 3))) & 1u);
+#pragma unroll
+        for (int i = 0; i < A; i++) b[k++] = (uint8_t)(w.cnt[i / 4] >> (8 * (i & 3)));
+        b[k++] = (uint8_t)(tag_interval - w.timer);
     }
 #pragma unroll
     for (; k < (F + 3) / 4 * 4; k++) b[k] = 0;
