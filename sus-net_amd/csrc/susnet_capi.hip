@@ -430,6 +430,14 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
                     if (r == 0.0) r = rewards[3];                      // base.py:389-390
                     c.rew_tab[t * 16 + neg * 8 + dd * 4 + code] = (float)r;
                 }
+    if (cfg->variant == SUSNET_VARIANT_TAGGING) {
+        // tagging.py:162-213 adds a per-step team reward that the table above does not span: the byte-parallel step
+        // (susnet_swar.h) looks up only what an assignment left on an agent and does the rest in registers
+        c.rew_tab[0] = (float)(1.0 * rewards[3]);  // tagging.py:162: ones * time_step_reward
+        c.rew_tab[RC_KILL] = (float)rewards[0];
+        c.rew_tab[RC_FIX] = (float)rewards[1];
+        c.rew_tab[RC_SAB] = (float)(-1.0 * rewards[2]);
+    }
     c.seed = cfg->seed; c.env_id_base = cfg->env_id_base;
     { // 1v1 ImposterTrainingGround on a grid without walls, every reachable reward an integer in [-127, 127]: susnet_duel.h
         bool ok = e->float_exact && A == 2 && J == 0 && cfg->variant == SUSNET_VARIANT_ITG && !c.shuffle_imp && c.n_valid == N * N;

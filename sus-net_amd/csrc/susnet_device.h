@@ -339,7 +339,10 @@ struct Tables {
     uint32_t *stage;       // observation staging
 };
 
-constexpr uint32_t kTableWords = 16 + 64 + 16 + 384 + 64; // grid + valid + obs components + move table + rewards
+// grid + valid + obs components + move table + rewards, then the turn-rank tables of the byte-parallel rollouts (susnet_swar.h
+// RankLut: 120 x 2 words for the first five agents, 336 x 2 words for agents 5 .. 7; filled by the kernel that uses them)
+constexpr uint32_t kRankLut1Word = 16 + 64 + 16 + 384 + 64, kRankLut2Word = kRankLut1Word + 240;
+constexpr uint32_t kTableWords = kRankLut2Word + 672;
 
 // LDS byte address of word `word` of the kernel's dynamic LDS (every kernel here uses dynamic LDS only, so the static
 // size the intrinsic returns folds to a constant): table lookups through these integer addresses need no base add --

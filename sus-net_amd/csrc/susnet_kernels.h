@@ -519,6 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     typename StoreFor<S>::type st;
     Tables T = setup_lds<S>(c, smem, tid, st);
     if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
+    if (!RNG::kNumpy && RankLut<S>::kOk) build_rank_lut<S>(smem, tid);
     wave_lds_fence();
     Env e = {};
     RNG rng = make_rng<RNG>(c, s, active ? b : 0);
@@ -571,7 +572,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 }
             } else {
                 sample_actions_swar<S, POS>(c, w, rng, as, tick_base + (uint64_t)tick, act);
-                if (S::kOrd > 0) ranks_from_stream<S, POS>(c, 0u, rng, as, tick_base + (uint64_t)tick, true, R);
+                if (RankLut<S>::kOk) ranks_from_lut<S, POS>(rng, as, tick_base + (uint64_t)tick, R);
+                else if (S::kOrd > 0) ranks_from_stream<S, POS>(c, 0u, rng, as, tick_base + (uint64_t)tick, true, R);
                 else identity_ranks<S>(R);
             }
             if (kTraj) store_packed_bytes<A>(da, act);

@@ -192,6 +192,99 @@ __device__ __forceinline__ void identity_ranks(uint32_t (&R)[Swar<S>::NW]) {
     if (Swar<S>::NW > 1) R[Swar<S>::NW - 1] = 0x87868584u;
 }
 
+// ---- turn ranks from tables ---------------------------------------------------------------------------------------------------
+// ranks_from_stream (susnet_device.h) places agent k = 1 .. A-1 at slot d_k = the k-th shuffle digit of the tick; consecutive
+// digits of one action-stream word are the mixed-radix digits of ONE multiply -- hi32(w * (2*3*..)) = ((d_1 * 3 + d_2) * 4 +
+// d_3) * 5 + d_4, exactly, with lo32 the word's remainder -- so the rollouts look the result of the insertions up instead of
+// performing them: table 1 (index over d_1 .. d_4) holds the ranks of agents 0 .. 4 among themselves; table 2 (index over
+// d_5 .. d_{A-1}) holds the final ranks of agents 5 .. A-1 and, for every intermediate rank 0 .. 4, the final rank it ends up
+// at -- applied to table 1's bytes with one v_perm_b32.  Both tables are built in LDS by the kernel's own lanes at launch
+// (with the same insertion rule), so they cannot drift from ranks_from_stream, which the one-step kernels keep using.
+template <class S>
+struct RankLut {
+    static constexpr int A = S::kA;
+    static constexpr int K1 = A - 1 < 4 ? A - 1 : 4, K2 = A - 1 - K1; // digits served by table 1 / table 2
+    static constexpr uint32_t prod(int lo, int hi) { uint32_t p = 1; for (int k = lo; k <= hi; k++) p *= (uint32_t)k; return p; }
+    static constexpr uint32_t P1 = prod(2, K1 + 1), P2 = K2 > 0 ? prod(6, A) : 1u;
+    static constexpr bool same_word(int d0, int n) {
+        for (int d = d0 + 1; d < d0 + n; d++) if (S::kAw.word[d] != S::kAw.word[d0]) return false;
+        return true;
+    }
+    static constexpr bool kOk = S::kOrd > 0 && S::kStaticAw && A >= 2 && A <= 8 && same_word(A, K1) && (K2 == 0 || same_word(A + K1, K2));
+    static constexpr int kW1 = K1 + 1 > 4 ? 2 : 1; // words per entry of table 1
+};
+
+template <class S>
+__device__ __forceinline__ void build_rank_lut(uint32_t *smem, int tid) {
+    using L = RankLut<S>;
+    for (uint32_t p = (uint32_t)tid; p < L::P1; p += kBlock) {
+        uint32_t r[5] = {0, 0, 0, 0, 0}, d[5] = {0, 0, 0, 0, 0};
+        uint32_t x = p;
+#pragma unroll
+        for (int k = L::K1; k >= 1; k--) { d[k] = x % (uint32_t)(k + 1); x /= (uint32_t)(k + 1); } // d_1 is the most significant digit
+#pragma unroll
+        for (int k = 1; k <= L::K1; k++) {
+#pragma unroll
+            for (int q = 0; q < k; q++) r[q] += r[q] >= d[k] ? 1u : 0u;
+            r[k] = d[k];
+        }
+        smem[kRankLut1Word + p * L::kW1] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        if (L::kW1 > 1) smem[kRankLut1Word + p * L::kW1 + 1] = r[4];
+    }
+    if (L::K2 > 0) {
+        for (uint32_t p = (uint32_t)tid; p < L::P2; p += kBlock) {
+            uint32_t f[5] = {0, 1, 2, 3, 4}, r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t x = p;
+#pragma unroll
+            for (int k = L::A - 1; k >= 5; k--) { d[k] = x % (uint32_t)(k + 1); x /= (uint32_t)(k + 1); }
+#pragma unroll
+            for (int k = 5; k < L::A; k++) {
+#pragma unroll
+                for (int q = 0; q < 5; q++) f[q] += f[q] >= d[k] ? 1u : 0u;
+#pragma unroll
+                for (int q = 5; q < k; q++) r[q] += r[q] >= d[k] ? 1u : 0u;
+                r[k] = d[k];
+            }
+            smem[kRankLut2Word + 2 * p] = (f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24)) | k80;
+            smem[kRankLut2Word + 2 * p + 1] = (f[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24)) | k80; // (agents that do not exist: rank 0, like the insertion's initial value)
+        }
+    }
+}
+
+template <class S, int POS, int NW>
+__device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, ActionStream &as, uint64_t tick, uint32_t (&R)[NW]) {
+    using L = RankLut<S>;
+    constexpr int A = L::A;
+    const uint64_t W = (uint64_t)S::kAw.W;
+    auto fetch = [&](int k) __attribute__((always_inline)) {
+        return POS >= 0 ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * W, (POS >= 0 ? POS : 0) * S::kAw.W + k)
+                        : as.word(rng, tick * W + (uint64_t)k);
+    };
+    uint32_t w = as.rem; // what the tick's action draws left of their last word
+    if (S::kAw.word[A] != S::kAw.word[A - 1]) w = fetch(S::kAw.word[A]);
+    const uint64_t p1 = (uint64_t)w * (uint64_t)L::P1;
+    w = (uint32_t)p1;
+    const uint32_t a1 = lds_table_addr(kRankLut1Word) + (uint32_t)(p1 >> 32) * (4u * L::kW1);
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    const uint32_t lo = *(lds_u32_ptr)(uintptr_t)a1;
+    uint32_t hi = 0;
+    if (L::kW1 > 1) hi = *(lds_u32_ptr)(uintptr_t)(a1 + 4u);
+    if (L::K2 == 0) {
+        R[0] = lo | k80;
+        if (NW > 1) R[NW - 1] = hi | k80;
+    } else {
+        if (S::kAw.word[A + L::K1] != S::kAw.word[A + L::K1 - 1]) w = fetch(S::kAw.word[A + L::K1]);
+        const uint64_t p2 = (uint64_t)w * (uint64_t)L::P2;
+        w = (uint32_t)p2;
+        const uint32_t a2 = lds_table_addr(kRankLut2Word) + (uint32_t)(p2 >> 32) * 8u;
+        const uint32_t flo = *(lds_u32_ptr)(uintptr_t)a2, fhi = *(lds_u32_ptr)(uintptr_t)(a2 + 4u);
+        R[0] = __builtin_amdgcn_perm(fhi, flo, lo);                         // final rank of agents 0 .. 3
+        const uint32_t t = __builtin_amdgcn_perm(fhi, flo, hi);             // byte 0: agent 4
+        if (NW > 1) R[NW - 1] = __builtin_amdgcn_perm(fhi, t, 0x07060500u); // agent 4 | agents 5 .. 7
+    }
+    as.rem = w;
+}
+
 // One step.  act: role-relative action bytes (valid for their roles); R: turn ranks (byte = rank | 0x80).
 // Rewards go to rr[] (float32: the compiled-in kernels are only selected when every reward constant is float-exact).
 template <class S, class RNG>
@@ -328,66 +421,74 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     for (int q = 0; q < NW; q++) w.xy[q] = sel_bytes(ff_from80(pend80[q]), w.xy[q], newt[q]);
 
     // ---- FIX (base.py:518-524) / SABOTAGE (527-533): first job on the agent's own cell (544-546; job cells are distinct) ------
+    // Evaluated for all jobs without a branch per job, in AGENT space: on[j] = the actors standing on job j; an actor succeeds
+    // when the job's status is the one its role changes (crew: open, imposter: completed) -- one 3-input bit operation per word
+    // against the job's status broadcast to every byte; a job whose actor succeeded flips.  Exact as long as no job has two
+    // actors in the same step; two actors on job cells anywhere in an env (a superset, rare) send the wave to the turn-ordered
+    // loop instead.
     uint32_t fc80[NW], sc80[NW];
 #pragma unroll
     for (int q = 0; q < NW; q++) fc80[q] = sc80[q] = 0;
     if (W::kBase && J > 0) {
-        uint32_t ja80[NW], xy0[NW];
+        constexpr int JW = W::JW;
+        uint32_t ja80[NW], on[J][NW], onany[NW], acted[NW], tog[JW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
-            ja80[q] = (fix80[q] | sab80[q]) & ~pend80[q];
-            // job actors did not move: w.xy is still their cell (movers are excluded by ja80)
-            xy0[q] = w.xy[q];
+            ja80[q] = (fix80[q] | sab80[q]) & ~pend80[q]; // job actors did not move: w.xy is still their cell
+            onany[q] = acted[q] = 0;
         }
 #pragma unroll
+        for (int q = 0; q < JW; q++) tog[q] = 0;
+#pragma unroll
         for (int j = 0; j < J; j++) {
-            uint32_t on[NW];
-            uint32_t any = 0;
+            const uint32_t dj80 = (0u - ((w.jd[j / 4] >> (8 * (j & 3))) & 1u)) & k80; // the job's status at every agent byte
+            uint32_t n = 0;
 #pragma unroll
             for (int q = 0; q < NW; q++) {
-                on[q] = zero80(xy0[q] ^ w.jb[j]) & ja80[q];
-                any |= on[q];
+                on[j][q] = zero80(w.xy[q] ^ w.jb[j]) & ja80[q];
+                onany[q] |= on[j][q];
+                const uint32_t succ = on[j][q] & ~(w.im80[q] ^ dj80); // crew (flag 0) on an open job, imposter (0x80) on a completed one
+                acted[q] |= succ;
+                n += (uint32_t)__popc(succ);
             }
-            if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) {
-                uint32_t cnt = 0;
+            tog[j / 4] |= n << (8 * (j & 3));
+        }
+        uint32_t n_on = 0;
 #pragma unroll
-                for (int q = 0; q < NW; q++) cnt += (uint32_t)__popc(on[q]);
+        for (int q = 0; q < NW; q++) n_on += (uint32_t)__popc(onany[q]);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(n_on > 1u) != 0ull, 0)) {
+            // two agents work on job cells in one env of this wave -- possibly the same job: every job in turn order (base.py:377-382)
+#pragma unroll
+            for (int j = 0; j < J; j++) {
                 uint32_t dj = (w.jd[j / 4] >> (8 * (j & 3))) & 1u;
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt > 1u) != 0ull, 0)) {
-                    // several agents work on this job in one step: in turn order (base.py:377-382)
-                    for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
-                        const uint32_t tb = (turn | 0x80u) * k01;
-#pragma unroll
-                        for (int q = 0; q < NW; q++) {
-                            const uint32_t me = zero80(R[q] ^ tb) & on[q]; // the actor whose turn it is, if it works on this job
-                            const bool is_sab = (me & w.im80[q]) != 0u, is_fix = (me & ~w.im80[q]) != 0u;
-                            const bool f = is_fix && dj == 0u, sb = is_sab && dj != 0u;
-                            dj = f ? 1u : (sb ? 0u : dj);
-                            e.m_fix += f ? 1u : 0u;
-                            e.m_sab += sb ? 1u : 0u;
-                            fc80[q] |= f ? me : 0u;
-                            sc80[q] |= sb ? me : 0u;
-                        }
-                    }
-                } else {
-                    uint32_t imp_on = 0;
-#pragma unroll
-                    for (int q = 0; q < NW; q++) imp_on |= on[q] & w.im80[q];
-                    const bool f = any != 0u && imp_on == 0u && dj == 0u, sb = imp_on != 0u && dj != 0u;
-                    dj = f ? 1u : (sb ? 0u : dj);
-                    e.m_fix += f ? 1u : 0u;
-                    e.m_sab += sb ? 1u : 0u;
+                for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
+                    const uint32_t tb = (turn | 0x80u) * k01;
 #pragma unroll
                     for (int q = 0; q < NW; q++) {
-                        fc80[q] |= f ? on[q] : 0u;
-                        sc80[q] |= sb ? on[q] : 0u;
+                        const uint32_t me = zero80(R[q] ^ tb) & on[j][q]; // the actor whose turn it is, if it works on this job
+                        const bool is_sab = (me & w.im80[q]) != 0u, is_fix = (me & ~w.im80[q]) != 0u;
+                        const bool f = is_fix && dj == 0u, sb = is_sab && dj != 0u;
+                        dj = f ? 1u : (sb ? 0u : dj);
+                        e.m_fix += f ? 1u : 0u;
+                        e.m_sab += sb ? 1u : 0u;
+                        fc80[q] |= f ? me : 0u;
+                        sc80[q] |= sb ? me : 0u;
                     }
                 }
                 w.jd[j / 4] = (w.jd[j / 4] & ~(1u << (8 * (j & 3)))) | (dj << (8 * (j & 3)));
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < JW; q++) w.jd[q] ^= tog[q];
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                fc80[q] = acted[q] & ~w.im80[q];
+                sc80[q] = acted[q] & w.im80[q];
+                e.m_fix += (uint32_t)__popc(fc80[q]);
+                e.m_sab += (uint32_t)__popc(sc80[q]);
+            }
         }
     }
-
 
     // ---- tag actions (tagging.py:103-110) and the vote (tagging.py:180-207) ------------------------------------------------------
     float team = 0.0f; // team reward: vote outcome, then the win reward (tagging.py:196, 209-213)
@@ -505,18 +606,19 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         // the compiled-in kernels are only selected when every constant is a small integer
         const float end = c.fr[RW_END];
         team += wsel == 16u ? end : (wsel == 32u ? -1.0f * end : 0.0f);
-        const float r_tsr = 1.0f * c.fr[RW_TSR], r_kill = c.fr[RW_KILL], r_fix = c.fr[RW_FIX], r_sab = -1.0f * c.fr[RW_SAB], r_dead = c.fr[RW_DEAD];
+        // the assignment a step left on an agent (none = time_step_reward, kill, fix, -sabotage): a 4-entry table the host put at
+        // the head of the LDS reward table for this variant
+        const uint32_t dead_bits = __float_as_uint(c.fr[RW_DEAD]);
+        uint32_t code4[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) code4[q] = (kc80[q] >> 5) | (fc80[q] >> 4) | (sc80[q] >> 5) | (sc80[q] >> 4); // RC_KILL 1, RC_FIX 2, RC_SAB 3, times 4
 #pragma unroll
         for (int i = 0; i < A; i++) {
-            const int q = i / 4;
-            const uint32_t m = 0x80u << (8 * (i & 3));
-            float r = r_tsr;
-            r = (kc80[q] & m) ? r_kill : r;
-            r = (fc80[q] & m) ? r_fix : r;
-            r = (sc80[q] & m) ? r_sab : r;
-            r += team;
-            if (i < NI) r *= -1.0f;
-            rr[i] = (w.al[q] & (m >> 7)) ? r : r_dead;
+            const int q = i / 4, sh = 8 * (i & 3);
+            float r = lds_reward_lookup((code4[q] >> sh) & 0xffu) + team;
+            if (i < NI) r = -r; // indices [:n_imposters], NOT the imposter mask (base.py:559); x * -1 == -x, zeros included
+            const uint32_t live = 0u - ((w.al[q] >> sh) & 1u);
+            rr[i] = __uint_as_float((__float_as_uint(r) & live) | (dead_bits & ~live)); // base.py:562
         }
     }
     // base.py:392-395: t saturates at max_time_steps - 1
