@@ -10,6 +10,7 @@
 #include "susnet_device.h"
 #include "susnet_obs.h"
 #include "susnet_swar.h"
+#include "susnet_swar2.h"
 #include "susnet_duel.h"
 
 namespace susnet {
@@ -662,6 +663,155 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     }
 }
 
+// Fused random rollout with TWO lanes per environment (susnet_swar2.h): 8-agent configurations at 32 envs per wave.  Same contract
+// as k_rollout_swar for the modes OUT_NONE / OUT_TRAJ / OUT_TRAJ_RAW8 / OUT_RECORD on the production stream.
+template <class S, int OUT>
+__global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, RolloutArgs a, ObsArgs o) {
+    using W = Swar2<S>;
+    using RNG = PhiloxRng;
+    constexpr int A = W::A;
+    static_assert(A == 8, "two words of four agents");
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x;
+    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3; // XCD-aware mapping (see k_rollout)
+    const uint32_t per = nblk >> 3, rem = nblk & 7u;
+    const uint32_t wave_id = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    const uint32_t h = (uint32_t)tid >> 5;
+    const int64_t b0 = (int64_t)wave_id * 32, b = b0 + (tid & 31);
+    const bool active = b < c.B;
+    typename StoreFor<S>::type st;
+    Tables T = setup_lds<S>(c, smem, tid, st);
+    if (RankLut<S>::kOk) build_rank_lut<S>(smem, tid);
+    wave_lds_fence();
+    Env e = {};
+    RNG rng = make_rng<RNG>(c, s, active ? b : 0);
+    PairActionStream as;
+    as.init();
+    as.h_ = h;
+    if (!active) return; // both lanes of a pair leave together: every exchange below is between two active lanes
+    load_env<S>(c, s, st, b, e);
+    W w;
+    to_swar2<S>(c, st, e, h, w);
+    uint64_t tick_base = a.tick_base;
+    if (c.dev_tick) tick_base = uniform64(s.tickw[b]);
+    LifeAcc life;
+    life.clear();
+    const int64_t AB = (int64_t)A * c.B;
+    constexpr int kRawF = S::kRawF;
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ, kRec = OUT == OUT_RECORD;
+    const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+    // every lane writes its own four agents' actions / rewards / cells / alive flags; what the environment has once (done,
+    // truncated, job cells and status, the replay feed) is written by the lane of the low word
+    BufDst da = make_buf_dst(a.actions, nt * (uint64_t)AB, (uint32_t)(b * A) + 4u * h);
+    BufDst dr = make_buf_dst(a.rewards, nt * (uint64_t)AB * 4u, ((uint32_t)(b * A) + 4u * h) * 4u);
+    BufDst dd = make_buf_dst(a.done, nt * (uint64_t)c.B, (uint32_t)b);
+    BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)b);
+    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(b * kRawF));
+    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(b * a.record_bytes));
+    const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
+    if (a.n_ticks > 0) clear_info_if_fresh(e);
+    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
+        constexpr int POS = decltype(par)::value;
+        if (kTraj) {
+            const uint32_t t32 = (uint32_t)tick;
+            da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
+        }
+        if (kRec) drec.so = (uint32_t)tick * slab_rec;
+        uint32_t act2[2], R2[2];
+        sample_actions_swar<S, POS>(c, w, rng, as, tick_base + (uint64_t)tick, act2);
+        static_assert(RankLut<S>::kOk || S::kOrd == 0, "a shuffled order comes from the rank tables here");
+        if constexpr (RankLut<S>::kOk) ranks_from_lut<S, POS>(rng, as, tick_base + (uint64_t)tick, R2);
+        else identity_ranks<S>(R2);
+        const uint32_t act = h ? act2[1] : act2[0], R = h ? R2[1] : R2[0];
+        float rr[4];
+        bool done, trunc;
+        step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc);
+        if (kTraj) {
+            da.st32(0u, act);
+            store_row_f32<4>(dr, rr);
+            if (h == 0u) {
+                dd.st8(0u, done ? 1u : 0u);
+                dt.st8(0u, trunc ? 1u : 0u);
+            }
+        }
+        if (kRec) { // rewards f32[8] | actions u8[8] | ...: my four of each
+            drec.st128(16u * h, __float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3]));
+            drec.st32(4u * A + 4u * h, act);
+        }
+        if (a.roles != nullptr && h == 0u) a.roles[(int64_t)tick * c.B + b] = (uint16_t)w.imp_bits;
+        if (__builtin_expect(done || trunc, 0)) { // (both lanes of the pair: done / truncated are the environment's)
+            life.add_episode(e, trunc);
+            if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                Swar<S> f;
+                gather_swar2<S>(w, f);
+                uint32_t trow[(kRawF + 3) / 4];
+                raw_row_swar<S>(f, trow);
+                if (h == 0u) store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+            }
+            reset_env<S>(c, T, st, tid, e, rng);
+            to_swar2<S>(c, st, e, h, w);
+            if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+            else zero_metrics(e);
+        }
+        if (OUT == OUT_TRAJ_RAW8) { // flatten_state (base.py:234-235): cells [0, 16) | alive [16, 24) | job cells [24, 32) | job status [32, 36)
+            const uint32_t x = w.xy & 0x0f0f0f0fu, y = (w.xy >> 4) & 0x0f0f0f0fu;
+            dobs.st64(8u * h, __builtin_amdgcn_perm(y, x, 0x05010400u), __builtin_amdgcn_perm(y, x, 0x07030602u));
+            dobs.st32(16u + 4u * h, w.al & k01);
+            if (h == 0u) {
+                dobs.st64(24u, w.jobs_obs[0], w.jobs_obs[1]);
+                dobs.st32(32u, w.jd);
+            }
+        }
+        if (kRec) { // done | truncated | the raw row, bytes [5A, 5A + 2 + F): assembled from the pair, written by the low lane
+            Swar<S> f;
+            gather_swar2<S>(w, f);
+            uint32_t row[(kRawF + 3) / 4];
+            raw_row_swar<S>(f, row);
+            constexpr int kNB = 2 + kRawF, kND = (kNB + 3) / 4;
+            uint8_t by[kND * 4];
+            by[0] = done ? 1 : 0;
+            by[1] = trunc ? 1 : 0;
+#pragma unroll
+            for (int f8 = 0; f8 < kRawF; f8++) by[2 + f8] = (uint8_t)(row[f8 / 4] >> (8 * (f8 & 3)));
+#pragma unroll
+            for (int q = kNB; q < kND * 4; q++) by[q] = 0;
+            uint32_t rec[kND];
+#pragma unroll
+            for (int q = 0; q < kND; q++)
+                rec[q] = (uint32_t)by[4 * q] | ((uint32_t)by[4 * q + 1] << 8) | ((uint32_t)by[4 * q + 2] << 16) | ((uint32_t)by[4 * q + 3] << 24);
+            static_assert(kND == 10, "tail of the 80-byte record: 8 + 16 + 16 bytes, each store naturally aligned");
+            if (h == 0u) {
+                drec.st64(5u * A, rec[0], rec[1]);
+                drec.st128(5u * A + 8u, rec[2], rec[3], rec[4], rec[5]);
+                drec.st128(5u * A + 24u, rec[6], rec[7], rec[8], rec[9]);
+            }
+        }
+    };
+    constexpr int kGroup = 8; // groups of 8 ticks start on a boundary of Philox block PAIRS of the action stream (W words per tick)
+    int tick = 0;
+    while (tick < a.n_ticks) {
+        if (tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) & 7ull) == 0ull) {
+            static_for<0, kGroup>([&](auto pos) __attribute__((always_inline)) { tick_body(tick + decltype(pos)::value, pos); });
+            tick += kGroup;
+        } else {
+            tick_body(tick, std::integral_constant<int, -1>{});
+            tick++;
+        }
+    }
+    {
+        Swar<S> f;
+        gather_swar2<S>(w, f);
+        from_swar<S>(c, f, st, e);
+    }
+    if (h == 0u) {
+        store_env<S>(c, s, st, b, e, true);
+        finish_rng(s, b, rng);
+        life.flush(c, s, b);
+        if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+    }
+}
+
 // Fused random rollout of the 1v1 no-walls game (susnet_duel.h): the headline kernel.  Same contract as k_rollout for the
 // modes OUT_NONE / OUT_TRAJ / OUT_TRAJ_RAW8; RNG = the production stream or caller-supplied words (numpy parity).
 template <class RNG, int OUT>
@@ -812,6 +962,15 @@ void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t
             else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_NONE>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
             else hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+            return;
+        }
+    }
+    if constexpr (UseSplit<SPEC>::value) {
+        if (!tape && c.epw == 32 && out != OUT_ANY) { // half-filled waves: two lanes per environment (susnet_swar2.h)
+            if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+            else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+            else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
+            else hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
             return;
         }
     }

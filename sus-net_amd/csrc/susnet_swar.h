@@ -147,8 +147,8 @@ __device__ __forceinline__ uint32_t swar_imp_bits(const Swar<S> &w) {
 }
 
 // base.py:326-330 on the production stream (see sample_actions_env): the action bytes, packed like every per-agent value
-template <class S, int POS = -1>
-__device__ __forceinline__ void sample_actions_swar(const Consts &c, const Swar<S> &w, PhiloxRng &rng, ActionStream &as, uint64_t tick,
+template <class S, int POS = -1, class WT = Swar<S>, class AS = ActionStream>
+__device__ __forceinline__ void sample_actions_swar(const Consts &c, const WT &w, PhiloxRng &rng, AS &as, uint64_t tick,
                                                     uint32_t (&act)[Swar<S>::NW]) {
     using W = Swar<S>;
     const uint64_t Wt = (uint64_t)S::kAw.W;
@@ -251,8 +251,8 @@ __device__ __forceinline__ void build_rank_lut(uint32_t *smem, int tid) {
     }
 }
 
-template <class S, int POS, int NW>
-__device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, ActionStream &as, uint64_t tick, uint32_t (&R)[NW]) {
+template <class S, int POS, int NW, class AS = ActionStream>
+__device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, AS &as, uint64_t tick, uint32_t (&R)[NW]) {
     using L = RankLut<S>;
     constexpr int A = L::A;
     const uint64_t W = (uint64_t)S::kAw.W;

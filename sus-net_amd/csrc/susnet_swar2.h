@@ -1,0 +1,289 @@
+// susnet_swar2.h -- the byte-parallel step (susnet_swar.h) with TWO lanes per environment, for 8-agent games at batches that fill
+// only half of every wave (32 768 envs per GPU = the 8-GPU shard of BASELINE configs[3]: 1 024 waves of 32 envs, one per SIMD).
+//
+// Lane L (0..31) holds agents 0..3 of env L, lane L + 32 agents 4..7: every per-agent quantity is ONE packed word per lane
+// instead of two, so the per-word part of the step costs half the instructions per wave.  What concerns the whole environment
+// (step counters, job status, the random streams, win / truncation) is kept identically in both lanes; the few places where the
+// two words meet -- the killer's cell and rank, kill candidates, job toggles, alive counts -- go through v_permlane32_swap_b32,
+// which hands both lanes the pair (word of lanes 0..31, word of lanes 32..63) in one instruction.
+//
+// Reference behaviour: as susnet_swar.h (base.py:332-563, pred_prey.py:78-99).
+#pragma once
+
+#include "susnet_swar.h"
+
+namespace susnet {
+
+template <class S>
+struct UseSplit {
+    static constexpr bool value = UseSwar<S>::value && S::kA == 8 && S::kVar != SUSNET_VARIANT_TAGGING && S::kJ <= 4;
+};
+
+struct Pair {
+    uint32_t lo, hi; // the value lanes 0..31 hold / the value lanes 32..63 hold (of the same environment), in both lanes
+};
+__device__ __forceinline__ Pair both_halves(uint32_t v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); // vdst[32..63] <-> src[0..31]
+    return Pair{r[0], r[1]};
+}
+
+// The action stream for a lane PAIR: inside a group of ticks whose words start on an 8-word boundary of the stream, the low
+// lane generates Philox block 2n and the high lane block 2n + 1 in the same instructions, and one exchange per word gives
+// both lanes all eight words -- half the Philox work per environment.  Outside such groups (ragged launch ends) every lane
+// generates whole blocks itself, like ActionStream.
+struct PairActionStream {
+    ActionStream solo;   // ungrouped ticks
+    uint32_t wl[4], wh[4]; // words of the even / odd block of the pair held
+    uint32_t rem;
+    __device__ __forceinline__ void init() { solo.init(); rem = 0; wl[0] = wl[1] = wl[2] = wl[3] = wh[0] = wh[1] = wh[2] = wh[3] = 0; }
+    __device__ __forceinline__ void gen_pair(const PhiloxRng &r, uint64_t pair, uint32_t h) {
+        ActionStream mine;
+        mine.init();
+        mine.gen(r, 2ull * pair + (uint64_t)h);
+        const Pair p0 = both_halves(mine.w0), p1 = both_halves(mine.w1), p2 = both_halves(mine.w2), p3 = both_halves(mine.w3);
+        wl[0] = p0.lo; wl[1] = p1.lo; wl[2] = p2.lo; wl[3] = p3.lo;
+        wh[0] = p0.hi; wh[1] = p1.hi; wh[2] = p2.hi; wh[3] = p3.hi;
+    }
+    uint32_t h_;
+    // word number `g` (compile-time) of the group that starts at stream index `base` (a multiple of 8)
+    __device__ __forceinline__ uint32_t word_in_group(const PhiloxRng &r, uint64_t base, int g) {
+        if ((g & 7) == 0) gen_pair(r, (base >> 3) + (uint64_t)(g >> 3), h_);
+        return ((g >> 2) & 1) ? wh[g & 3] : wl[g & 3];
+    }
+    __device__ __forceinline__ uint32_t word(const PhiloxRng &r, uint64_t index) { return solo.word(r, index); }
+};
+
+template <class S>
+struct Swar2 {
+    static constexpr int A = S::kA, J = S::kJ, NI = S::kNI > 0 ? S::kNI : 1;
+    static constexpr bool kBase = S::kVar != SUSNET_VARIANT_ITG;
+    uint32_t h;                 // 0: this lane holds agents 0..3, 1: agents 4..7
+    uint32_t xy, al, im80;      // my word of cells / alive (0x01) / imposter flags (0x80)
+    uint32_t isel[NI];          // v_perm selector of imposter s's byte over the PAIR {hi word, lo word}
+    uint32_t ihot[NI];          // 0x80 at imposter s's byte if it is in my word
+    uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes
+    uint32_t jobs_obs[2], jd;   // observation bytes of the job cells; completed: 0x01 per job
+    uint32_t nact[A];           // len(agent_action_map[i]), all agents (the action draws are made for the whole env in both lanes)
+    uint32_t imp_bits;          // imposter bitmask of the episode
+};
+
+template <class S, class Store>
+__device__ __forceinline__ void to_swar2(const Consts &c, const Store &st, const Env &e, uint32_t h, Swar2<S> &w) {
+    Swar<S> f;
+    to_swar<S>(c, st, e, f);
+    w.h = h;
+    w.xy = h ? f.xy[1] : f.xy[0];
+    w.al = h ? f.al[1] : f.al[0];
+    w.im80 = h ? f.im80[1] : f.im80[0];
+#pragma unroll
+    for (int s = 0; s < Swar2<S>::NI; s++) {
+        w.isel[s] = f.isel[s];
+        w.ihot[s] = h ? f.ihot[s][1] : f.ihot[s][0];
+    }
+#pragma unroll
+    for (int j = 0; j < Swar2<S>::J; j++) w.jb[j] = f.jb[j];
+    w.jobs_obs[0] = f.jobs_obs[0];
+    w.jobs_obs[1] = f.jobs_obs[1];
+    w.jd = f.jd[0];
+#pragma unroll
+    for (int i = 0; i < Swar2<S>::A; i++) w.nact[i] = f.nact[i];
+    w.imp_bits = swar_imp_bits(f);
+}
+
+// the whole environment again (both lanes of the pair must be active)
+template <class S>
+__device__ __forceinline__ void gather_swar2(const Swar2<S> &w, Swar<S> &f) {
+    const Pair x = both_halves(w.xy), a = both_halves(w.al), m = both_halves(w.im80);
+    f.xy[0] = x.lo; f.xy[1] = x.hi;
+    f.al[0] = a.lo; f.al[1] = a.hi;
+    f.im80[0] = m.lo; f.im80[1] = m.hi;
+    f.jobs_obs[0] = w.jobs_obs[0];
+    f.jobs_obs[1] = w.jobs_obs[1];
+    f.jd[0] = w.jd;
+}
+
+// One step; act / R: MY word of the action bytes and of the turn ranks.  rr: the rewards of my four agents.
+template <class S, class RNG>
+__device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e, RNG &rng, uint32_t act, uint32_t R, float (&rr)[4], bool &done,
+                                           bool &trunc) {
+    using W = Swar2<S>;
+    constexpr int A = W::A, J = W::J, NI = W::NI;
+    const uint32_t h = w.h;
+    e.m_steps += 1; // base.py:366
+    rng.align();
+
+    // ---- action classes (0x80 per agent): alive agents only (base.py:477) --------------------------------------------------
+    const uint32_t g5 = (act + 0x7b7b7b7bu) & k80, g6 = (act + 0x7a7a7a7au) & k80; // action index >= 5 / >= 6
+    const uint32_t al80 = (w.al << 7) & k80;
+    uint32_t kill80, fix80 = 0, sab80 = 0, rows;
+    if (W::kBase) { // crew: 5 = FIX; imposter: 5 = SABOTAGE, 6 = KILL (base.py:82-99)
+        kill80 = g6 & al80;
+        const uint32_t j5 = g5 & ~g6 & al80;
+        sab80 = j5 & w.im80;
+        fix80 = j5 & ~w.im80;
+        rows = act - (g6 >> 7);
+    } else { // pred_prey.py:4-19: imposter 5 = KILL, no job actions
+        kill80 = g5 & al80;
+        rows = act;
+    }
+    const uint32_t mv80 = ~g5 & al80;
+    // ---- destinations: one lookup per agent in the (action, cell) table (move() + _is_valid_position(), base.py:69-79, 548-551)
+    uint32_t dest;
+    {
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)i) << 8) | (uint32_t)i; // address = row << 8 | cell
+            d[i] = lds_move_lookup(__builtin_amdgcn_perm(rows, w.xy, sel));
+        }
+        dest = d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24);
+    }
+    const uint32_t newt = sel_bytes(ff_from80(mv80), dest, w.xy); // positions if every living mover moved
+
+    // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
+    uint32_t kc80 = 0, pend80 = 0;
+    {
+        const Pair pk = both_halves(kill80), pr = both_halves(R), px = both_halves(w.xy);
+        uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot: kill flag (0x80 / 0), rank | 0x80, cell
+#pragma unroll
+        for (int s = 0; s < NI; s++) {
+            kb[s] = __builtin_amdgcn_perm(pk.hi, pk.lo, w.isel[s]);
+            rb[s] = __builtin_amdgcn_perm(pr.hi, pr.lo, w.isel[s]);
+            cb[s] = __builtin_amdgcn_perm(px.hi, px.lo, w.isel[s]);
+        }
+        bool second_first = false; // two imposters: the one with the earlier turn kills first
+        if (NI == 2) second_first = kb[1] != 0u && (kb[0] == 0u || rb[1] < rb[0]);
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+            const int s0 = it, s1 = NI - 1 - it;
+            const uint32_t kbi = second_first ? kb[s1] : kb[s0], rbi = second_first ? rb[s1] : rb[s0], cbi = second_first ? cb[s1] : cb[s0];
+            const bool attempt = kbi != 0u;
+            if (__builtin_amdgcn_ballot_w64(attempt) != 0ull) {
+                const uint32_t tb = bcast_byte0(rbi & 0x7fu), cbb = bcast_byte0(cbi);
+                const uint32_t ge80 = (R - tb) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
+                const uint32_t pos = sel_bytes(ff_from80(ge80), w.xy, newt);
+                const uint32_t crew80 = (w.al << 7) & ~w.im80 & k80; // living crew NOW (base.py:535-542)
+                const uint32_t cand = attempt ? (zero80(pos ^ cbb) & crew80) : 0u;
+                const Pair pc = both_halves(cand);
+                const uint32_t nc = (uint32_t)__popc(pc.lo) + (uint32_t)__popc(pc.hi);
+                // base.py:497: uniform among the candidates (ascending agent index); with one candidate the lowest set flag
+                uint32_t v0 = pc.lo & (0u - pc.lo), v1 = pc.lo != 0u ? 0u : (pc.hi & (0u - pc.hi));
+                const uint64_t word_pos = rng.cur; // production protocol: one word per landed kill
+                if (!RNG::kNumpy) rng.cur += nc != 0u ? 1ull : 0ull;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(nc > 1u) != 0ull, 0)) {
+                    if (nc > 1u) {
+                        if (!RNG::kNumpy) rng.cur = word_pos;
+                        const uint32_t r = rng.bounded(nc);
+                        uint32_t c0 = pc.lo, c1 = pc.hi;
+                        for (uint32_t k = 0; k < r; k++) {
+                            const bool lo = c0 != 0u;
+                            c0 = lo ? (c0 & (c0 - 1u)) : c0;
+                            c1 = lo ? c1 : (c1 & (c1 - 1u));
+                        }
+                        v0 = c0 & (0u - c0);
+                        v1 = c0 != 0u ? 0u : (c1 & (0u - c1));
+                    }
+                }
+                const uint32_t v80 = h ? v1 : v0;
+                const bool hit = nc != 0u;
+                e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
+                w.al &= ~(v80 >> 7);     // base.py:511
+                const uint32_t hot = second_first ? w.ihot[s1] : w.ihot[s0];
+                kc80 |= hit ? hot : 0u;  // base.py:514-515 (the victim's slot ends as dead_penalty)
+                pend80 |= v80 & ge80;    // killed before its own turn: it never acts
+            }
+        }
+    }
+    w.xy = sel_bytes(ff_from80(pend80), w.xy, newt); // a victim that had not acted yet stays where it was
+
+    // ---- FIX (base.py:518-524) / SABOTAGE (527-533), in agent space (see susnet_swar.h) ----------------------------------------
+    uint32_t fc80 = 0, sc80 = 0;
+    if (W::kBase && J > 0) {
+        const uint32_t ja80 = (fix80 | sab80) & ~pend80;
+        uint32_t on[J], onany = 0, acted = 0, tog = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint32_t dj80 = (0u - ((w.jd >> (8 * j)) & 1u)) & k80;
+            on[j] = zero80(w.xy ^ w.jb[j]) & ja80;
+            onany |= on[j];
+            const uint32_t succ = on[j] & ~(w.im80 ^ dj80);
+            acted |= succ;
+            tog |= (uint32_t)__popc(succ) << (8 * j);
+        }
+        // the pair's toggles and actor count in one exchange: toggles are 0x01 bytes, the count goes to the top byte
+        // (J <= 3 leaves it free; with J == 4 the count is exchanged on its own)
+        const Pair pt = both_halves(tog), pn = both_halves(onany);
+        const uint32_t tog_env = pt.lo | pt.hi;
+        const uint32_t n_on = (uint32_t)__popc(pn.lo) + (uint32_t)__popc(pn.hi);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(n_on > 1u) != 0ull, 0)) {
+            // two agents on job cells in one env of this wave: every job in turn order over BOTH words (base.py:377-382)
+            const Pair pr = both_halves(R), pm = both_halves(w.im80);
+            const uint32_t R2[2] = {pr.lo, pr.hi}, im2[2] = {pm.lo, pm.hi};
+            uint32_t f2[2] = {0, 0}, s2[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const Pair po = both_halves(on[j]);
+                const uint32_t on2[2] = {po.lo, po.hi};
+                uint32_t dj = (w.jd >> (8 * j)) & 1u;
+                for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
+                    const uint32_t tb = (turn | 0x80u) * k01;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const uint32_t me = zero80(R2[q] ^ tb) & on2[q];
+                        const bool is_sab = (me & im2[q]) != 0u, is_fix = (me & ~im2[q]) != 0u;
+                        const bool f = is_fix && dj == 0u, sb = is_sab && dj != 0u;
+                        dj = f ? 1u : (sb ? 0u : dj);
+                        e.m_fix += f ? 1u : 0u;
+                        e.m_sab += sb ? 1u : 0u;
+                        f2[q] |= f ? me : 0u;
+                        s2[q] |= sb ? me : 0u;
+                    }
+                }
+                w.jd = (w.jd & ~(1u << (8 * j))) | (dj << (8 * j));
+            }
+            fc80 = h ? f2[1] : f2[0];
+            sc80 = h ? s2[1] : s2[0];
+        } else {
+            e.m_fix += (uint32_t)__popc(tog_env & ~w.jd);
+            e.m_sab += (uint32_t)__popc(tog_env & w.jd);
+            w.jd ^= tog_env;
+            fc80 = acted & ~w.im80;
+            sc80 = acted & w.im80;
+        }
+    }
+
+    // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
+    uint32_t wsel;
+    {
+        const uint32_t mine = (uint32_t)__popc(w.al & k01) | ((uint32_t)__popc((w.al << 7) & w.im80 & k80) << 8);
+        const Pair pa = both_halves(mine);
+        const uint32_t sum = pa.lo + pa.hi;
+        const int alive_all = (int)(sum & 0xffu), alive_imp = (int)(sum >> 8);
+        const int done_jobs = __popc(w.jd);
+        bool crew_won, imp_won;
+        if (!W::kBase) {
+            crew_won = J != 0 && done_jobs == J;
+            imp_won = !crew_won && alive_all - alive_imp == 0;
+        } else {
+            crew_won = alive_imp == 0 || done_jobs == J;
+            imp_won = !crew_won && alive_all - alive_imp <= alive_imp;
+        }
+        done = crew_won || imp_won;
+        e.flags |= (crew_won ? FLAG_CREW_WON : 0u) | (imp_won ? FLAG_IMP_WON : 0u);
+        wsel = crew_won ? 16u : (imp_won ? 32u : 0u);
+    }
+    // ---- rewards: one lookup per agent in the host-evaluated table [win][index < n_imposters][dead][assignment code] -------------
+    {
+        const uint32_t code4 = (kc80 >> 5) | (fc80 >> 4) | (sc80 >> 5) | (sc80 >> 4); // RC_KILL 1, RC_FIX 2, RC_SAB 3, times 4
+        const uint32_t dead16 = ((w.al & k01) ^ k01) << 4;
+        constexpr uint32_t neg32 = (NI >= 1 ? 0x20u : 0u) | (NI >= 2 ? 0x2000u : 0u); // indices [:n_imposters]: all in the low word
+        const uint32_t idx4 = code4 + dead16 + (h ? 0u : neg32) + (wsel << 2) * k01;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rr[i] = lds_reward_lookup((idx4 >> (8 * i)) & 0xffu);
+    }
+    trunc = false; // base.py:392-395: t saturates at max_time_steps - 1
+    if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;
+    else e.t += 1u;
+}
+
+} // namespace susnet

@@ -650,6 +650,57 @@ def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B):
     compare_full_state(env, ob, f"{name} after rollout")
 
 
+def test_two_lanes_per_env_rollout_equals_the_one_lane_kernel(pkg, oracle_mod, monkeypatch):
+    """8-agent configurations at 32 environments per wave run with TWO lanes per environment (susnet_swar2.h).  Forced at a
+    small batch here (SUSNET_EPW) and compared, output by output, with the one-lane kernel (itself pinned to the oracle
+    above) over long launches with many episode ends: separate tensors + replay feed, packed records, no outputs; the first
+    120 ticks also against the oracle."""
+    name, B, seed = "base_2v6_j4_14", 1000, 77
+    obs_cfg = pkg.ObsConfig("raw", dtype=torch.uint8)
+    envs = {}
+    for epw in (16, 32):
+        monkeypatch.setenv("SUSNET_EPW", str(epw))
+        envs[epw], ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+        envs[epw].reset()
+    ob.reset()
+    outs = {}
+    for epw, env in envs.items():
+        got = {}
+        bufs = env.alloc_rollout(400, obs=obs_cfg, replay_feed=True)
+        bufs["term_obs"].zero_()  # (written only where an episode ended)
+        env.rollout_into(400, bufs)
+        got["feed"] = {k: np_(bufs[k]).copy() for k in ("actions", "rewards", "done", "truncated", "obs", "term_obs", "roles")}
+        env.rollout(37, store=(), obs=None)  # state-only fast-forward, odd length
+        tr = env.rollout(203, obs=obs_cfg, packed=True)
+        got["record"] = np_(tr["record"]).copy()
+        tr = env.rollout(50, obs=None)
+        got["traj"] = {k: np_(tr[k]).copy() for k in ("actions", "rewards", "done", "truncated")}
+        torch.cuda.synchronize()
+        env._export(full=True)
+        got["state"] = {k: np_(getattr(env, k)).copy() for k in ("agent_positions", "alive_agents", "imposter_mask", "job_positions", "completed_jobs", "t")}
+        got["metrics"], got["cursor"] = np_(env._metrics).copy(), np_(env.rng_cursor()).copy()
+        got["lifetime"] = np_(env.lifetime_totals()).copy()
+        outs[epw] = got
+    a, b = outs[16], outs[32]
+    assert a["feed"]["done"].sum() > 50, "the launches must cross many episode ends"
+    for grp in ("feed", "traj", "state"):
+        for k in a[grp]:
+            np.testing.assert_array_equal(a[grp][k], b[grp][k], err_msg=f"{grp}/{k}")
+    for k in ("record", "metrics", "cursor", "lifetime"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    f = b["feed"]
+    for s in range(120):
+        oa = ob.sample_actions()
+        np.testing.assert_array_equal(f["actions"][s], oa, err_msg=f"actions tick {s}")
+        orew, odone, otrunc, _ = ob.step(oa)
+        assert np.array_equal(f["rewards"][s].astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"rewards tick {s}"
+        np.testing.assert_array_equal(f["done"][s], odone.astype(bool))
+        ended = (odone | otrunc).astype(bool)
+        np.testing.assert_array_equal(f["term_obs"][s][ended], ob.obs_raw_u8()[ended], err_msg=f"terminal rows tick {s}")
+        ob.reset(mask=ended)
+        np.testing.assert_array_equal(f["obs"][s], ob.obs_raw_u8(), err_msg=f"raw obs tick {s}")
+
+
 # ------------------------------------------------------------------------------------------------
 # observations
 # ------------------------------------------------------------------------------------------------
