@@ -763,29 +763,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
                 dobs.st32(32u, w.jd);
             }
         }
-        if (kRec) { // done | truncated | the raw row, bytes [5A, 5A + 2 + F): assembled from the pair, written by the low lane
-            Swar<S> f;
-            gather_swar2<S>(w, f);
-            uint32_t row[(kRawF + 3) / 4];
-            raw_row_swar<S>(f, row);
-            constexpr int kNB = 2 + kRawF, kND = (kNB + 3) / 4;
-            uint8_t by[kND * 4];
-            by[0] = done ? 1 : 0;
-            by[1] = trunc ? 1 : 0;
-#pragma unroll
-            for (int f8 = 0; f8 < kRawF; f8++) by[2 + f8] = (uint8_t)(row[f8 / 4] >> (8 * (f8 & 3)));
-#pragma unroll
-            for (int q = kNB; q < kND * 4; q++) by[q] = 0;
-            uint32_t rec[kND];
-#pragma unroll
-            for (int q = 0; q < kND; q++)
-                rec[q] = (uint32_t)by[4 * q] | ((uint32_t)by[4 * q + 1] << 8) | ((uint32_t)by[4 * q + 2] << 16) | ((uint32_t)by[4 * q + 3] << 24);
-            static_assert(kND == 10, "tail of the 80-byte record: 8 + 16 + 16 bytes, each store naturally aligned");
-            if (h == 0u) {
-                drec.st64(5u * A, rec[0], rec[1]);
-                drec.st128(5u * A + 8u, rec[2], rec[3], rec[4], rec[5]);
-                drec.st128(5u * A + 24u, rec[6], rec[7], rec[8], rec[9]);
-            }
+        if (kRec) { // the raw row at [5A, 5A + F) -- every lane its own dwords of it -- then done | truncated | 0-padding (low lane)
+            static_assert(kRawF == 36 && A == 8, "cells [0, 16) | alive [16, 24) | job cells [24, 32) | job status [32, 36)");
+            const uint32_t x = w.xy & 0x0f0f0f0fu, y = (w.xy >> 4) & 0x0f0f0f0fu;
+            drec.st64(5u * A + 8u * h, __builtin_amdgcn_perm(y, x, 0x05010400u), __builtin_amdgcn_perm(y, x, 0x07030602u));
+            drec.st32(5u * A + 16u + 4u * h, w.al & k01);
+            if (h == 0u)
+                drec.st128(5u * A + 24u, w.jobs_obs[0], w.jobs_obs[1], w.jd, (done ? 1u : 0u) | (trunc ? 0x100u : 0u));
         }
     };
     constexpr int kGroup = 8; // groups of 8 ticks start on a boundary of Philox block PAIRS of the action stream (W words per tick)

@@ -575,7 +575,7 @@ def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch
     if env.record_layout() is None:
         pytest.skip("configuration not compiled in")
     lay = env.record_layout()
-    assert lay.record_bytes % 4 == 0 and lay.off_obs + env.flattened_state_size <= lay.record_bytes
+    assert lay.record_bytes % 4 == 0 and max(lay.off_obs + env.flattened_state_size, lay.off_truncated + 1) <= lay.record_bytes
     env.reset()
     ob.reset(threads=0)
     obs_cfg = pkg.ObsConfig("raw", dtype=torch.uint8)
@@ -596,8 +596,12 @@ def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch
             np.testing.assert_array_equal(np_(traj["truncated"])[s], otrunc.astype(bool))
             ob.reset(mask=(odone | otrunc).astype(bool))
             np.testing.assert_array_equal(np_(traj["obs"])[s], ob.obs_raw_u8())
-        pad = np_(traj["record"])[:, :, lay.off_obs + env.flattened_state_size:]
-        assert not pad.any(), "padding bytes are zero"
+        used = np.zeros(lay.record_bytes, dtype=bool)  # (the field order is the layout's business: read it through the offsets)
+        for off, n in ((lay.off_rewards, 4 * env.n_agents), (lay.off_actions, env.n_agents), (lay.off_done, 1), (lay.off_truncated, 1),
+                       (lay.off_obs, env.flattened_state_size)):
+            assert not used[off:off + n].any(), "record fields overlap"
+            used[off:off + n] = True
+        assert not np_(traj["record"])[:, :, ~used].any(), "padding bytes are zero"
     env._export(full=True)
     compare_full_state(env, ob, f"{name} after packed rollouts")
 
@@ -672,7 +676,7 @@ def test_two_lanes_per_env_rollout_equals_the_one_lane_kernel(pkg, oracle_mod, m
         got["feed"] = {k: np_(bufs[k]).copy() for k in ("actions", "rewards", "done", "truncated", "obs", "term_obs", "roles")}
         env.rollout(37, store=(), obs=None)  # state-only fast-forward, odd length
         tr = env.rollout(203, obs=obs_cfg, packed=True)
-        got["record"] = np_(tr["record"]).copy()
+        got["packed"] = {k: np_(tr[k]).copy() for k in ("actions", "rewards", "done", "truncated", "obs")}  # (views: the two kernels lay the record out differently)
         tr = env.rollout(50, obs=None)
         got["traj"] = {k: np_(tr[k]).copy() for k in ("actions", "rewards", "done", "truncated")}
         torch.cuda.synchronize()
@@ -683,10 +687,10 @@ def test_two_lanes_per_env_rollout_equals_the_one_lane_kernel(pkg, oracle_mod, m
         outs[epw] = got
     a, b = outs[16], outs[32]
     assert a["feed"]["done"].sum() > 50, "the launches must cross many episode ends"
-    for grp in ("feed", "traj", "state"):
+    for grp in ("feed", "packed", "traj", "state"):
         for k in a[grp]:
             np.testing.assert_array_equal(a[grp][k], b[grp][k], err_msg=f"{grp}/{k}")
-    for k in ("record", "metrics", "cursor", "lifetime"):
+    for k in ("metrics", "cursor", "lifetime"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     f = b["feed"]
     for s in range(120):
