@@ -92,7 +92,8 @@ def profiled_traffic(config, obs):
         d = json.load(open(files[-1]))
         d = d.get(config, d if config == "cfg2" else {})  # (round-1 summaries held cfg2 only, at top level)
         wkey = {"raw": "pmc_WRITE_SIZE", "planes": "pmc_W_planes", "flat": "pmc_W_flat"}.get(obs)
-        pick = lambda grp, ctr: next(v[ctr]["mean_per_launch"] for k, v in d[grp].items() if "k_rollout" in k)
+        # (per bench step: a step whose record array would pass 2 GiB runs as several consecutive launches)
+        pick = lambda grp, ctr: next(v[ctr]["mean_per_launch"] * v.get("launches_per_bench_step", 1) for k, v in d[grp].items() if "k_rollout" in k)
         w = pick(wkey, "WRITE_SIZE")
         f = pick("pmc_FETCH_SIZE", "FETCH_SIZE") if obs == "raw" else 0.0
         return (w + 2.0 * f) * 1024.0, os.path.basename(files[-1])

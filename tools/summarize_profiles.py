@@ -43,13 +43,19 @@ for cdir in sorted(glob.glob(f"{root}/*")):
             out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in cs.items()}
             # (every counter row of a dispatch repeats its timestamps: average over dispatches, not rows)
             out[k]["avg_duration_us"] = sum(dur[k]) / len(dur[k])
+            # (the profiled command runs 33 bench steps; a step split into consecutive launches shows as a multiple of 33)
+            n = len(dur[k])
+            out[k]["launches_per_bench_step"] = n // 33 if n % 33 == 0 and n >= 33 else 1
         per[os.path.basename(d)] = out
     # derived per wave-tick figures of the fused rollout kernel (SQ_* cycle counters tick in quad-cycles)
     try:
         roll = lambda grp: next(v for k, v in per[grp].items() if "k_rollout" in k)
         s1, s2 = roll("pmc_sq1"), roll("pmc_sq2")
         waves = s1["SQ_WAVES"]["mean_per_launch"]
-        ticks = 512
+        # the profiled command runs 33 bench steps of 512 ticks (5 warm-up + 20 timed + 8 event-pair launches); a step whose
+        # record array would pass 2 GiB is split into consecutive launches (tag5: two), so a launch holds fewer ticks
+        launches = s1["SQ_WAVES"]["launches"]
+        ticks = 512 * 33 / launches if launches % 33 == 0 else 512
         wt = waves * ticks
         wc = s1["SQ_WAVE_CYCLES"]["mean_per_launch"]
         per["derived_per_wave_tick"] = {
