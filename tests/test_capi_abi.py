@@ -110,6 +110,40 @@ def test_create_validates_like_the_reference_constructors(pkg):
     assert create(rng_mode=0) == L.E_INVALID
 
 
+def test_packed_record_layouts(pkg):
+    """susnet_record_layout: compiled-in configurations only; fields inside the record, no overlap, dword-sized; the two-lane
+    cfg4 kernel (32 environments per wave) starts the raw row on a dword boundary."""
+    L = pkg._lib
+    lib = L.lib()
+    h = C.c_void_p()
+    lay = L.RecordLayout()
+
+    def layout(**kw):
+        assert lib.susnet_create(C.byref(make_cfg(L, **kw)), C.byref(h)) == 0
+        info = L.Layout()
+        assert lib.susnet_get_layout(h, C.byref(info)) == 0
+        assert lib.susnet_record_layout(h, C.byref(lay)) == 0
+        lib.susnet_destroy(h)
+        return info.n_agents, info.obs_raw_size
+
+    itg = dict(variant=L.VARIANT_ITG, n_crew=1, n_jobs=0, is_action_order_random=0, shuffle_imposter_index=0)
+    cfg4 = dict(n_imposters=2, n_crew=6, n_jobs=4, grid_n=14)
+    for kw, want_obs_first in ((itg, False), (dict(n_crew=2, grid_n=14), False), (dict(cfg4, batch=65536), False),
+                               (dict(cfg4, batch=32768), True), (dict(variant=L.VARIANT_TAGGING, n_crew=4, n_jobs=5), False)):
+        A, F = layout(**kw)
+        assert lay.record_bytes > 0 and lay.record_bytes % 4 == 0, kw
+        used = [False] * lay.record_bytes
+        for off, n in ((lay.off_rewards, 4 * A), (lay.off_actions, A), (lay.off_done, 1), (lay.off_truncated, 1), (lay.off_obs, F)):
+            assert 0 <= off and off + n <= lay.record_bytes and not any(used[off:off + n]), (kw, off, n)
+            used[off:off + n] = [True] * n
+        assert lay.off_rewards % 4 == 0
+        assert (lay.off_obs < lay.off_done) == want_obs_first, kw
+        if want_obs_first:
+            assert lay.off_obs % 4 == 0
+    A, F = layout(n_imposters=1, n_crew=3, n_jobs=2)  # not compiled in: no packed mode
+    assert lay.record_bytes == 0
+
+
 def test_obs_sizes_follow_the_reference_featurizers(pkg):
     L = pkg._lib
     lib = L.lib()
