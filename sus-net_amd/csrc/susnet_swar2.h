@@ -210,8 +210,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
             acted |= succ;
             tog |= (uint32_t)__popc(succ) << (8 * j);
         }
-        // the pair's toggles and actor count in one exchange: toggles are 0x01 bytes, the count goes to the top byte
-        // (J <= 3 leaves it free; with J == 4 the count is exchanged on its own)
+        // the environment's toggles (0x01 per job: at most one of the two lanes holds the actor) and the actors of both words
         const Pair pt = both_halves(tog), pn = both_halves(onany);
         const uint32_t tog_env = pt.lo | pt.hi;
         const uint32_t n_on = (uint32_t)__popc(pn.lo) + (uint32_t)__popc(pn.hi);
