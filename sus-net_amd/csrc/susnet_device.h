@@ -207,6 +207,8 @@ using GenericSpec = Spec<-1, -1, -1, -1>;
 // ---------------------------------------------------------------------------------------------------
 // Philox4x32-10; key = (seed lo, hi), counter = (block lo, block hi, env lo, env hi), block = cursor >> 2,
 // word = out[cursor & 3].  Identical mapping in oracle/susnet_oracle.c (philox_word).
+// a ^ b ^ c in ONE instruction (v_bitop3_b32, truth table 0x96): a Philox round is two multiplies and two of these
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 struct PhiloxRng {
     static constexpr bool kNumpy = false;
     uint32_t k0, k1, e0, e1;
@@ -226,7 +228,7 @@ struct PhiloxRng {
 #pragma unroll
         for (int r = 0; r < 10; r++) {
             uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ d;
+            uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, a), n2 = xor3((uint32_t)(p0 >> 32), c3, d);
             c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
             a += 0x9E3779B9u; d += 0xBB67AE85u;
         }
@@ -269,7 +271,7 @@ struct ActionStream {
 #pragma unroll
         for (int q = 0; q < 10; q++) {
             uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ d;
+            uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, a), n2 = xor3((uint32_t)(p0 >> 32), c3, d);
             c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
             a += 0x9E3779B9u; d += 0xBB67AE85u;
         }
