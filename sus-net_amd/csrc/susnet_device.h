@@ -587,10 +587,90 @@ __device__ __forceinline__ int role_action(const Consts &c, uint32_t is_imp, uin
 //   TAPE   : numpy semantics incl. the FULL permutation of the valid cells (drawn even when J == 0)
 //   PHILOX : same distributions by sequential rejection of duplicates (n_imp + A + J draws, +rare retries)
 // ---------------------------------------------------------------------------------------------------
+// The placement draws of a reset at STATIC positions of the run that starts at the align(): [NPICK imposter picks], A agent cells,
+// J job cells.  With the positions known, the run's Philox blocks are generated where they start and every word is picked
+// without a cursor / block check (a reset is paid by the whole wave whenever one lane resets; with a block check -- i.e. control
+// flow and an inlined block generator -- at every draw it was 14-16 % of a rollout's cycles).  Both rejection
+// rules of the protocol (a pick that hits an earlier imposter is redrawn; a job cell that hits an earlier job is redrawn) keep the
+// first draws when those are distinct, which is what the static positions assume: distinct picks -> true, and the jobs walk the
+// loop from the first job draw only in a lane that sees a duplicate cell; colliding picks -> false, nothing the caller keeps has
+// been touched but the cursor (the caller rewinds and takes the draw-by-draw path).
+template <class S, int NPICK, class Store>
+__device__ __forceinline__ bool place_static(const Consts &c, const Tables &T, Store &st, Env &e, PhiloxRng &rng) {
+    constexpr int AA = S::kA, JJ = S::kJ;
+    if (NPICK > 0) {
+        uint32_t imp = 0;
+        bool clash = false;
+#pragma unroll
+        for (int k = 0; k < NPICK; k++) {
+            const uint32_t bit = 1u << rng.bounded_at((uint32_t)AA, k);
+            clash |= (imp & bit) != 0u;
+            imp |= bit;
+        }
+        if (__builtin_expect(clash, 0)) return false;
+        e.imp = imp;
+    }
+    uint32_t ai[AA], ji[JJ > 0 ? JJ : 1], ac[AA], jc[JJ > 0 ? JJ : 1];
+#pragma unroll
+    for (int i = 0; i < AA; i++) ai[i] = rng.bounded_at((uint32_t)c.n_valid, NPICK + i);
+    const uint64_t cur0 = rng.cur;
+#pragma unroll
+    for (int j = 0; j < JJ; j++) ji[j] = rng.bounded_at((uint32_t)c.n_valid, NPICK + AA + j);
+#pragma unroll
+    for (int i = 0; i < AA; i++) ac[i] = T.valid[ai[i]];
+#pragma unroll
+    for (int j = 0; j < JJ; j++) jc[j] = T.valid[ji[j]];
+#pragma unroll
+    for (int i = 0; i < AA; i++) st.set_agent(i, ac[i], 0u); // base.py:288-291, with replacement; tagging.py:64: counts cleared
+    bool dup = false;
+#pragma unroll
+    for (int j = 1; j < JJ; j++)
+#pragma unroll
+        for (int k = 0; k < j; k++) dup |= jc[j] == jc[k];
+    if (!dup) {
+#pragma unroll
+        for (int j = 0; j < JJ; j++) st.set_job(j, jc[j]);
+    } else {
+        rng.cur = cur0;
+#pragma unroll
+        for (int j = 0; j < JJ; j++) {
+            uint32_t xy;
+            bool d2;
+            do {
+                xy = T.valid[rng.bounded((uint32_t)c.n_valid)];
+                d2 = false;
+#pragma unroll
+                for (int k = 0; k < JJ; k++) d2 |= (k < j) && (st.job(k) == xy);
+            } while (d2);
+            st.set_job(j, xy);
+        }
+    }
+    return true;
+}
+
 template <class S, class RNG, class Store>
 __device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Store &st, int tid, Env &e, RNG &rng) {
     const int A = S::A(c), J = S::J(c);
     rng.align();
+    if constexpr (!RNG::kNumpy && !S::kGeneric && S::kJ >= 0 && S::kNI >= 1) {
+        const uint64_t run0 = rng.cur;
+        bool placed;
+        if (S::shuffle_imp(c)) {
+            placed = place_static<S, S::kNI>(c, T, st, e, rng);
+        } else {
+            e.imp = (1u << S::n_imp(c)) - 1u; // np.arange(n_imposters), base.py:278
+            placed = place_static<S, 0>(c, T, st, e, rng);
+        }
+        if (__builtin_expect(placed, 1)) {
+            e.alive = (1u << A) - 1u; // base.py:301
+            e.jd = 0;                 // base.py:302
+            e.used = 0;               // tagging.py:64-66
+            e.timer = 0;
+            e.t = 0;                  // base.py:315
+            return;
+        }
+        rng.cur = run0; // two imposter picks collided: draw by draw, below
+    }
     if (S::shuffle_imp(c)) {
         if (RNG::kNumpy) {
             uint64_t perm = 0xFEDCBA9876543210ull;
