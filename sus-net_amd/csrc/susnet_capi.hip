@@ -728,9 +728,11 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
     out->off_truncated = 5 * A + 1;
     out->off_obs = 5 * A + 2;
     out->record_bytes = 4 * A + (A + 2 + F + 3) / 4 * 4;
-    if (spec == 4 && env->c.epw == 32) {
-        // two lanes per environment (susnet_swar2.h): the raw row starts on a dword boundary so that each lane's part of it is
-        // whole dwords (done / truncated follow it): rewards | actions | obs | done | truncated | 0-padding
+    if (spec != 2) {
+        // the byte-parallel kernels (susnet_swar.h / susnet_swar2.h) put the raw row right behind the actions and done / truncated
+        // behind the row: rewards | actions | obs | done | truncated | 0-padding.  The row's job cells then start at byte 8A, so
+        // the words that hold them are stored as they are; with two lanes per environment (cfg4 at 32 envs per wave) every lane's
+        // part of the row is whole dwords
         out->off_obs = 5 * A;
         out->off_done = 5 * A + F;
         out->off_truncated = 5 * A + F + 1;

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
     BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * kRawF));
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
-    constexpr bool kRec = OUT == OUT_RECORD; // one packed record per env-step: rewards f32[A] | actions u8[A] | done | truncated | raw obs u8[F] | 0-padding
+    constexpr bool kRec = OUT == OUT_RECORD; // one packed record per env-step: rewards f32[A] | actions u8[A] | raw obs u8[F] | done | truncated | 0-padding
     constexpr int kRecDwords = RecordLayout<S>::kDwords;
     BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
     const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
@@ -617,10 +617,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 uint8_t by[(kNB + 3) / 4 * 4];
 #pragma unroll
                 for (int i = 0; i < A; i++) by[i] = (uint8_t)(act[i / 4] >> (8 * (i & 3)));
-                by[A] = done ? 1 : 0;
-                by[A + 1] = trunc ? 1 : 0;
+                // the raw row right behind the actions: its job cells then start at byte 8A of the record, i.e. the words that hold
+                // them (and, for an even job count, the status word) go out as they are; done | truncated follow the row
 #pragma unroll
-                for (int f = 0; f < kRawF; f++) by[A + 2 + f] = (uint8_t)(row[f / 4] >> (8 * (f & 3)));
+                for (int f = 0; f < kRawF; f++) by[A + f] = (uint8_t)(row[f / 4] >> (8 * (f & 3)));
+                by[A + kRawF] = done ? 1 : 0;
+                by[A + kRawF + 1] = trunc ? 1 : 0;
 #pragma unroll
                 for (int q = kNB; q < (kNB + 3) / 4 * 4; q++) by[q] = 0;
                 uint32_t rec[kRecDwords];

@@ -111,8 +111,8 @@ def test_create_validates_like_the_reference_constructors(pkg):
 
 
 def test_packed_record_layouts(pkg):
-    """susnet_record_layout: compiled-in configurations only; fields inside the record, no overlap, dword-sized; the two-lane
-    cfg4 kernel (32 environments per wave) starts the raw row on a dword boundary."""
+    """susnet_record_layout: compiled-in configurations only; fields inside the record, no overlap, dword-sized; the byte-parallel
+    kernels put the raw row right behind the actions (job cells on a dword boundary), the 1v1 kernels done / truncated first."""
     L = pkg._lib
     lib = L.lib()
     h = C.c_void_p()
@@ -128,8 +128,8 @@ def test_packed_record_layouts(pkg):
 
     itg = dict(variant=L.VARIANT_ITG, n_crew=1, n_jobs=0, is_action_order_random=0, shuffle_imposter_index=0)
     cfg4 = dict(n_imposters=2, n_crew=6, n_jobs=4, grid_n=14)
-    for kw, want_obs_first in ((itg, False), (dict(n_crew=2, grid_n=14), False), (dict(cfg4, batch=65536), False),
-                               (dict(cfg4, batch=32768), True), (dict(variant=L.VARIANT_TAGGING, n_crew=4, n_jobs=5), False)):
+    for kw, want_obs_first in ((itg, False), (dict(n_crew=2, grid_n=14), True), (dict(cfg4, batch=65536), True),
+                               (dict(cfg4, batch=32768), True), (dict(variant=L.VARIANT_TAGGING, n_crew=4, n_jobs=5), True)):
         A, F = layout(**kw)
         assert lay.record_bytes > 0 and lay.record_bytes % 4 == 0, kw
         used = [False] * lay.record_bytes
@@ -138,8 +138,8 @@ def test_packed_record_layouts(pkg):
             used[off:off + n] = [True] * n
         assert lay.off_rewards % 4 == 0
         assert (lay.off_obs < lay.off_done) == want_obs_first, kw
-        if want_obs_first:
-            assert lay.off_obs % 4 == 0
+        if want_obs_first:  # the byte-parallel kernels: raw row right behind the actions, its job cells on a dword boundary
+            assert lay.off_obs == 5 * A and (lay.off_obs + 3 * A) % 4 == 0
     A, F = layout(n_imposters=1, n_crew=3, n_jobs=2)  # not compiled in: no packed mode
     assert lay.record_bytes == 0
 
