@@ -720,12 +720,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
         if (kRec) drec.so = (uint32_t)tick * slab_rec;
-        uint32_t act2[2], R2[2];
-        sample_actions_swar<S, POS>(c, w, rng, as, tick_base + (uint64_t)tick, act2);
+        uint32_t R2[2];
+        const uint32_t act = sample_actions_pair<S, POS>(w, rng, as, tick_base + (uint64_t)tick);
         static_assert(RankLut<S>::kOk || S::kOrd == 0, "a shuffled order comes from the rank tables here");
         if constexpr (RankLut<S>::kOk) ranks_from_lut<S, POS>(rng, as, tick_base + (uint64_t)tick, R2);
         else identity_ranks<S>(R2);
-        const uint32_t act = h ? act2[1] : act2[0], R = h ? R2[1] : R2[0];
+        const uint32_t R = h ? R2[1] : R2[0];
         float rr[4];
         bool done, trunc;
         step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc);

@@ -63,7 +63,8 @@ struct Swar2 {
     uint32_t ihot[NI];          // 0x80 at imposter s's byte if it is in my word
     uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes
     uint32_t jobs_obs[2], jd;   // observation bytes of the job cells; completed: 0x01 per job
-    uint32_t nact[A];           // len(agent_action_map[i]), all agents (the action draws are made for the whole env in both lanes)
+    uint32_t nq[4];             // len(agent_action_map[i]) of MY four agents
+    uint32_t pre;               // what my first action draw's word is multiplied with first (see sample_actions_pair)
     uint32_t imp_bits;          // imposter bitmask of the episode
 };
 
@@ -86,8 +87,40 @@ __device__ __forceinline__ void to_swar2(const Consts &c, const Store &st, const
     w.jobs_obs[1] = f.jobs_obs[1];
     w.jd = f.jd[0];
 #pragma unroll
-    for (int i = 0; i < Swar2<S>::A; i++) w.nact[i] = f.nact[i];
+    for (int q = 0; q < 4; q++) w.nq[q] = h ? f.nact[4 + q] : f.nact[q];
+    w.pre = h ? f.nact[0] * f.nact[1] * f.nact[2] * f.nact[3] : 1u;
     w.imp_bits = swar_imp_bits(f);
+}
+
+// base.py:326-330 on the production stream, MY four action bytes only.  The tick's action draws are nested multiply-shift digits of
+// its words (susnet_device.h AwLayout; 8 agents with at most 7 actions: agents 0-4 in word 0, agents 5-7 and the first shuffle digits
+// in word 1).  The low lane takes the first four digits of word 0.  The high lane needs the FIFTH digit of word 0: what four
+// draws leave of a word is lo32(word * n0 n1 n2 n3) -- multiplication mod 2^32 is associative -- so one multiply by the episode's
+// product gets it there; it then takes the three digits of word 1.  Same instructions in both lanes, lane-specific operands:
+// one multiply, four multiply-shifts, one select instead of eight multiply-shifts and the packing of both words.
+// `as.rem` is left as ranks_from_lut expects it: what the action draws left of word 1 (the high lane holds it).
+template <class S, int POS, class AS>
+__device__ __forceinline__ uint32_t sample_actions_pair(const Swar2<S> &w, PhiloxRng &rng, AS &as, uint64_t tick) {
+    static_assert(S::kA == 8 && S::kAw.word[0] == 0 && S::kAw.word[4] == 0 && S::kAw.word[5] == 1 && S::kAw.word[7] == 1 && S::kAw.word[8] == 1,
+                  "agents 0-4 draw from word 0, agents 5-7 from word 1, the shuffle digits follow in word 1");
+    const uint64_t Wt = (uint64_t)S::kAw.W;
+    auto fetch = [&](int k) __attribute__((always_inline)) {
+        return POS >= 0 ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * Wt, (POS >= 0 ? POS : 0) * S::kAw.W + k)
+                        : as.word(rng, tick * Wt + (uint64_t)k);
+    };
+    const uint32_t w0 = fetch(0), w1 = fetch(1);
+    uint32_t x = w0 * w.pre;
+    uint64_t p = (uint64_t)x * (uint64_t)w.nq[0];
+    uint32_t act = (uint32_t)(p >> 32);
+    x = w.h ? w1 : (uint32_t)p;
+#pragma unroll
+    for (int q = 1; q < 4; q++) {
+        p = (uint64_t)x * (uint64_t)w.nq[q];
+        act |= (uint32_t)(p >> 32) << (8 * q);
+        x = (uint32_t)p;
+    }
+    as.rem = both_halves(x).hi;
+    return act;
 }
 
 // the whole environment again (both lanes of the pair must be active)
