@@ -953,6 +953,27 @@ def test_full_batch_invariants(pkg):
     assert torch.equal(env3.agent_positions, env.agent_positions) and torch.equal(env3.job_positions, env.job_positions)
 
 
+@pytest.mark.parametrize("name,B", [("itg_1v1_nowalls", 65536), ("base_1v2_j4_14", 65536), ("base_2v6_j4_14", 32768), ("tagging_1v4_j5", 65536)])
+def test_packed_records_are_reproducible_at_bench_sizes(pkg, oracle_mod, name, B):
+    """The benchmarked launches (packed records, the bench's batch per GPU) repeated from the same state give the same bytes.
+    This is the cheap net for timing-dependent faults of the kind found this round (a store's data registers overwritten before
+    the store had read them: a few waves of a 40 000-env launch differed from run to run)."""
+    T = 48
+    recs = []
+    for rep in range(3):
+        env, _ = make_pair(pkg, oracle_mod, name, B, 5, auto_reset=True, check_errors=False)
+        if env.record_layout() is None:
+            pytest.skip("configuration not compiled in")
+        env.reset()
+        bufs = env.alloc_rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8), packed=True)
+        env.rollout_into(T, bufs)
+        env.rollout_into(T, bufs)  # (a second launch: starts mid-stream, other group phases)
+        torch.cuda.synchronize()
+        recs.append(bufs["record"].clone())
+        del env, bufs
+    assert torch.equal(recs[0], recs[1]) and torch.equal(recs[0], recs[2])
+
+
 # ------------------------------------------------------------------------------------------------
 # policy in the loop (BASELINE config 5): device-side obs -> MLP -> argmax -> step, checked by replaying the
 # recorded actions through the oracle
