@@ -232,9 +232,11 @@ typedef struct susnet_ring_io {
 } susnet_ring_io;
 int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, void *stream);
 
-/* Packed trajectory record of susnet_rollout_io.record: rewards f32[A] at byte 0, then actions u8[A], done u8,
- * truncated u8, raw observation u8[obs_raw_size] (flatten_state order), zero-padded to a multiple of 4 bytes.
- * *record_bytes = 0 when the handle's configuration has no packed mode (not one of the compiled-in games). */
+/* Packed trajectory record of susnet_rollout_io.record: rewards f32[A], actions u8[A], done u8, truncated u8 and the raw
+ * observation u8[obs_raw_size] (flatten_state order) of one env-step, zero-padded to a multiple of 4 bytes.  The ORDER of the
+ * fields depends on the kernel that serves the handle (the multi-agent kernels store the observation right behind the actions
+ * and done / truncated behind it, so that its words go out unshifted): read the byte offsets below, do not assume them.
+ * record_bytes = 0 when the handle's configuration has no packed mode (not one of the compiled-in games). */
 typedef struct susnet_record_layout_t {
     int32_t record_bytes;
     int32_t off_rewards, off_actions, off_done, off_truncated, off_obs;
