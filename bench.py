@@ -337,7 +337,11 @@ def main():
             "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
             "stored_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "algorithmic_bytes_per_launch": steps_per_launch * b_alg, "stored_bytes_per_launch": steps_per_launch * b_stored,
-            "kernel": "k_rollout" if args.mode == "fused" else "k_step<PhiloxRng>",
+            # (the names rocprofv3 reports for these launches: profiles/rNN_<config>_kernel_stats.csv)
+            "kernel": ({"cfg2": "k_rollout_duel<PhiloxRng, OUT>", "cfg3": "k_rollout_swar<Spec<3,4,..>, OUT>",
+                        "cfg4": "k_rollout_swar2<Spec<8,4,..>, OUT>" if B == 32768 else "k_rollout_swar<Spec<8,4,..>, OUT>",
+                        "tag5": "k_rollout_swar<Spec<5,5,2,..>, OUT>"}.get(args.config, "k_rollout")
+                       if args.mode == "fused" else "k_step<PhiloxRng, Spec>"),
             "algorithmic_bytes_per_env_step": b_alg, "stored_bytes_per_env_step": b_stored,
             "achieved_stored_GBs": steps_per_launch * b_stored / avg_launch_s / 1e9,
             "env_steps_per_launch": steps_per_launch, "avg_launch_us": avg_launch_s * 1e6,
