@@ -879,58 +879,129 @@ __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t 
     if (u < 0) return r.io.window + ((size_t)b * Tw + (size_t)(Tw + u < 0 ? 0 : Tw + u)) * r.S; // window[Tw - 1] = state before tick 0
     return r.io.obs + ((size_t)u * r.B + b) * r.S;
 }
-// One wave per 64 consecutive transitions.  Lane r gathers its row's Tw + 1 states (window + true next state) into an
-// LDS strip; the wave then expands the strips to float32 with coalesced stores (states = strip[0 .. Tw), next = strip[1 .. Tw]).
+// One wave per 64 consecutive transitions.  Lane r gathers what its row needs into flat images in LDS, laid out exactly as the
+// wave's 64 rows lie in each ring tensor (row-major; `states` and `next_states`: Tw * S bytes per row, the Tw - 1 shared states
+// written to both; actions, rewards, done, imposters likewise), and the wave then writes every tensor as ONE linear range:
+// 16 bytes per lane and step, no index arithmetic.  Two things made the first version slow (3.1-3.5 TB/s, 82 % of the wave cycles
+// waiting): every element index was divided by Tw * S to find its row, and each lane stored its row's small tensors between its
+// loads -- stores the loads behind them had to wait for (may-alias), one memory round trip per element.  Now a lane only LOADS in
+// the gather phase (flags first, unrolled without an early exit; then rows, actions, rewards, roles) and all global stores happen
+// after it.
+constexpr int kRingFlagsUnroll = 8;
 __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
     extern __shared__ uint32_t smem[];
-    uint8_t *strip = reinterpret_cast<uint8_t *>(smem);
-    const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A;
+    const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A, NI = r.n_imp;
     const int64_t n_first = r.n0 + (int64_t)blockIdx.x * 64, n = n_first + lane;
     const int rows = (int)((r.n1 - n_first) < 64 ? (r.n1 - n_first) : 64);
-    const int L = (Tw + 1) * S; // strip bytes per row
-    int64_t pos = 0;
+    const int TS = Tw * S;
+    const int img = (64 * TS + 15) & ~15; // bytes of one state image (padded: the vector loops read up to 3 bytes past the last row)
+    uint8_t *st_img = reinterpret_cast<uint8_t *>(smem), *nx_img = st_img + img;
+    float *rew_img = reinterpret_cast<float *>(nx_img + img);         // [64][A]
+    uint8_t *act_img = reinterpret_cast<uint8_t *>(rew_img + 64 * A); // [64][A] (+ pad)
+    uint8_t *done_img = act_img + ((64 * A + 15) & ~15);              // [64]
+    int16_t *imp_img = reinterpret_cast<int16_t *>(done_img + 64);    // [64][NI]
     if (lane < rows) {
         const int64_t t = n / r.B, b = n % r.B;
-        pos = (r.io.idx + n) % r.io.max_size;
-        // most recent episode boundary before tick t within the window's reach: the episode's first state is obs[e]
+        // most recent episode boundary before tick t within the window's reach (the episode's first state is obs[e]); all flag
+        // loads are independent of each other
         int64_t e = -(1ll << 62);
-        for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
-            if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
-        uint8_t *mine = strip + (size_t)lane * L;
+        if (Tw <= kRingFlagsUnroll) {
+            uint32_t fl[kRingFlagsUnroll];
+#pragma unroll
+            for (int k = 1; k <= kRingFlagsUnroll; k++) {
+                const int64_t u = t - k;
+                fl[k - 1] = (k <= Tw && u >= 0) ? (uint32_t)(r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) : 0u;
+            }
+#pragma unroll
+            for (int k = kRingFlagsUnroll; k >= 1; k--)
+                if (fl[k - 1]) e = t - k; // (descending k: the most recent boundary wins)
+        } else {
+            for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
+                if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
+        }
+        const uint32_t dn = r.io.done[t * r.B + b], tr = r.io.truncated[t * r.B + b];
+        const uint32_t role_bits = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << NI) - 1u);
+        uint8_t *my_st = st_img + (size_t)lane * TS, *my_nx = nx_img + (size_t)lane * TS;
         for (int k = 0; k < Tw; k++) { // replay_memory.py:108-113, 122-127
             int64_t u = t - Tw + k;
             if (u < e) u = e;
             const uint8_t *src = ring_state(r, u, b);
-            for (int f = 0; f < S; f++) mine[k * S + f] = src[f];
+            if (k == 0) {
+                for (int f = 0; f < S; f++) my_st[f] = src[f];
+            } else {
+                for (int f = 0; f < S; f++) {
+                    const uint8_t v = src[f];
+                    my_st[k * S + f] = v;
+                    my_nx[(k - 1) * S + f] = v;
+                }
+            }
         }
-        const bool ended = (r.io.done[t * r.B + b] | r.io.truncated[t * r.B + b]) != 0;
-        const uint8_t *nxt = (ended ? r.io.term_obs : r.io.obs) + ((size_t)t * r.B + b) * S;
-        for (int f = 0; f < S; f++) mine[Tw * S + f] = nxt[f];
-        // the small per-row tensors
+        const uint8_t *nxt = ((dn | tr) ? r.io.term_obs : r.io.obs) + ((size_t)t * r.B + b) * S;
+        for (int f = 0; f < S; f++) my_nx[(Tw - 1) * S + f] = nxt[f];
         for (int i = 0; i < A; i++) {
-            r.io.ring_actions[pos * A + i] = (int64_t)r.io.actions[((size_t)t * r.B + b) * A + i];
-            r.io.ring_rewards[pos * A + i] = r.io.rewards[((size_t)t * r.B + b) * A + i];
+            act_img[lane * A + i] = r.io.actions[((size_t)t * r.B + b) * A + i];
+            rew_img[lane * A + i] = r.io.rewards[((size_t)t * r.B + b) * A + i];
         }
-        r.io.ring_dones[pos] = r.io.done[t * r.B + b] ? 1 : 0; // replay_memory.py:131: done, not truncation
-        uint32_t m = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << r.n_imp) - 1u);
-        for (int k = 0; k < r.n_imp; k++) { // ascending agent indices
+        done_img[lane] = dn ? 1 : 0; // replay_memory.py:131: done, not truncation
+        uint32_t m = role_bits;
+        for (int k = 0; k < NI; k++) { // ascending agent indices
             const int i = __ffs((int)m) - 1;
-            r.io.ring_imposters[pos * r.n_imp + k] = (int16_t)(i < 0 ? 0 : i);
+            imp_img[lane * NI + k] = (int16_t)(i < 0 ? 0 : i);
             m &= m - 1u;
         }
     }
     wave_lds_fence();
     // ring position of row 0 of this wave; rows are consecutive positions modulo max_size
     const int64_t pos0 = (r.io.idx + n_first) % r.io.max_size;
-    const int TS = Tw * S;
     const int total = rows * TS;
-    for (int g = lane; g < total; g += 64) {
-        const int row = g / TS, k = g - row * TS;
-        int64_t p = pos0 + row;
-        if (p >= r.io.max_size) p -= r.io.max_size;
-        const uint8_t *st = strip + (size_t)row * L;
-        r.io.states[(size_t)p * TS + k] = (float)st[k];
-        r.io.next_states[(size_t)p * TS + k] = (float)st[S + k];
+    if (__builtin_expect(pos0 + rows <= r.io.max_size, 1)) { // no wrap inside the wave: every output is ONE contiguous range
+        float *out_s = r.io.states + (size_t)pos0 * TS, *out_n = r.io.next_states + (size_t)pos0 * TS;
+        if ((((size_t)pos0 * TS) & 3u) == 0) { // 16-byte aligned ranges: four elements per lane and step
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(st_img), *n4 = reinterpret_cast<const uint32_t *>(nx_img);
+            for (int g = 4 * lane; g < total; g += 256) {
+                const uint32_t a = s4[g >> 2], c = n4[g >> 2];
+                const float4 fa = make_float4((float)(a & 0xffu), (float)((a >> 8) & 0xffu), (float)((a >> 16) & 0xffu), (float)(a >> 24));
+                const float4 fc = make_float4((float)(c & 0xffu), (float)((c >> 8) & 0xffu), (float)((c >> 16) & 0xffu), (float)(c >> 24));
+                if (g + 4 <= total) {
+                    *reinterpret_cast<float4 *>(out_s + g) = fa;
+                    *reinterpret_cast<float4 *>(out_n + g) = fc;
+                } else { // the range's last, partial group
+                    const float va[4] = {fa.x, fa.y, fa.z, fa.w}, vc[4] = {fc.x, fc.y, fc.z, fc.w};
+                    for (int q = 0; q < total - g; q++) { out_s[g + q] = va[q]; out_n[g + q] = vc[q]; }
+                }
+            }
+        } else {
+            for (int g = lane; g < total; g += 64) {
+                out_s[g] = (float)st_img[g];
+                out_n[g] = (float)nx_img[g];
+            }
+        }
+        int64_t *out_a = r.io.ring_actions + (size_t)pos0 * A;
+        float *out_r = r.io.ring_rewards + (size_t)pos0 * A;
+        for (int g = lane; g < rows * A; g += 64) {
+            out_a[g] = (int64_t)act_img[g];
+            out_r[g] = rew_img[g];
+        }
+        if (lane < rows) r.io.ring_dones[pos0 + lane] = done_img[lane];
+        for (int g = lane; g < rows * NI; g += 64) r.io.ring_imposters[(size_t)pos0 * NI + g] = imp_img[g];
+    } else { // the ring wraps inside this wave's rows (once per trip round the ring): element by element
+        for (int g = lane; g < total; g += 64) {
+            const int row = g / TS, k = g - row * TS;
+            int64_t p = pos0 + row;
+            if (p >= r.io.max_size) p -= r.io.max_size;
+            r.io.states[(size_t)p * TS + k] = (float)st_img[g];
+            r.io.next_states[(size_t)p * TS + k] = (float)nx_img[g];
+        }
+        if (lane < rows) {
+            int64_t p = pos0 + lane;
+            if (p >= r.io.max_size) p -= r.io.max_size;
+            for (int i = 0; i < A; i++) {
+                r.io.ring_actions[p * A + i] = (int64_t)act_img[lane * A + i];
+                r.io.ring_rewards[p * A + i] = rew_img[lane * A + i];
+            }
+            r.io.ring_dones[p] = done_img[lane];
+            for (int k = 0; k < NI; k++) r.io.ring_imposters[p * NI + k] = imp_img[lane * NI + k];
+        }
     }
 }
 // the carried window of every env after the launch: the window before the tick that follows the last one
@@ -970,7 +1041,9 @@ extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, voi
     const int64_t total = (int64_t)io->n_ticks * r.B;
     r.n0 = total > io->max_size ? total - io->max_size : 0; // (earlier rows would be overwritten by later ones of this same launch)
     r.n1 = total;
-    const size_t sh = (size_t)64 * (size_t)(io->trajectory_size + 1) * (size_t)r.S;
+    // the row images of k_ring_append: states, next_states (bytes), rewards (f32), actions (bytes), done, imposters (i16)
+    const size_t sh = 2 * (((size_t)64 * (size_t)io->trajectory_size * (size_t)r.S + 15) & ~(size_t)15) + (size_t)64 * r.A * 4 +
+                      (((size_t)64 * r.A + 15) & ~(size_t)15) + 64 + (size_t)64 * r.n_imp * 2 + 16;
     if (sh > 64 * 1024) return fail(SUSNET_E_INVALID, "susnet_ring_append: trajectory_size x state size too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t waves = (r.n1 - r.n0 + 63) / 64;
