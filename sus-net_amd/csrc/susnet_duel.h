@@ -78,7 +78,7 @@ __device__ __forceinline__ void duel_step(const DuelConsts &k, Duel &d, Env &e, 
     const uint32_t dy = __builtin_amdgcn_perm(0x00000000u, 0x007f0100u, selx); // dy by action: 0 +1 -1 0 | 0 0
     uint32_t delta = dx | (dy << 8);
     // dead agents do not act (base.py:477); a crew member killed this tick never gets its turn
-    const uint32_t live = (0u - (d.al & 1u)) & 0x0000ffffu | (0u - (d.al >> 1)) & 0xffff0000u;
+    const uint32_t live = ((0u - (d.al & 1u)) & 0x0000ffffu) | ((0u - (d.al >> 1)) & 0xffff0000u);
     delta &= live;
     const uint32_t q = (d.pq + delta) ^ ((delta << 1) & k80); // bytes in [0, n + 1]
     // undo a step off the grid: byte == 0 or byte == n + 1 (_is_valid_position, base.py:548-551: bounds only, no walls here)
