@@ -604,9 +604,11 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
     return SUSNET_OK;
 }
 
-static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset, bool generic = true) {
+// spec: what pick_spec() returned for the launch (0 = the generic kernels, the LDS-column store; 3 / 4 / 6 = the byte-parallel
+// configurations, whose rollouts stage the action stream in LDS: HasGroupWords in susnet_device.h)
+static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset, int spec = 0) {
     const Consts &c = env->c;
-    size_t core = (size_t)lds_core_words(c.A, c.J, generic) * 4;
+    size_t core = (size_t)lds_core_words(c.A, c.J, spec == 0, spec == 3 || spec == 4 || spec == 6) * 4;
     size_t perm = (may_reset && env->cfg.rng_mode == SUSNET_RNG_TAPE) ? (size_t)c.n_valid * kBlock : 0;
     size_t stage = (size_t)(o.words1 + o.words2) * 4;
     return core + (perm > stage ? perm : stage);
@@ -694,7 +696,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     // same code the production stream uses
     const bool tape = env->cfg.rng_mode == SUSNET_RNG_TAPE;
     const int spec = pick_spec(env->c, env->float_exact);
-    size_t sh = lds_bytes(env, o, env->c.auto_reset != 0, spec == 0);
+    size_t sh = lds_bytes(env, o, env->c.auto_reset != 0, spec);
     CHECK_LDS(sh);
     const dim3 g = grid_for(env), blk(kBlock);
     switch (spec) {
@@ -768,7 +770,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         if ((uintptr_t)a.record % 16) return fail(SUSNET_E_INVALID, "record buffer must be 16-byte aligned");
         a.record_bytes = lay.record_bytes;
     }
-    size_t sh = lds_bytes(env, o, true, spec == 0);
+    size_t sh = lds_bytes(env, o, true, spec);
     CHECK_LDS(sh);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 g((unsigned)((env->c.B + env->c.epw - 1) / env->c.epw)), blk(kBlock);

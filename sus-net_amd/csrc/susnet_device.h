@@ -201,6 +201,10 @@ struct Spec {
     __device__ static __forceinline__ uint32_t nr_crew(const Consts &c) { return VAR_ >= 0 ? (VAR_ == SUSNET_VARIANT_ITG ? 5u : 6u) : (uint32_t)c.nr_crew; }
 };
 using GenericSpec = Spec<-1, -1, -1, -1>;
+// configurations whose fused rollouts stage the action stream in LDS a group of ticks at a time (the byte-parallel kernels:
+// agent count, variant and order compiled in, 3 .. 8 agents); the host reserves the space for exactly these (susnet_capi.hip)
+template <class S>
+struct HasGroupWords { static constexpr bool value = !S::kGeneric && S::kStaticAw && S::kA >= 3 && S::kA <= 8; };
 
 // ---------------------------------------------------------------------------------------------------
 // word sources
@@ -356,9 +360,16 @@ constexpr uint32_t kMoveTableWord = 96, kRewardTableWord = 480; // (setup_lds)
 __device__ __forceinline__ uint32_t lds_move_lookup(uint32_t row_cell) { return *(lds_u8_ptr)(uintptr_t)(lds_table_addr(kMoveTableWord) + row_cell); }
 __device__ __forceinline__ float lds_reward_lookup(uint32_t byte_index) { return *(lds_f32_ptr)(uintptr_t)(lds_table_addr(kRewardTableWord) + byte_index); }
 
-__host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic) {
-    return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u);
+// The byte-parallel rollouts (susnet_swar.h GroupWords) stage the action-stream words of one GROUP of ticks behind the tables:
+// at most 12 words x 64 environments (cfg4: 3 words per tick, 4 ticks; with two lanes per environment 24 words x 32)
+constexpr uint32_t kGroupWords = 768;
+__host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic, bool group_words = false) {
+    return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u) + (group_words ? kGroupWords : 0u);
 }
+
+// first LDS word of the group-words area (carve_lds: behind the tables; compiled-in configurations have no store columns)
+template <class S>
+__device__ __forceinline__ constexpr uint32_t kGroupWordsWord() { static_assert(!S::kGeneric, "compiled-in configurations"); return kTableWords; }
 
 // generic flavour: [index][lane] columns in LDS (cell in bits 0-7, tag count in bits 8-15 of one word)
 struct LdsStore {
@@ -463,6 +474,7 @@ __device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, int
     uint32_t *rest = smem + kTableWords;
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
+    if (HasGroupWords<S>::value) rest += kGroupWords;
     T.perm = reinterpret_cast<uint8_t *>(rest);
     T.stage = rest;
     return T;

@@ -524,8 +524,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     wave_lds_fence();
     Env e = {};
     RNG rng = make_rng<RNG>(c, s, active ? b : 0);
-    ActionStream as;
-    as.init();
     if (active) load_env<S>(c, s, st, b, e);
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
     if ((kTraj || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
@@ -554,8 +552,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
     const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
     if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
-    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
-        constexpr int POS = decltype(par)::value;
+    // production stream: the words of a group of 4 ticks (whole Philox blocks) are generated at the group's first tick and staged
+    // in LDS (GroupWords); the tick loop is rolled -- one copy of the step and of the reset path
+    static_assert(HasGroupWords<S>::value && (RankLut<S>::kOk || S::kOrd == 0), "grouped action stream; a shuffled order comes from the rank tables");
+    using GW = GroupWords<S::kAw.W, false>;
+    GW gw;
+    gw.init(kGroupWordsWord<S>(), tid);
+    auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) { // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index, nothing loop-carried
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
@@ -572,9 +575,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                     ranks_from_order<S>(ord, R);
                 }
             } else {
-                sample_actions_swar<S, POS>(c, w, rng, as, tick_base + (uint64_t)tick, act);
-                if (RankLut<S>::kOk) ranks_from_lut<S, POS>(rng, as, tick_base + (uint64_t)tick, R);
-                else if (S::kOrd > 0) ranks_from_stream<S, POS>(c, 0u, rng, as, tick_base + (uint64_t)tick, true, R);
+                const uint64_t gt = tick_base + (uint64_t)tick;
+                const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
+                if (tick == 0 || pos == 0u) { // (wave-uniform)
+                    gw.refill(rng, gt / (uint64_t)GW::G);
+                    wave_lds_publish();
+                }
+                TickWords<GW::W> tw;
+#pragma unroll
+                for (int k = 0; k < GW::W; k++) tw.wd[k] = gw.read(pos, k);
+                tw.rem = 0u;
+                sample_actions_swar<S, 0>(c, w, rng, tw, gt, act);
+                if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R);
                 else identity_ranks<S>(R);
             }
             if (kTraj) store_packed_bytes<A>(da, act);
@@ -645,17 +657,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
         }
     };
-    constexpr int kGroup = (OUT == OUT_ANY || RNG::kNumpy) ? 0 : 4; // groups of 4 ticks start on a Philox block boundary of the action stream
-    int tick = 0;
-    while (tick < a.n_ticks) {
-        if (kGroup > 0 && tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) & 3ull) == 0ull) {
-            static_for<0, (kGroup > 0 ? kGroup : 1)>([&](auto pos) __attribute__((always_inline)) { tick_body(tick + decltype(pos)::value, pos); });
-            tick += kGroup;
-        } else {
-            tick_body(tick, std::integral_constant<int, -1>{});
-            tick++;
-        }
-    }
+#pragma clang loop unroll(disable)
+    for (int tick = 0; tick < a.n_ticks; tick++) tick_body(tick);
     if (active) {
         from_swar<S>(c, w, st, e);
         store_env<S>(c, s, st, b, e, true);
@@ -687,9 +690,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     wave_lds_fence();
     Env e = {};
     RNG rng = make_rng<RNG>(c, s, active ? b : 0);
-    PairActionStream as;
-    as.init();
-    as.h_ = h;
     if (!active) return; // both lanes of a pair leave together: every exchange below is between two active lanes
     load_env<S>(c, s, st, b, e);
     W w;
@@ -713,17 +713,31 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
     const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
     if (a.n_ticks > 0) clear_info_if_fresh(e);
-    auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
-        constexpr int POS = decltype(par)::value;
+    // the action stream: groups of 8 ticks = whole PAIRS of Philox blocks, lane h generating the blocks 2k + h, staged in LDS
+    // (GroupWords); the tick loop is rolled -- one copy of the step and of the reset path
+    static_assert(HasGroupWords<S>::value && (RankLut<S>::kOk || S::kOrd == 0), "grouped action stream; a shuffled order comes from the rank tables");
+    using GW = GroupWords<S::kAw.W, true>;
+    GW gw;
+    gw.init(kGroupWordsWord<S>(), tid);
+    auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) {
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
         if (kRec) drec.so = (uint32_t)tick * slab_rec;
+        const uint64_t gt = tick_base + (uint64_t)tick;
+        const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
+        if (tick == 0 || pos == 0u) { // (wave-uniform)
+            gw.refill(rng, gt / (uint64_t)GW::G);
+            wave_lds_publish();
+        }
+        TickWords<GW::W> tw;
+#pragma unroll
+        for (int k = 0; k < GW::W; k++) tw.wd[k] = gw.read(pos, k);
+        tw.rem = 0u;
         uint32_t R2[2];
-        const uint32_t act = sample_actions_pair<S, POS>(w, rng, as, tick_base + (uint64_t)tick);
-        static_assert(RankLut<S>::kOk || S::kOrd == 0, "a shuffled order comes from the rank tables here");
-        if constexpr (RankLut<S>::kOk) ranks_from_lut<S, POS>(rng, as, tick_base + (uint64_t)tick, R2);
+        const uint32_t act = sample_actions_pair<S, 0>(w, rng, tw, gt);
+        if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R2);
         else identity_ranks<S>(R2);
         const uint32_t R = h ? R2[1] : R2[0];
         float rr[4];
@@ -774,17 +788,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
                 drec.st128(5u * A + 24u, w.jobs_obs[0], w.jobs_obs[1], w.jd, (done ? 1u : 0u) | (trunc ? 0x100u : 0u));
         }
     };
-    constexpr int kGroup = 8; // groups of 8 ticks start on a boundary of Philox block PAIRS of the action stream (W words per tick)
-    int tick = 0;
-    while (tick < a.n_ticks) {
-        if (tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) & 7ull) == 0ull) {
-            static_for<0, kGroup>([&](auto pos) __attribute__((always_inline)) { tick_body(tick + decltype(pos)::value, pos); });
-            tick += kGroup;
-        } else {
-            tick_body(tick, std::integral_constant<int, -1>{});
-            tick++;
-        }
-    }
+#pragma clang loop unroll(disable)
+    for (int tick = 0; tick < a.n_ticks; tick++) tick_body(tick);
     {
         Swar<S> f;
         gather_swar2<S>(w, f);

@@ -44,6 +44,56 @@ __device__ __forceinline__ uint32_t zero80(uint32_t x) {
 // bytes of a where the 0xff mask m is set, else bytes of b
 __device__ __forceinline__ uint32_t sel_bytes(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
+// ---- the action stream of a fused rollout, one GROUP of ticks at a time -------------------------------------------------------
+// A tick owns W consecutive words of the action stream (susnet_device.h AwLayout), a Philox block has four: a group of G ticks
+// (4; 8 with two lanes per environment) covers whole blocks.  At the first tick of a group the wave generates the group's blocks
+// in ONE rolled loop and parks the words in LDS, [word][environment]; a tick then reads its W words back by position.  The tick
+// loop itself is NOT unrolled: one copy of the step and of the in-launch reset path, whatever W is.  (Round 2 unrolled a whole
+// group with static word selection: cfg4's kernel was 36 000 instructions / 240 KB with 255 spilled SGPRs, the tagging kernel
+// used all 256 VGPRs + 73 AGPRs.)  PAIR: lanes L and L + 32 serve one environment (susnet_swar2.h); lane h generates the blocks
+// 2k + h and both lanes read all of them -- the exchange that cost a v_permlane32_swap per word is the LDS round trip itself.
+template <int W_, bool PAIR>
+struct GroupWords {
+    static constexpr int W = W_, G = PAIR ? 8 : 4, NBLK = W * G / 4, kCols = PAIR ? 32 : 64;
+    static_assert(W * G * kCols <= (int)kGroupWords && (W * G) % (PAIR ? 8 : 4) == 0, "group size");
+    typedef __attribute__((address_space(3))) uint32_t *lds_u32_wptr;
+    uint32_t col; // LDS byte address of word 0 of my environment's column
+    uint32_t h;   // PAIR: which half of the pair I am
+    __device__ __forceinline__ void init(uint32_t first_word, int tid) {
+        col = lds_table_addr(first_word) + 4u * (uint32_t)(PAIR ? (tid & 31) : tid);
+        h = PAIR ? (uint32_t)tid >> 5 : 0u;
+    }
+    // all blocks of group number `group` (= absolute tick / G)
+    __device__ __forceinline__ void refill(const PhiloxRng &r, uint64_t group) const {
+        constexpr int kMine = PAIR ? NBLK / 2 : NBLK; // blocks this lane generates
+        const uint64_t b0 = group * (uint64_t)NBLK + (uint64_t)h;
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < kMine; k++) {
+            ActionStream blk;
+            blk.gen(r, b0 + (uint64_t)(PAIR ? 2 * k : k));
+            const uint32_t a = col + (uint32_t)(PAIR ? 8 * k : 4 * k) * (4u * kCols) + (PAIR ? h * (16u * kCols) : 0u);
+            *(lds_u32_wptr)(uintptr_t)(a) = blk.w0;
+            *(lds_u32_wptr)(uintptr_t)(a + 4u * kCols) = blk.w1;
+            *(lds_u32_wptr)(uintptr_t)(a + 8u * kCols) = blk.w2;
+            *(lds_u32_wptr)(uintptr_t)(a + 12u * kCols) = blk.w3;
+        }
+    }
+    // word k (compile-time) of the tick at position `pos` of the group
+    __device__ __forceinline__ uint32_t read(uint32_t pos, int k) const {
+        typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+        return *(lds_u32_ptr)(uintptr_t)(col + pos * (uint32_t)(W * 4 * kCols) + (uint32_t)(k * 4 * kCols));
+    }
+};
+// the W words of one tick in registers, behind the interface sample_actions_swar / sample_actions_pair / ranks_from_lut expect
+// of a word source (they are called with POS = 0: "word g of the group that starts at this tick")
+template <int W_>
+struct TickWords {
+    uint32_t wd[W_];
+    uint32_t rem;
+    __device__ __forceinline__ uint32_t word_in_group(const PhiloxRng &, uint64_t, int g) const { return wd[g]; }
+    __device__ __forceinline__ uint32_t word(const PhiloxRng &, uint64_t) const { return 0u; } // (run-time positions: not used with POS = 0)
+};
+
 template <class S>
 struct Swar {
     static constexpr int A = S::kA, J = S::kJ, NW = (S::kA + 3) / 4, NI = S::kNI > 0 ? S::kNI : 1, JW = S::kJ > 4 ? 2 : 1;
@@ -424,59 +474,68 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     // Evaluated for all jobs without a branch per job, in AGENT space: on[j] = the actors standing on job j; an actor succeeds
     // when the job's status is the one its role changes (crew: open, imposter: completed) -- one 3-input bit operation per word
     // against the job's status broadcast to every byte; a job whose actor succeeded flips.  Exact as long as no job has two
-    // actors in the same step; two actors on job cells anywhere in an env (a superset, rare) send the wave to the turn-ordered
-    // loop instead.
+    // actors in the same step; a job with two actors in some env (rare: two agents on one cell, both working) sends the wave to
+    // the turn-ordered loop instead.
     uint32_t fc80[NW], sc80[NW];
 #pragma unroll
     for (int q = 0; q < NW; q++) fc80[q] = sc80[q] = 0;
     if (W::kBase && J > 0) {
         constexpr int JW = W::JW;
-        uint32_t ja80[NW], on[J][NW], onany[NW], acted[NW], tog[JW];
+        uint32_t ja80[NW], on[J][NW], acted[NW], tog[JW];
 #pragma unroll
         for (int q = 0; q < NW; q++) {
             ja80[q] = (fix80[q] | sab80[q]) & ~pend80[q]; // job actors did not move: w.xy is still their cell
-            onany[q] = acted[q] = 0;
+            acted[q] = 0;
         }
 #pragma unroll
         for (int q = 0; q < JW; q++) tog[q] = 0;
+        uint32_t crowd = 0; // bit 1 and up: some job has more than one actor on it
 #pragma unroll
         for (int j = 0; j < J; j++) {
             const uint32_t dj80 = (0u - ((w.jd[j / 4] >> (8 * (j & 3))) & 1u)) & k80; // the job's status at every agent byte
-            uint32_t n = 0;
+            uint32_t n = 0, n_on = 0;
 #pragma unroll
             for (int q = 0; q < NW; q++) {
                 on[j][q] = zero80(w.xy[q] ^ w.jb[j]) & ja80[q];
-                onany[q] |= on[j][q];
+                n_on += (uint32_t)__popc(on[j][q]);
                 const uint32_t succ = on[j][q] & ~(w.im80[q] ^ dj80); // crew (flag 0) on an open job, imposter (0x80) on a completed one
                 acted[q] |= succ;
                 n += (uint32_t)__popc(succ);
             }
+            crowd |= n_on;
             tog[j / 4] |= n << (8 * (j & 3));
         }
-        uint32_t n_on = 0;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(crowd > 1u) != 0ull, 0)) {
+            // two agents work on the SAME job in one env of this wave: the actors in turn order (base.py:377-382).  Jobs are
+            // independent of each other (distinct cells, base.py:295-299), so the turns are the outer, ROLLED loop: rare code, kept small
+            uint32_t dj[J];
 #pragma unroll
-        for (int q = 0; q < NW; q++) n_on += (uint32_t)__popc(onany[q]);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(n_on > 1u) != 0ull, 0)) {
-            // two agents work on job cells in one env of this wave -- possibly the same job: every job in turn order (base.py:377-382)
+            for (int j = 0; j < J; j++) dj[j] = (w.jd[j / 4] >> (8 * (j & 3))) & 1u;
+#pragma clang loop unroll(disable)
+            for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
+                const uint32_t tb = (turn | 0x80u) * k01;
+                uint32_t mine[NW];
 #pragma unroll
-            for (int j = 0; j < J; j++) {
-                uint32_t dj = (w.jd[j / 4] >> (8 * (j & 3))) & 1u;
-                for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
-                    const uint32_t tb = (turn | 0x80u) * k01;
+                for (int q = 0; q < NW; q++) mine[q] = zero80(R[q] ^ tb); // the agent whose turn it is
+#pragma unroll
+                for (int j = 0; j < J; j++) {
 #pragma unroll
                     for (int q = 0; q < NW; q++) {
-                        const uint32_t me = zero80(R[q] ^ tb) & on[j][q]; // the actor whose turn it is, if it works on this job
+                        const uint32_t me = mine[q] & on[j][q]; // ... if it works on this job
                         const bool is_sab = (me & w.im80[q]) != 0u, is_fix = (me & ~w.im80[q]) != 0u;
-                        const bool f = is_fix && dj == 0u, sb = is_sab && dj != 0u;
-                        dj = f ? 1u : (sb ? 0u : dj);
+                        const bool f = is_fix && dj[j] == 0u, sb = is_sab && dj[j] != 0u;
+                        dj[j] = f ? 1u : (sb ? 0u : dj[j]);
                         e.m_fix += f ? 1u : 0u;
                         e.m_sab += sb ? 1u : 0u;
                         fc80[q] |= f ? me : 0u;
                         sc80[q] |= sb ? me : 0u;
                     }
                 }
-                w.jd[j / 4] = (w.jd[j / 4] & ~(1u << (8 * (j & 3)))) | (dj << (8 * (j & 3)));
             }
+#pragma unroll
+            for (int q = 0; q < JW; q++) w.jd[q] = 0;
+#pragma unroll
+            for (int j = 0; j < J; j++) w.jd[j / 4] |= dj[j] << (8 * (j & 3));
         } else {
 #pragma unroll
             for (int q = 0; q < JW; q++) w.jd[q] ^= tog[q];

@@ -27,32 +27,6 @@ __device__ __forceinline__ Pair both_halves(uint32_t v) {
     return Pair{r[0], r[1]};
 }
 
-// The action stream for a lane PAIR: inside a group of ticks whose words start on an 8-word boundary of the stream, the low
-// lane generates Philox block 2n and the high lane block 2n + 1 in the same instructions, and one exchange per word gives
-// both lanes all eight words -- half the Philox work per environment.  Outside such groups (ragged launch ends) every lane
-// generates whole blocks itself, like ActionStream.
-struct PairActionStream {
-    ActionStream solo;   // ungrouped ticks
-    uint32_t wl[4], wh[4]; // words of the even / odd block of the pair held
-    uint32_t rem;
-    __device__ __forceinline__ void init() { solo.init(); rem = 0; wl[0] = wl[1] = wl[2] = wl[3] = wh[0] = wh[1] = wh[2] = wh[3] = 0; }
-    __device__ __forceinline__ void gen_pair(const PhiloxRng &r, uint64_t pair, uint32_t h) {
-        ActionStream mine;
-        mine.init();
-        mine.gen(r, 2ull * pair + (uint64_t)h);
-        const Pair p0 = both_halves(mine.w0), p1 = both_halves(mine.w1), p2 = both_halves(mine.w2), p3 = both_halves(mine.w3);
-        wl[0] = p0.lo; wl[1] = p1.lo; wl[2] = p2.lo; wl[3] = p3.lo;
-        wh[0] = p0.hi; wh[1] = p1.hi; wh[2] = p2.hi; wh[3] = p3.hi;
-    }
-    uint32_t h_;
-    // word number `g` (compile-time) of the group that starts at stream index `base` (a multiple of 8)
-    __device__ __forceinline__ uint32_t word_in_group(const PhiloxRng &r, uint64_t base, int g) {
-        if ((g & 7) == 0) gen_pair(r, (base >> 3) + (uint64_t)(g >> 3), h_);
-        return ((g >> 2) & 1) ? wh[g & 3] : wl[g & 3];
-    }
-    __device__ __forceinline__ uint32_t word(const PhiloxRng &r, uint64_t index) { return solo.word(r, index); }
-};
-
 template <class S>
 struct Swar2 {
     static constexpr int A = S::kA, J = S::kJ, NI = S::kNI > 0 ? S::kNI : 1;
@@ -233,46 +207,55 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     uint32_t fc80 = 0, sc80 = 0;
     if (W::kBase && J > 0) {
         const uint32_t ja80 = (fix80 | sab80) & ~pend80;
-        uint32_t on[J], onany = 0, acted = 0, tog = 0;
+        uint32_t on[J], acted = 0, tog = 0, cntb = 0;
 #pragma unroll
         for (int j = 0; j < J; j++) {
             const uint32_t dj80 = (0u - ((w.jd >> (8 * j)) & 1u)) & k80;
             on[j] = zero80(w.xy ^ w.jb[j]) & ja80;
-            onany |= on[j];
+            cntb |= (uint32_t)__popc(on[j]) << (8 * j);
             const uint32_t succ = on[j] & ~(w.im80 ^ dj80);
             acted |= succ;
             tog |= (uint32_t)__popc(succ) << (8 * j);
         }
-        // the environment's toggles (0x01 per job: at most one of the two lanes holds the actor) and the actors of both words
-        const Pair pt = both_halves(tog), pn = both_halves(onany);
+        // the environment's toggles (0x01 per job: at most one of the two lanes holds the actor) and, per job, the actors of both words
+        const Pair pt = both_halves(tog), pn = both_halves(cntb);
         const uint32_t tog_env = pt.lo | pt.hi;
-        const uint32_t n_on = (uint32_t)__popc(pn.lo) + (uint32_t)__popc(pn.hi);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(n_on > 1u) != 0ull, 0)) {
-            // two agents on job cells in one env of this wave: every job in turn order over BOTH words (base.py:377-382)
+        const uint32_t crowd = ((pn.lo + pn.hi) + 0x7e7e7e7eu) & k80; // some job with two or more actors
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(crowd != 0u) != 0ull, 0)) {
+            // two agents work on the SAME job in one env of this wave: the actors in turn order over BOTH words (base.py:377-382);
+            // jobs are independent of each other, so the turns are the outer, ROLLED loop (rare code, kept small)
             const Pair pr = both_halves(R), pm = both_halves(w.im80);
             const uint32_t R2[2] = {pr.lo, pr.hi}, im2[2] = {pm.lo, pm.hi};
-            uint32_t f2[2] = {0, 0}, s2[2] = {0, 0};
+            uint32_t f2[2] = {0, 0}, s2[2] = {0, 0}, on2[J][2], dj[J];
 #pragma unroll
             for (int j = 0; j < J; j++) {
                 const Pair po = both_halves(on[j]);
-                const uint32_t on2[2] = {po.lo, po.hi};
-                uint32_t dj = (w.jd >> (8 * j)) & 1u;
-                for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
-                    const uint32_t tb = (turn | 0x80u) * k01;
+                on2[j][0] = po.lo;
+                on2[j][1] = po.hi;
+                dj[j] = (w.jd >> (8 * j)) & 1u;
+            }
+#pragma clang loop unroll(disable)
+            for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
+                const uint32_t tb = (turn | 0x80u) * k01;
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const uint32_t me = zero80(R2[q] ^ tb) & on2[q];
+                for (int q = 0; q < 2; q++) {
+                    const uint32_t mine = zero80(R2[q] ^ tb); // the agent whose turn it is
+#pragma unroll
+                    for (int j = 0; j < J; j++) {
+                        const uint32_t me = mine & on2[j][q];
                         const bool is_sab = (me & im2[q]) != 0u, is_fix = (me & ~im2[q]) != 0u;
-                        const bool f = is_fix && dj == 0u, sb = is_sab && dj != 0u;
-                        dj = f ? 1u : (sb ? 0u : dj);
+                        const bool f = is_fix && dj[j] == 0u, sb = is_sab && dj[j] != 0u;
+                        dj[j] = f ? 1u : (sb ? 0u : dj[j]);
                         e.m_fix += f ? 1u : 0u;
                         e.m_sab += sb ? 1u : 0u;
                         f2[q] |= f ? me : 0u;
                         s2[q] |= sb ? me : 0u;
                     }
                 }
-                w.jd = (w.jd & ~(1u << (8 * j))) | (dj << (8 * j));
             }
+            w.jd = 0;
+#pragma unroll
+            for (int j = 0; j < J; j++) w.jd |= dj[j] << (8 * j);
             fc80 = h ? f2[1] : f2[0];
             sc80 = h ? s2[1] : s2[0];
         } else {
