@@ -61,7 +61,27 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_one, todo))
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    verify(OUT)
     return OUT
+
+
+def verify(lib: str = OUT) -> None:
+    """The ISA checks a linked library must pass before it ships (sus-net_amd/isa_checks.py): no wide-store data hazard (the
+    gfx950 hazard BufDst::st128 works around: a toolchain update or a new call site must not bring it back silently), no
+    scratch traffic, the register budget of the benchmarked kernels.  A failing library is removed."""
+    if os.environ.get("SUSNET_SKIP_ISA_CHECKS") == "1":
+        return
+    try:
+        from . import isa_checks
+    except ImportError:  # run as a script
+        import isa_checks
+    if not isa_checks.tools_available():
+        raise RuntimeError("llvm-objdump / llvm-readelf / c++filt not found: cannot verify the gfx950 code objects "
+                           "(SUSNET_SKIP_ISA_CHECKS=1 builds without the check)")
+    _, problems = isa_checks.verify_library(lib)
+    if problems:
+        os.replace(lib, lib + ".rejected")
+        raise RuntimeError("libsusnet_hip.so failed the ISA checks (kept as " + lib + ".rejected):\n  " + "\n  ".join(problems))
 
 
 if __name__ == "__main__":

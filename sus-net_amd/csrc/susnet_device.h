@@ -213,6 +213,13 @@ struct HasGroupWords { static constexpr bool value = !S::kGeneric && S::kStaticA
 // word = out[cursor & 3].  Identical mapping in oracle/susnet_oracle.c (philox_word).
 // a ^ b ^ c in ONE instruction (v_bitop3_b32, truth table 0x96): a Philox round is two multiplies and two of these
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+// A wave-uniform value the compiler must treat as new at this point: the ten round keys of a Philox block (key + r * constant,
+// scalar registers) are then recomputed where a block is generated -- 18 scalar additions -- instead of being hoisted out of the
+// tick loop, where they held 18 SGPRs for the whole launch and pushed other values into spill lanes.
+__device__ __forceinline__ uint32_t fresh_scalar(uint32_t v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
 struct PhiloxRng {
     static constexpr bool kNumpy = false;
     uint32_t k0, k1, e0, e1;
@@ -228,7 +235,7 @@ struct PhiloxRng {
     }
     __device__ __forceinline__ void gen(uint64_t b) {
         uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32), c2 = e0, c3 = e1;
-        uint32_t a = k0, d = k1;
+        uint32_t a = fresh_scalar(k0), d = fresh_scalar(k1);
 #pragma unroll
         for (int r = 0; r < 10; r++) {
             uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -271,7 +278,7 @@ struct ActionStream {
     __device__ __forceinline__ void init() { blk = ~0ull; w0 = w1 = w2 = w3 = 0; rem = 0; }
     __device__ __forceinline__ void gen(const PhiloxRng &r, uint64_t b) {
         uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32) | kActionStreamTag, c2 = r.e0, c3 = r.e1;
-        uint32_t a = r.k0, d = r.k1;
+        uint32_t a = fresh_scalar(r.k0), d = fresh_scalar(r.k1);
 #pragma unroll
         for (int q = 0; q < 10; q++) {
             uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -355,7 +362,10 @@ constexpr uint32_t kTableWords = kRankLut2Word + 672;
 // a pointer derived from the `extern __shared__` symbol costs one `v_add_u32 v, <symbol>, v` per access.
 typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
 typedef const __attribute__((address_space(3))) float *lds_f32_ptr;
-__device__ __forceinline__ uint32_t lds_table_addr(uint32_t word) { return __builtin_amdgcn_groupstaticsize() + 4u * word; }
+// (No kernel that uses the tables declares static LDS, so the dynamic area starts at LDS address 0: written as a plain constant,
+// the table base folds into the ds_read's offset field; going through __builtin_amdgcn_groupstaticsize() left one
+// `v_add_u32 v, 0, v` per lookup in the code, the symbol being resolved only at link time.)
+__device__ __forceinline__ constexpr uint32_t lds_table_addr(uint32_t word) { return 4u * word; }
 constexpr uint32_t kMoveTableWord = 96, kRewardTableWord = 480; // (setup_lds)
 __device__ __forceinline__ uint32_t lds_move_lookup(uint32_t row_cell) { return *(lds_u8_ptr)(uintptr_t)(lds_table_addr(kMoveTableWord) + row_cell); }
 __device__ __forceinline__ float lds_reward_lookup(uint32_t byte_index) { return *(lds_f32_ptr)(uintptr_t)(lds_table_addr(kRewardTableWord) + byte_index); }

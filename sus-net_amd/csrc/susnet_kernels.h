@@ -558,6 +558,41 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     using GW = GroupWords<S::kAw.W, false>;
     GW gw;
     gw.init(kGroupWordsWord<S>(), tid);
+    // SOFTWARE PIPELINE (production stream): a tick's actions and turn ranks depend on nothing but the tick index and the
+    // episode's roles, so tick t + 1 is sampled while tick t steps -- the LDS round trips of the words, of the rank tables and of
+    // the step's own lookups overlap instead of queueing up behind one another (28 % of the wave's cycles were parked on
+    // s_waitcnt with the stages in sequence).  A reset at tick t changes the roles: the lanes that reset re-derive their
+    // actions and ranks of tick t + 1 from the same words inside the (rare) reset branch.
+#ifdef SUSNET_STAMPS
+    unsigned long long wseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wseg2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wprev = 0;
+#define KSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); wseg[k] += tn - wprev; wprev = tn; } while (0)
+#else
+#define KSTAMP(k) do {} while (0)
+#endif
+    uint32_t act_n[NW], R_n[NW];
+    TickWords<GW::W> tw_n;
+#pragma unroll
+    for (int q = 0; q < NW; q++) act_n[q] = R_n[q] = 0u;
+#pragma unroll
+    for (int k = 0; k < GW::W; k++) tw_n.wd[k] = 0u;
+    tw_n.rem = 0u;
+    auto sample_tick = [&](int tick, bool first) __attribute__((always_inline)) {
+        if constexpr (!RNG::kNumpy) {
+            const uint64_t gt = tick_base + (uint64_t)tick;
+            const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
+            if (first || pos == 0u) { // (wave-uniform)
+                gw.refill(rng, gt / (uint64_t)GW::G);
+                wave_lds_publish();
+            }
+#pragma unroll
+            for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
+            TickWords<GW::W> tw = tw_n;
+            sample_actions_swar<S, 0>(c, w, rng, tw, gt, act_n);
+            if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R_n);
+            else identity_ranks<S>(R_n);
+        }
+    };
+    if (!RNG::kNumpy && active && a.n_ticks > 0) sample_tick(0, true);
     auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) { // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index, nothing loop-carried
             const uint32_t t32 = (uint32_t)tick;
@@ -575,25 +610,24 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                     ranks_from_order<S>(ord, R);
                 }
             } else {
-                const uint64_t gt = tick_base + (uint64_t)tick;
-                const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
-                if (tick == 0 || pos == 0u) { // (wave-uniform)
-                    gw.refill(rng, gt / (uint64_t)GW::G);
-                    wave_lds_publish();
-                }
-                TickWords<GW::W> tw;
+#ifdef SUSNET_STAMPS
+                wprev = __builtin_readcyclecounter();
+#endif
 #pragma unroll
-                for (int k = 0; k < GW::W; k++) tw.wd[k] = gw.read(pos, k);
-                tw.rem = 0u;
-                sample_actions_swar<S, 0>(c, w, rng, tw, gt, act);
-                if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R);
-                else identity_ranks<S>(R);
+                for (int q = 0; q < NW; q++) { act[q] = act_n[q]; R[q] = R_n[q]; }
+                sample_tick(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
+                KSTAMP(0);
             }
             if (kTraj) store_packed_bytes<A>(da, act);
             else if (OUT == OUT_ANY && pa != nullptr) store_packed_bytes<A>(PtrDst{pa}, act);
             float rr[A];
             bool done, trunc;
+#ifdef SUSNET_STAMPS
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2);
+#else
             step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc);
+#endif
+            KSTAMP(1);
             if (kTraj) {
                 store_row_f32<A>(dr, rr);
                 dd.st8(0u, done ? 1u : 0u);
@@ -604,6 +638,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 if (pt != nullptr) *pt = trunc ? 1 : 0;
             }
             if (a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)swar_imp_bits(w);
+            KSTAMP(2);
             if (__builtin_expect(done || trunc, 0)) {
                 life.add_episode(e, trunc);
                 if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
@@ -613,10 +648,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 }
                 reset_env<S>(c, T, st, tid, e, rng);
                 to_swar<S>(c, st, e, w);
+                if constexpr (!RNG::kNumpy) { // new roles: the next tick's actions again, from the words already fetched -- and its
+                    // turn ranks, whose digits continue what the action draws (role-dependent ranges) left of their last word
+                    TickWords<GW::W> tw = tw_n;
+                    sample_actions_swar<S, 0>(c, w, rng, tw, 0ull, act_n);
+                    if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, 0ull, R_n);
+                }
                 // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed
                 if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
                 else zero_metrics(e);
             }
+            KSTAMP(3);
             if (OUT == OUT_TRAJ_RAW8) {
                 uint32_t row[(kRawF + 3) / 4];
                 raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
@@ -645,6 +687,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                     rec[A + q] = (uint32_t)by[4 * q] | ((uint32_t)by[4 * q + 1] << 8) | ((uint32_t)by[4 * q + 2] << 16) | ((uint32_t)by[4 * q + 3] << 24);
                 store_dwords<kRecDwords>(drec, rec);
             }
+            KSTAMP(4);
             if (OUT == OUT_ANY) {
                 pa = pa ? pa + AB : pa;
                 pr = pr ? pr + AB : pr;
@@ -659,6 +702,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     };
 #pragma clang loop unroll(disable)
     for (int tick = 0; tick < a.n_ticks; tick++) tick_body(tick);
+#ifdef SUSNET_STAMPS
+    if (blockIdx.x == 100 && tid == 0)
+        for (int k = 0; k < 8; k++) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 2 + k, wseg[k]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(s.err) + 10 + k, wseg2[k]);
+        }
+#endif
     if (active) {
         from_swar<S>(c, w, st, e);
         store_env<S>(c, s, st, b, e, true);
@@ -719,27 +769,38 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     using GW = GroupWords<S::kAw.W, true>;
     GW gw;
     gw.init(kGroupWordsWord<S>(), tid);
+    // SOFTWARE PIPELINE: tick t + 1 is sampled (words, action digits, turn ranks) while tick t steps; a reset re-derives the
+    // next tick's actions for the new roles from the words already fetched (see k_rollout_swar)
+    uint32_t act_n = 0u, R_n = 0u;
+    TickWords<GW::W> tw_n;
+#pragma unroll
+    for (int k = 0; k < GW::W; k++) tw_n.wd[k] = 0u;
+    tw_n.rem = 0u;
+    auto sample_tick = [&](int tick, bool first) __attribute__((always_inline)) {
+        const uint64_t gt = tick_base + (uint64_t)tick;
+        const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
+        if (first || pos == 0u) { // (wave-uniform)
+            gw.refill(rng, gt / (uint64_t)GW::G);
+            wave_lds_publish();
+        }
+#pragma unroll
+        for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
+        TickWords<GW::W> tw = tw_n;
+        uint32_t R2[2];
+        act_n = sample_actions_pair<S, 0>(w, rng, tw, gt);
+        if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R2);
+        else identity_ranks<S>(R2);
+        R_n = h ? R2[1] : R2[0];
+    };
+    if (a.n_ticks > 0) sample_tick(0, true);
     auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) {
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
         if (kRec) drec.so = (uint32_t)tick * slab_rec;
-        const uint64_t gt = tick_base + (uint64_t)tick;
-        const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
-        if (tick == 0 || pos == 0u) { // (wave-uniform)
-            gw.refill(rng, gt / (uint64_t)GW::G);
-            wave_lds_publish();
-        }
-        TickWords<GW::W> tw;
-#pragma unroll
-        for (int k = 0; k < GW::W; k++) tw.wd[k] = gw.read(pos, k);
-        tw.rem = 0u;
-        uint32_t R2[2];
-        const uint32_t act = sample_actions_pair<S, 0>(w, rng, tw, gt);
-        if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R2);
-        else identity_ranks<S>(R2);
-        const uint32_t R = h ? R2[1] : R2[0];
+        const uint32_t act = act_n, R = R_n;
+        sample_tick(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
         float rr[4];
         bool done, trunc;
         step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc);
@@ -767,6 +828,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             }
             reset_env<S>(c, T, st, tid, e, rng);
             to_swar2<S>(c, st, e, h, w);
+            { // new roles: the next tick's actions again, from the words already fetched -- and its turn ranks, whose digits
+                // continue what the action draws (role-dependent ranges) left of their last word
+                TickWords<GW::W> tw = tw_n;
+                act_n = sample_actions_pair<S, 0>(w, rng, tw, 0ull);
+                if constexpr (RankLut<S>::kOk) {
+                    uint32_t R2[2];
+                    ranks_from_lut<S, 0>(rng, tw, 0ull, R2);
+                    R_n = h ? R2[1] : R2[0];
+                }
+            }
             if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
             else zero_metrics(e);
         }

@@ -339,7 +339,14 @@ __device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, AS &as, uint64_t 
 // Rewards go to rr[] (float32: the compiled-in kernels are only selected when every reward constant is float-exact).
 template <class S, class RNG>
 __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar<S> &w, Env &e, RNG &rng, const uint32_t (&act)[Swar<S>::NW],
-                                          const uint32_t (&R)[Swar<S>::NW], float (&rr)[Swar<S>::A], bool &done, bool &trunc) {
+                                          const uint32_t (&R)[Swar<S>::NW], float (&rr)[Swar<S>::A], bool &done, bool &trunc,
+                                          unsigned long long *sg = nullptr) {
+#ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycles of the step's sections, one wave
+    unsigned long long sprev = __builtin_readcyclecounter();
+#define WSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); if (sg) sg[k] += tn - sprev; sprev = tn; } while (0)
+#else
+#define WSTAMP(k) do {} while (0)
+#endif
     using W = Swar<S>;
     constexpr int A = W::A, J = W::J, NW = W::NW, NI = W::NI;
     constexpr uint32_t kLive[2] = {A >= 4 ? 0xffffffffu : (1u << (8 * (A & 3))) - 1u, A >= 8 ? 0xffffffffu : (A > 4 ? (1u << (8 * (A & 3))) - 1u : 0u)};
@@ -395,6 +402,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 #pragma unroll
     for (int q = 0; q < NW; q++) newt[q] = sel_bytes(ff_from80(mv80[q]), dest[q], w.xy[q]);
 
+    WSTAMP(0);
     // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
     uint32_t kc80[NW], pend80[NW]; // killers that landed a kill; victims killed before their own turn
     uint32_t vk80[NI][NW], gek80[NI][NW]; // per kill turn: the victim; the agents that had not acted yet (tagging only)
@@ -470,6 +478,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 #pragma unroll
     for (int q = 0; q < NW; q++) w.xy[q] = sel_bytes(ff_from80(pend80[q]), w.xy[q], newt[q]);
 
+    WSTAMP(1);
     // ---- FIX (base.py:518-524) / SABOTAGE (527-533): first job on the agent's own cell (544-546; job cells are distinct) ------
     // Evaluated for all jobs without a branch per job, in AGENT space: on[j] = the actors standing on job j; an actor succeeds
     // when the job's status is the one its role changes (crew: open, imposter: completed) -- one 3-input bit operation per word
@@ -549,6 +558,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         }
     }
 
+    WSTAMP(2);
     // ---- tag actions (tagging.py:103-110) and the vote (tagging.py:180-207) ------------------------------------------------------
     float team = 0.0f; // team reward: vote outcome, then the win reward (tagging.py:196, 209-213)
     if (W::kTag) {
@@ -621,6 +631,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         }
     }
 
+    WSTAMP(3);
     // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
     uint32_t wsel; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
     {
@@ -680,6 +691,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             rr[i] = __uint_as_float((__float_as_uint(r) & live) | (dead_bits & ~live)); // base.py:562
         }
     }
+    WSTAMP(4);
     // base.py:392-395: t saturates at max_time_steps - 1
     trunc = false;
     if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;

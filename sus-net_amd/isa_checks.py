@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Register / spill / code-size table of every kernel in the shipped gfx950 code objects.
+"""Checks on the SHIPPED gfx950 code objects (the ISA inside libsusnet_hip.so), run by build_hip.build() after every link
+and by tests/test_capi_abi.py:
 
-    python tools/kernel_resources.py [--match SUBSTR] [--json OUT] [--md OUT]
+  * store_data_hazards(): no vector write into the data registers of a > 64-bit store within two wait states (a gfx950
+    hazard the compiler only guards when the store's scalar-offset field is a constant: see BufDst::st128);
+  * scratch_instructions(): no scratch (private memory) traffic;
+  * collect(): per kernel the ELF notes (`llvm-readelf --notes`: vgpr / agpr / sgpr counts, spill counts, private segment,
+    static LDS) and disassembly statistics (`llvm-objdump -d`: static instruction count; `v_readlane` / `v_writelane` = SGPR
+    spills to vector lanes, `v_accvgpr_*` = VGPR spills to accumulation registers, `scratch_*` = memory);
+  * check_limits(): the register budget of the kernels bench.py times (HEADLINE_LIMITS).
 
-Reads the ELF notes (`llvm-readelf --notes`: vgpr / agpr / sgpr counts, spill counts, private segment, LDS) and the
-disassembly (`llvm-objdump -d`: static instruction count and the moves register pressure costs -- `v_readlane` /
-`v_writelane` = SGPR spills to vector lanes, `v_accvgpr_*` = VGPR spills to accumulation registers, `scratch_*` = memory)
-of the gfx950 code objects embedded in sus-net_amd/libsusnet_hip.so.  Used by build_hip.py (hazard scan), by
-tests/test_capi_abi.py (the limits the headline kernels must keep) and to write profiles/rNN_kernel_resources.md.
+    python sus-net_amd/isa_checks.py [--match SUBSTR] [--json OUT] [--md OUT]      prints the table
 """
 from __future__ import annotations
 
@@ -20,9 +23,9 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LLVM = "/opt/rocm/lib/llvm/bin"
-LIB = os.path.join(ROOT, "sus-net_amd", "libsusnet_hip.so")
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LLVM = os.environ.get("SUSNET_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+LIB = os.path.join(PKG_DIR, "libsusnet_hip.so")
 
 
 CXXFILT = shutil.which("c++filt") or os.path.join(LLVM, "llvm-cxxfilt")
@@ -93,7 +96,7 @@ def parse_notes(obj: str):
 
 def parse_disasm(obj: str):
     """mangled kernel name -> static instruction statistics"""
-    asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", obj], capture_output=True, text=True, check=True).stdout
+    asm = disassemble(obj)
     stats, cur = {}, None
     for ln in asm.splitlines():
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", ln)
@@ -135,6 +138,110 @@ def parse_disasm(obj: str):
         if op.startswith(("s_cbranch", "s_branch")):
             cur["branch"] += 1
     return stats
+
+
+def disassemble(obj: str) -> str:
+    return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", obj], capture_output=True, text=True, check=True).stdout
+
+
+def _vgprs(operand):
+    """'v12' -> {12}, 'v[4:7]' -> {4..7}, anything else -> empty."""
+    m = re.fullmatch(r"v(\d+)", operand)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def store_data_hazards(asm, window=2):
+    """Vector writes to the data registers of a > 64-bit store within `window` wait states after it.
+
+    The store reads its data over several cycles; gfx950 needs two wait states before a VALU instruction may overwrite
+    them (measured: record dwords of lanes 12-15 / 28-31 carried the next tick's values).  The compiler inserts the
+    `s_nop` only when the store's scalar-offset field is a constant, which is why BufDst::st128 keeps it 0.
+    Validated against: AMD clang 22.0.0git (ROCm 7.2.0)."""
+    lines = []
+    for ln in asm.splitlines():
+        ln = ln.split("//")[0].strip()
+        if ln and not ln.endswith(":") and not ln.startswith((".", ";", "/")):
+            lines.append(ln)
+    # data operand: first for buffer stores, second (after the address) for global / flat stores
+    wide = re.compile(r"^(?:buffer_store_(?:dwordx[34]|format_xyzw?)\s+|(?:global|flat)_store_dwordx[34]\s+[^,]+,\s*)(v\[\d+:\d+\])")
+    bad = []
+    for i, ln in enumerate(lines):
+        m = wide.match(ln)
+        if not m:
+            continue
+        data = _vgprs(m.group(1))
+        waited = 0
+        for nxt in lines[i + 1 : i + 1 + window]:
+            if waited >= window or nxt.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")):
+                break
+            mn = re.match(r"^s_nop\s+(\d+)", nxt)
+            if mn:
+                waited += int(mn.group(1)) + 1
+                continue
+            if nxt.startswith("v_"):
+                ops = nxt.split(None, 1)[1].split(",") if " " in nxt else []
+                if ops and _vgprs(ops[0].strip()) & data:
+                    bad.append((ln, nxt))
+            waited += 1
+    return bad
+
+
+def scratch_instructions(asm):
+    return [ln.strip() for ln in asm.splitlines() if re.search(r"\bscratch_", ln.split("//")[0])]
+
+
+# The kernels bench.py's lines are made of (fused rollout, packed record).  VERDICT r02 item 1: at most 16 spilled SGPRs, no
+# accumulation registers, no spilled VGPRs; and small enough for the instruction cache (64 KB per pair of CUs).
+HEADLINE_KERNELS = ("k_rollout_duel<PhiloxRng, 4>", "k_rollout_swar<Spec<3, 4, 0, 1, -1, 1>, 4, PhiloxRng>",
+                    "k_rollout_swar2<Spec<8, 4, 0, 1, -1, 2>, 4>", "k_rollout_swar<Spec<5, 5, 2, 1, -1, 1>, 4, PhiloxRng>")
+HEADLINE_LIMITS = dict(sgpr_spill=16, agpr=0, vgpr_spill=0, v_accvgpr=0, scratch=0, code_bytes=48 * 1024)
+
+
+def check_limits(rows):
+    """-> list of violations of HEADLINE_LIMITS among HEADLINE_KERNELS (also: a headline kernel that is missing)."""
+    by = {r["name"]: r for r in rows}
+    bad = []
+    for k in HEADLINE_KERNELS:
+        if k not in by:
+            bad.append(f"{k}: not in the library")
+            continue
+        for key, lim in HEADLINE_LIMITS.items():
+            if by[k].get(key, 0) > lim:
+                bad.append(f"{k}: {key} = {by[k].get(key)} > {lim}")
+    # the LDS tables are addressed from 0 (lds_table_addr): no kernel that uses them may declare static LDS
+    for r in rows:
+        if r.get("lds_static", 0) != 0 and not r["name"].startswith("k_reduce_lifetime"):
+            bad.append(f"{r['name']}: static LDS ({r['lds_static']} B) under the dynamic table area")
+    return bad
+
+
+def verify_library(lib: str = LIB):
+    """Everything build_hip.build() requires of a freshly linked library; returns (rows, problems)."""
+    problems, rows = [], []
+    with tempfile.TemporaryDirectory() as wd:
+        objs = code_objects(lib, wd)
+        if not objs:
+            problems.append("no gfx950 code object in the library")
+        stores = 0
+        for obj in objs:
+            asm = disassemble(obj)
+            stores += asm.count("_store_dwordx4")
+            hz = store_data_hazards(asm)
+            if hz:
+                problems.append(f"{os.path.basename(obj)}: {len(hz)} wide-store data hazards, e.g. {hz[:2]}")
+            sc = scratch_instructions(asm)
+            if sc:
+                problems.append(f"{os.path.basename(obj)}: {len(sc)} scratch instructions, e.g. {sc[:2]}")
+        if objs and stores < 100:
+            problems.append("disassembly looks empty")
+    rows = collect(lib)
+    problems += check_limits(rows)
+    return rows, problems
 
 
 def collect(lib: str = LIB):
@@ -187,6 +294,9 @@ def main():
         json.dump(rows, open(args.json, "w"), indent=1)
     if args.md:
         open(args.md, "w").write(table(rows, md=True) + "\n")
+    bad = check_limits(collect(args.lib))
+    if bad:
+        sys.exit("limits violated:\n  " + "\n  ".join(bad))
 
 
 if __name__ == "__main__":

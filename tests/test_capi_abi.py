@@ -164,106 +164,70 @@ def test_obs_sizes_follow_the_reference_featurizers(pkg):
     lib.susnet_destroy(h)
 
 
-def test_device_code_has_no_scratch_memory_traffic(pkg, tmp_path):
-    """Per-lane arrays indexed at run time get demoted to scratch (private) memory: slow, and every scratch load
-    carries an `s_waitcnt vmcnt(0)` that also waits for all outstanding trajectory stores.  The hot kernels keep
-    such tables in packed VGPR words or LDS instead; this pins it on the shipped gfx950 code object."""
-    import shutil
-
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("llvm-objdump not available")
-    so = tmp_path / "libsusnet_hip.so"
-    shutil.copy(pkg._lib.LIB_PATH, so)
-    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
-    assert len(objs) >= 1, "expected gfx950 code objects in the library (one per translation unit)"
-    muls = 0
-    for obj in objs:
-        asm = subprocess.run([objdump, "-d", str(obj)], check=True, capture_output=True, text=True).stdout
-        muls += asm.count("v_mad_u64_u32")
-        scratch = [ln for ln in asm.splitlines() if "scratch_" in ln]
-        assert not scratch, f"{obj.name}: {len(scratch)} scratch instructions, e.g. {scratch[:3]}"
-    assert muls > 1000, "disassembly looks empty"
+@pytest.fixture(scope="module")
+def isa(pkg):
+    """sus-net_amd/isa_checks.py on the shipped library.  The LLVM tools ship with hipcc: where the library could be built
+    they are there, and their absence fails the checks instead of skipping them."""
+    mod = importlib.import_module("sus-net_amd.isa_checks")
+    assert mod.tools_available(), "llvm-objdump / llvm-readelf / c++filt not found next to hipcc"
+    return mod
 
 
-def _vgprs(operand):
-    """'v12' -> {12}, 'v[4:7]' -> {4..7}, anything else -> empty."""
-    import re
-
-    m = re.fullmatch(r"v(\d+)", operand)
-    if m:
-        return {int(m.group(1))}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    return set()
+@pytest.fixture(scope="module")
+def shipped(pkg, isa):
+    """(per-kernel rows, problems) of the shipped library: disassembled once for the module"""
+    return isa.verify_library(pkg._lib.LIB_PATH)
 
 
-def store_data_hazards(asm, window=2):
-    """Vector writes to the data registers of a > 64-bit store within `window` wait states after it.
-
-    The store reads its data over several cycles; gfx950 needs two wait states before a VALU instruction may overwrite
-    them (measured: record dwords of lanes 12-15 / 28-31 carried the next tick's values).  The compiler inserts the
-    `s_nop` only when the store's scalar-offset field is a constant, which is why BufDst::st128 keeps it 0."""
-    import re
-
-    lines = []
-    for ln in asm.splitlines():
-        ln = ln.split("//")[0].strip()
-        if ln and not ln.endswith(":") and not ln.startswith((".", ";", "/")):
-            lines.append(ln)
-    # data operand: first for buffer stores, second (after the address) for global / flat stores
-    wide = re.compile(r"^(?:buffer_store_(?:dwordx[34]|format_xyzw?)\s+|(?:global|flat)_store_dwordx[34]\s+[^,]+,\s*)(v\[\d+:\d+\])")
-    bad = []
-    for i, ln in enumerate(lines):
-        m = wide.match(ln)
-        if not m:
-            continue
-        data = _vgprs(m.group(1))
-        waited = 0
-        for nxt in lines[i + 1 : i + 1 + window]:
-            if waited >= window or nxt.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")):
-                break
-            mn = re.match(r"^s_nop\s+(\d+)", nxt)
-            if mn:
-                waited += int(mn.group(1)) + 1
-                continue
-            if nxt.startswith("v_"):
-                ops = nxt.split(None, 1)[1].split(",") if " " in nxt else []
-                if ops and _vgprs(ops[0].strip()) & data:
-                    bad.append((ln, nxt))
-            waited += 1
-    return bad
+def test_shipped_library_passes_the_build_time_isa_checks(shipped):
+    """What build_hip.build() enforces after every link: no scratch traffic (per-lane arrays indexed at run time get demoted to
+    private memory: slow, and every scratch load carries an `s_waitcnt vmcnt(0)` that also waits for all outstanding trajectory
+    stores), no vector write into a wide store's data registers within two wait states, the register budget of the
+    benchmarked kernels, no static LDS under the table area."""
+    rows, problems = shipped
+    assert not problems, problems
+    assert len(rows) > 50 and sum(r.get("valu", 0) for r in rows) > 100000, "disassembly looks empty"
 
 
-def test_store_data_hazard_checker_flags_the_measured_case():
+def test_headline_kernels_keep_their_register_budget(isa, shipped):
+    """the four packed-record rollout kernels bench.py times spill at most 16 SGPRs, use no accumulation
+    registers, no `v_accvgpr` / scratch moves, and fit the instruction cache (the round-2 kernels unrolled whole tick groups:
+    36 000 instructions, 255 spilled SGPRs, 256 VGPRs + 73 AGPRs)."""
+    rows = {r["name"]: r for r in shipped[0]}
+    for k in isa.HEADLINE_KERNELS:
+        r = rows[k]
+        assert r["sgpr_spill"] <= 16 and r["agpr"] == 0 and r["vgpr_spill"] == 0 and r["v_accvgpr"] == 0 and r["scratch"] == 0, (k, r)
+        assert r["v_readlane"] + r["v_writelane"] <= 2 * 16, (k, r)  # spill moves: one write + (at most a few) reads per spilled SGPR
+        assert r["instructions"] < 6000 and r["code_bytes"] < 48 * 1024, (k, r)
+    # a deliberately broken budget is reported
+    worse = [dict(r, sgpr_spill=17) if r["name"] == isa.HEADLINE_KERNELS[0] else r for r in rows.values()]
+    assert any("sgpr_spill" in p for p in isa.check_limits(worse))
+
+
+def test_store_data_hazard_checker_flags_the_measured_case(isa):
     asm = "\n".join(
         [
             "\tbuffer_store_dwordx4 v[178:181], v91, s[76:79], s6 offen   // 0001: E07C1000",
             "\tv_alignbit_b32 v179, v53, v52, 24   // 0002: D1CE00B3",
         ]
     )
-    assert len(store_data_hazards(asm)) == 1
+    assert len(isa.store_data_hazards(asm)) == 1
     ok = asm.replace("\tv_alignbit", "\ts_nop 1\n\tv_alignbit")
-    assert store_data_hazards(ok) == []
-    assert store_data_hazards("global_store_dwordx4 v[2:3], v[4:7], off\nv_lshl_add_u64 v[2:3], v[2:3], 0, s[16:17]") == []
-    assert len(store_data_hazards("global_store_dwordx4 v[2:3], v[4:7], off\nv_mov_b32_e32 v7, 0")) == 1
+    assert isa.store_data_hazards(ok) == []
+    assert isa.store_data_hazards("global_store_dwordx4 v[2:3], v[4:7], off\nv_lshl_add_u64 v[2:3], v[2:3], 0, s[16:17]") == []
+    assert len(isa.store_data_hazards("global_store_dwordx4 v[2:3], v[4:7], off\nv_mov_b32_e32 v7, 0")) == 1
+    assert isa.scratch_instructions("\tscratch_load_dword v1, off, s32\n\tv_mov_b32 v0, v1") == ["scratch_load_dword v1, off, s32"]
 
 
-def test_device_code_never_overwrites_wide_store_data_too_early(pkg, tmp_path):
+def test_build_rejects_a_library_that_fails_the_isa_checks(pkg, isa, tmp_path, monkeypatch):
+    """build_hip.verify(): a library with a problem is moved aside and the build raises."""
     import shutil
 
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("llvm-objdump not available")
-    so = tmp_path / "libsusnet_hip.so"
-    shutil.copy(pkg._lib.LIB_PATH, so)
-    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    stores = 0
-    for obj in [p for p in tmp_path.iterdir() if "gfx950" in p.name]:
-        asm = subprocess.run([objdump, "-d", str(obj)], check=True, capture_output=True, text=True).stdout
-        stores += asm.count("_store_dwordx4")
-        bad = store_data_hazards(asm)
-        assert not bad, f"{obj.name}: {len(bad)} wide-store data hazards, e.g. {bad[:3]}"
-    assert stores > 100, "disassembly looks empty"
+    lib = tmp_path / "libsusnet_hip.so"
+    shutil.copy(pkg._lib.LIB_PATH, lib)
+    pkg.build_hip.verify(str(lib))  # the shipped library passes
+    assert lib.exists()
+    monkeypatch.setattr(isa, "HEADLINE_LIMITS", dict(isa.HEADLINE_LIMITS, code_bytes=1024))
+    with pytest.raises(RuntimeError, match="failed the ISA checks"):
+        pkg.build_hip.verify(str(lib))
+    assert not lib.exists() and (tmp_path / "libsusnet_hip.so.rejected").exists()
