@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SUSNET_ABI_VERSION 2
+#define SUSNET_ABI_VERSION 3
 
 #define SUSNET_MAX_AGENTS 16
 #define SUSNET_MAX_JOBS 16
@@ -160,7 +160,18 @@ typedef struct susnet_layout {
     int32_t n_actions_crew;
     int32_t action_space_n;   /* Discrete(n) of the reference (8, or 8 + A with tagging) */
     int32_t obs_raw_size;     /* flattened_state_size (base.py:230-232) */
+    int32_t envs_per_wave;    /* environments a wavefront of the fused rollout serves (64, 32 or 16, by batch size) */
+    uint32_t test_overrides;  /* SUSNET_OVERRIDE_* bits: which test hooks were found in the environment at susnet_create */
 } susnet_layout;
+
+/* Test hooks.  Three environment variables change how a handle launches its kernels (never what it computes); they are read
+ * ONCE, in susnet_create, recorded in susnet_layout.test_overrides, and named in susnet_last_error() messages of that handle:
+ *   SUSNET_FORCE_GENERIC=1      every configuration runs the generic (LDS-table) kernels, none of the compiled-in ones
+ *   SUSNET_EPW=16|32|64         environments per wave of the fused rollout
+ *   SUSNET_TRAJ_MAX_BYTES=n     default of susnet_set_launch_limit() */
+#define SUSNET_OVERRIDE_FORCE_GENERIC 1u
+#define SUSNET_OVERRIDE_EPW 2u
+#define SUSNET_OVERRIDE_TRAJ_MAX_BYTES 4u
 
 typedef struct susnet_obs_spec {
     int32_t mode;                 /* SUSNET_OBS_* */
@@ -242,6 +253,11 @@ typedef struct susnet_record_layout_t {
     int32_t off_rewards, off_actions, off_done, off_truncated, off_obs;
 } susnet_record_layout_t;
 int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out);
+
+/* The trajectory modes of susnet_rollout address every output array with 32-bit offsets: one launch covers at most as many ticks
+ * as keep each array below `bytes` (default and maximum 2^31 - 1); longer requests run as consecutive launches.  bytes = 0
+ * restores the default.  (No reference counterpart: launch plumbing.) */
+int susnet_set_launch_limit(susnet_env *env, uint64_t bytes);
 
 /* Reference-layout views of the state (export / import). NULL pointers are skipped. */
 typedef struct susnet_state_view {

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libsusnet_hip.so"
 LIB_PATH = os.environ.get("SUSNET_LIB_PATH", os.path.join(PKG_DIR, LIB_NAME))  # override: A/B experiments only
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_AGENTS, MAX_JOBS, MAX_GRID, N_METRICS, N_LIFETIME = 16, 16, 16, 13, 12
 
 VARIANT_BASE, VARIANT_ITG, VARIANT_TAGGING = 0, 1, 2
@@ -31,7 +31,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
     "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_step",
-    "susnet_rollout", "susnet_record_layout", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
+    "susnet_rollout", "susnet_record_layout", "susnet_set_launch_limit", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append", "susnet_scent",
 ]
 
@@ -54,7 +54,7 @@ class Layout(C.Structure):
     _fields_ = [
         ("state_bytes", C.c_uint64), ("state_align", C.c_uint64), ("batch_padded", C.c_int32), ("n_agents", C.c_int32),
         ("n_actions_imposter", C.c_int32), ("n_actions_crew", C.c_int32), ("action_space_n", C.c_int32),
-        ("obs_raw_size", C.c_int32),
+        ("obs_raw_size", C.c_int32), ("envs_per_wave", C.c_int32), ("test_overrides", C.c_uint32),
     ]
 
 
@@ -160,6 +160,7 @@ def lib():
     L.susnet_step.argtypes = [C.c_void_p, P(StepIO), C.c_void_p]
     L.susnet_rollout.argtypes = [C.c_void_p, P(RolloutIO), C.c_void_p]
     L.susnet_record_layout.argtypes = [C.c_void_p, P(RecordLayout)]
+    L.susnet_set_launch_limit.argtypes = [C.c_void_p, C.c_uint64]
     L.susnet_observe.argtypes = [C.c_void_p, P(ObsSpec), C.c_void_p]
     L.susnet_obs_size.argtypes = [C.c_void_p, P(ObsSpec), P(C.c_int32), P(C.c_int32)]
     L.susnet_featurize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, P(ObsSpec), C.c_void_p]

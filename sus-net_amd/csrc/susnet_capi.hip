@@ -186,10 +186,9 @@ __global__ __launch_bounds__(kBlock) void k_featurize(Consts c, const void *rows
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
 
-static int pick_spec(const Consts &c, bool float_exact) {
+static int pick_spec(const Consts &c, bool float_exact, bool force_generic) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
-    if (const char *ev = getenv("SUSNET_FORCE_GENERIC")) // tests: the same fixtures through the generic LDS-table kernels
-        if (ev[0] == '1') return 0;
+    if (force_generic) return 0; // (tests: the same fixtures through the generic LDS-table kernels)
     if (c.A == 2 && c.J == 0 && c.variant == SUSNET_VARIANT_ITG && !c.order_random && !c.shuffle_imp && c.n_imp == 1) return 2;
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 1) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 2) return 4;
@@ -309,6 +308,10 @@ struct susnet_env {
     bool bound = false;
     bool float_exact = false;
     uint64_t ticks = 0; // steps taken (index of the production action stream)
+    // test hooks, read ONCE at susnet_create (include/susnet.h SUSNET_OVERRIDE_*)
+    bool force_generic = false;
+    uint64_t launch_limit = (1ull << 31) - 1u, launch_limit_default = (1ull << 31) - 1u;
+    int spec = 0; // pick_spec(): which compiled-in kernel family serves the handle (0 = generic)
     susnet_layout layout;
     uint64_t off_err, off_agent, off_job, off_jobdone, off_t, off_timer, off_flags, off_rng, off_msteps, off_mfix, off_msab,
         off_mkv, off_life, off_tickw;
@@ -318,6 +321,18 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
+}
+// (messages about a handle created under test hooks say so: a stray environment variable is then visible where it bites)
+static int fail(const susnet_env *env, int code, const std::string &msg) {
+    std::string m = msg;
+    if (env && env->layout.test_overrides) {
+        m += " [handle created with";
+        if (env->layout.test_overrides & SUSNET_OVERRIDE_FORCE_GENERIC) m += " SUSNET_FORCE_GENERIC";
+        if (env->layout.test_overrides & SUSNET_OVERRIDE_EPW) m += " SUSNET_EPW";
+        if (env->layout.test_overrides & SUSNET_OVERRIDE_TRAJ_MAX_BYTES) m += " SUSNET_TRAJ_MAX_BYTES";
+        m += "]";
+    }
+    return fail(code, m);
 }
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -375,9 +390,16 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     // environments per wave in the fused rollout: fewer than 64 when the batch would otherwise leave SIMDs
     // idle (an MI355X has 1024 SIMDs; below one wave per SIMD the kernel is purely latency-bound)
     c.epw = cfg->batch >= 65536 ? 64 : cfg->batch >= 32768 ? 32 : 16;
+    uint32_t overrides = 0;
     if (const char *ev = getenv("SUSNET_EPW")) {
         int v = atoi(ev);
-        if (v == 16 || v == 32 || v == 64) c.epw = v;
+        if (v == 16 || v == 32 || v == 64) { c.epw = v; overrides |= SUSNET_OVERRIDE_EPW; }
+    }
+    if (const char *ev = getenv("SUSNET_FORCE_GENERIC"))
+        if (ev[0] == '1') { e->force_generic = true; overrides |= SUSNET_OVERRIDE_FORCE_GENERIC; }
+    if (const char *ev = getenv("SUSNET_TRAJ_MAX_BYTES")) {
+        const long long v = atoll(ev);
+        if (v > 0 && (uint64_t)v < e->launch_limit) { e->launch_limit = e->launch_limit_default = (uint64_t)v; overrides |= SUSNET_OVERRIDE_TRAJ_MAX_BYTES; }
     }
     c.nr_imp = cfg->variant == SUSNET_VARIANT_ITG ? 6 : 7;  // pred_prey.py:12-19 / base.py:91-99
     c.nr_crew = cfg->variant == SUSNET_VARIANT_ITG ? 5 : 6; // pred_prey.py:4-10  / base.py:82-89
@@ -482,6 +504,9 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     L.n_actions_crew = c.nr_crew + tag_extra;
     L.action_space_n = 8 + (cfg->variant == SUSNET_VARIANT_TAGGING ? A : 0);
     L.obs_raw_size = 3 * A + (cfg->variant == SUSNET_VARIANT_TAGGING ? 3 * J + 2 * A + 1 : (J > 0 ? 3 * J : 0));
+    L.envs_per_wave = c.epw;
+    L.test_overrides = overrides;
+    e->spec = pick_spec(c, e->float_exact, e->force_generic);
     *out = e;
     return SUSNET_OK;
 }
@@ -695,7 +720,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     // the compiled-in kernels also serve TAPE handles (numpy parity mode): the reference's golden traces run through the
     // same code the production stream uses
     const bool tape = env->cfg.rng_mode == SUSNET_RNG_TAPE;
-    const int spec = pick_spec(env->c, env->float_exact);
+    const int spec = env->spec;
     size_t sh = lds_bytes(env, o, env->c.auto_reset != 0, spec);
     CHECK_LDS(sh);
     const dim3 g = grid_for(env), blk(kBlock);
@@ -721,7 +746,7 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
 extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out) {
     if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
-    const int spec = env->cfg.rng_mode == SUSNET_RNG_PHILOX ? pick_spec(env->c, env->float_exact) : 0;
+    const int spec = env->spec; // (TAPE handles too: the reference's numpy streams run through the same kernels)
     if (spec != 2 && spec != 3 && spec != 4 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode
     const int A = env->c.A, F = env->layout.obs_raw_size;
     out->off_rewards = 0;
@@ -742,6 +767,13 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
     return SUSNET_OK;
 }
 
+extern "C" int susnet_set_launch_limit(susnet_env *env, uint64_t bytes) {
+    if (!env) return fail(SUSNET_E_INVALID, "null handle");
+    if (bytes > (1ull << 31) - 1u) return fail(SUSNET_E_INVALID, "susnet_set_launch_limit: at most 2^31 - 1 bytes (32-bit buffer offsets)");
+    env->launch_limit = bytes ? bytes : env->launch_limit_default;
+    return SUSNET_OK;
+}
+
 extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream) {
     if (int rc = check_bound(env)) return rc;
     if (!io || io->n_ticks < 1) return fail(SUSNET_E_INVALID, "n_ticks must be >= 1");
@@ -759,14 +791,13 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     a.roles = io->roles;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;
-    const int spec = pick_spec(env->c, env->float_exact);
-    if (a.record && tape) return fail(SUSNET_E_INVALID, "susnet_rollout: no packed record on a TAPE handle");
+    const int spec = env->spec;
     if (a.record) {
         if (a.actions || a.rewards || a.done || a.trunc || o.mode != SUSNET_OBS_NONE)
-            return fail(SUSNET_E_INVALID, "susnet_rollout: record is an alternative to the separate outputs, not an addition");
+            return fail(env, SUSNET_E_INVALID, "susnet_rollout: record is an alternative to the separate outputs, not an addition");
         susnet_record_layout_t lay;
         susnet_record_layout(env, &lay);
-        if (lay.record_bytes == 0) return fail(SUSNET_E_INVALID, "susnet_rollout: this configuration has no packed record mode");
+        if (lay.record_bytes == 0) return fail(env, SUSNET_E_INVALID, "susnet_rollout: this configuration has no packed record mode");
         if ((uintptr_t)a.record % 16) return fail(SUSNET_E_INVALID, "record buffer must be 16-byte aligned");
         a.record_bytes = lay.record_bytes;
     }
@@ -782,22 +813,19 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool traj_noobs = all_traj && o.mode == SUSNET_OBS_NONE;
     const uint64_t AB = (uint64_t)env->c.A * (uint64_t)env->c.B;
     const uint64_t tick_bytes = a.record ? (uint64_t)env->c.B * (uint64_t)a.record_bytes : std::max<uint64_t>(4u * AB, (uint64_t)o.tick_stride);
-    uint64_t limit = (1ull << 31) - 1u;
-    if (const char *ev = getenv("SUSNET_TRAJ_MAX_BYTES")) { // tests: exercise the chunking on small batches
-        const long long v = atoll(ev);
-        if (v > 0 && (uint64_t)v < limit) limit = (uint64_t)v;
-    }
+    const uint64_t limit = env->launch_limit; // (susnet_set_launch_limit; tests exercise the chunking on small batches)
     const uint64_t fit = limit / tick_bytes;
-    if (a.record && fit < 1) return fail(SUSNET_E_INVALID, "susnet_rollout: one tick of records exceeds 2 GiB");
+    if (a.record && fit < 1) return fail(env, SUSNET_E_INVALID, "susnet_rollout: one tick of records exceeds 2 GiB");
     const int out = a.record                                ? OUT_RECORD
                     : (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
                     : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
                                                             : OUT_ANY;
     if ((a.term_obs || a.roles) && !(all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8))
-        return fail(SUSNET_E_INVALID, "susnet_rollout: term_obs / roles go with the full trajectory and the raw uint8 observation");
-    if (tape && out != OUT_TRAJ_RAW8)
-        return fail(SUSNET_E_INVALID, "susnet_rollout on a TAPE handle stores the full trajectory with the raw uint8 observation (nothing else)");
+        return fail(env, SUSNET_E_INVALID, "susnet_rollout: term_obs / roles go with the full trajectory and the raw uint8 observation");
+    if (tape && out != OUT_TRAJ_RAW8 && out != OUT_RECORD)
+        return fail(env, SUSNET_E_INVALID, "susnet_rollout on a TAPE handle stores the full trajectory with the raw uint8 observation, as separate "
+                                      "tensors or as packed records (nothing else)");
     const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);

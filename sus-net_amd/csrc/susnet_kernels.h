@@ -719,11 +719,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
 }
 
 // Fused random rollout with TWO lanes per environment (susnet_swar2.h): 8-agent configurations at 32 envs per wave.  Same contract
-// as k_rollout_swar for the modes OUT_NONE / OUT_TRAJ / OUT_TRAJ_RAW8 / OUT_RECORD on the production stream.
-template <class S, int OUT>
+// as k_rollout_swar for the modes OUT_NONE / OUT_TRAJ / OUT_TRAJ_RAW8 / OUT_RECORD; RNG = the production stream, or
+// caller-supplied words (numpy parity: both lanes of a pair walk the environment's tape identically and keep their own half).
+template <class S, int OUT, class RNG = PhiloxRng>
 __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, RolloutArgs a, ObsArgs o) {
     using W = Swar2<S>;
-    using RNG = PhiloxRng;
     constexpr int A = W::A;
     static_assert(A == 8, "two words of four agents");
     extern __shared__ uint32_t smem[];
@@ -777,30 +777,48 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     for (int k = 0; k < GW::W; k++) tw_n.wd[k] = 0u;
     tw_n.rem = 0u;
     auto sample_tick = [&](int tick, bool first) __attribute__((always_inline)) {
-        const uint64_t gt = tick_base + (uint64_t)tick;
-        const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
-        if (first || pos == 0u) { // (wave-uniform)
-            gw.refill(rng, gt / (uint64_t)GW::G);
-            wave_lds_publish();
-        }
+        if constexpr (!RNG::kNumpy) {
+            const uint64_t gt = tick_base + (uint64_t)tick;
+            const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
+            if (first || pos == 0u) { // (wave-uniform)
+                gw.refill(rng, gt / (uint64_t)GW::G);
+                wave_lds_publish();
+            }
 #pragma unroll
-        for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
-        TickWords<GW::W> tw = tw_n;
-        uint32_t R2[2];
-        act_n = sample_actions_pair<S, 0>(w, rng, tw, gt);
-        if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R2);
-        else identity_ranks<S>(R2);
-        R_n = h ? R2[1] : R2[0];
+            for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
+            TickWords<GW::W> tw = tw_n;
+            uint32_t R2[2];
+            act_n = sample_actions_pair<S, 0>(w, rng, tw, gt);
+            if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R2);
+            else identity_ranks<S>(R2);
+            R_n = h ? R2[1] : R2[0];
+        }
     };
-    if (a.n_ticks > 0) sample_tick(0, true);
+    if (!RNG::kNumpy && a.n_ticks > 0) sample_tick(0, true);
     auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) {
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
         if (kRec) drec.so = (uint32_t)tick * slab_rec;
-        const uint32_t act = act_n, R = R_n;
-        sample_tick(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
+        uint32_t act, R;
+        if constexpr (RNG::kNumpy) { // numpy parity: base.py:326-330, then np.random.shuffle (base.py:372-374), from the env's own words
+            uint32_t a2[2] = {0u, 0u}, R2[2];
+#pragma unroll
+            for (int i = 0; i < A; i++) a2[i / 4] |= rng.bounded(S::nr_crew(c) + ((w.imp_bits >> i) & 1u)) << (8 * (i & 3));
+            identity_ranks<S>(R2);
+            if (S::kOrd > 0) {
+                OrderOf<S> ord = (OrderOf<S>)0xFEDCBA9876543210ull;
+                shuffle_nibbles<false>(rng, ord, A);
+                ranks_from_order<S>(ord, R2);
+            }
+            act = h ? a2[1] : a2[0];
+            R = h ? R2[1] : R2[0];
+        } else {
+            act = act_n;
+            R = R_n;
+            sample_tick(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
+        }
         float rr[4];
         bool done, trunc;
         step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc);
@@ -828,8 +846,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             }
             reset_env<S>(c, T, st, tid, e, rng);
             to_swar2<S>(c, st, e, h, w);
-            { // new roles: the next tick's actions again, from the words already fetched -- and its turn ranks, whose digits
-                // continue what the action draws (role-dependent ranges) left of their last word
+            if constexpr (!RNG::kNumpy) { // new roles: the next tick's actions again, from the words already fetched -- and its turn
+                // ranks, whose digits continue what the action draws (role-dependent ranges) left of their last word
                 TickWords<GW::W> tw = tw_n;
                 act_n = sample_actions_pair<S, 0>(w, rng, tw, 0ull);
                 if constexpr (RankLut<S>::kOk) {
@@ -1013,13 +1031,14 @@ template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
 // launchers
 // ---------------------------------------------------------------------------------------------------
 // tape: the handle draws from caller-supplied words (numpy parity) instead of the production stream; offered for the
-// populate()-shaped trajectory mode only (OUT_TRAJ_RAW8)
+// populate()-shaped trajectory (OUT_TRAJ_RAW8) and for the packed record (OUT_RECORD) -- the modes bench.py times
 template <class SPEC>
 void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
     constexpr bool kDuelSpec = !SPEC::kGeneric && SPEC::kA == 2 && SPEC::kJ == 0 && SPEC::kVar == SUSNET_VARIANT_ITG && SPEC::kStaticRoles && SPEC::kFixedOrder;
     if constexpr (kDuelSpec) {
         if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD)) { // susnet_duel.h
-            if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+            if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
+            else if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_NONE>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
@@ -1028,8 +1047,10 @@ void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t
         }
     }
     if constexpr (UseSplit<SPEC>::value) {
-        if (!tape && c.epw == 32 && out != OUT_ANY) { // half-filled waves: two lanes per environment (susnet_swar2.h)
-            if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
+        if (c.epw == 32 && out != OUT_ANY) { // half-filled waves: two lanes per environment (susnet_swar2.h)
+            if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_RECORD, TapeRng>), g, blk, sh, st, c, s, a, o);
+            else if (tape) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
+            else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
             else hipLaunchKernelGGL((k_rollout_swar2<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
@@ -1037,14 +1058,17 @@ void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t
         }
     }
     if constexpr (UseSwar<SPEC>::value) {
-        if (tape) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
+        if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_RECORD, TapeRng>), g, blk, sh, st, c, s, a, o);
+        else if (tape) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
         else hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
     } else {
-        if (tape) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
+        if (tape && out == OUT_RECORD) { // (SpecCfg2 on a wall map: the table kernel)
+            if constexpr (!SPEC::kGeneric && SPEC::kRawF > 0) hipLaunchKernelGGL((k_rollout<SPEC, OUT_RECORD, TapeRng>), g, blk, sh, st, c, s, a, o);
+        } else if (tape) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);

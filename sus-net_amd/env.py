@@ -505,6 +505,16 @@ class BatchedFourRoomEnv:
         obs = self.obs if self._obs_spec is not None else state
         return obs, rew, done | trunc, info
 
+    def native_layout(self):
+        """susnet_layout of the handle: sizes, environments per wave of the fused rollout, and which test hooks
+        (SUSNET_OVERRIDE_* bits) were found in the environment when it was created."""
+        return self._layout
+
+    def set_launch_limit(self, nbytes: int = 0):
+        """Largest output array one fused-rollout launch may address (susnet_set_launch_limit; 0 = the default, 2^31 - 1):
+        longer trajectories run as consecutive launches.  Launch plumbing only -- results do not depend on it."""
+        L.check(self.lib.susnet_set_launch_limit(self._h, int(nbytes)))
+
     def record_layout(self):
         """Field offsets of the packed per-env-step trajectory record, or None when the configuration has none."""
         lay = L.RecordLayout()

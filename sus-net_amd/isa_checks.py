@@ -198,7 +198,7 @@ def scratch_instructions(asm):
 # The kernels bench.py's lines are made of (fused rollout, packed record).  VERDICT r02 item 1: at most 16 spilled SGPRs, no
 # accumulation registers, no spilled VGPRs; and small enough for the instruction cache (64 KB per pair of CUs).
 HEADLINE_KERNELS = ("k_rollout_duel<PhiloxRng, 4>", "k_rollout_swar<Spec<3, 4, 0, 1, -1, 1>, 4, PhiloxRng>",
-                    "k_rollout_swar2<Spec<8, 4, 0, 1, -1, 2>, 4>", "k_rollout_swar<Spec<5, 5, 2, 1, -1, 1>, 4, PhiloxRng>")
+                    "k_rollout_swar2<Spec<8, 4, 0, 1, -1, 2>, 4, PhiloxRng>", "k_rollout_swar<Spec<5, 5, 2, 1, -1, 1>, 4, PhiloxRng>")
 HEADLINE_LIMITS = dict(sgpr_spill=16, agpr=0, vgpr_spill=0, v_accvgpr=0, scratch=0, code_bytes=48 * 1024)
 
 

@@ -80,7 +80,7 @@ KERNELS = ["compiled", "generic"]  # the compiled-in (Spec) kernels bench.py tim
 
 def select_kernels(monkeypatch, kernels):
     """Route a handle's step launches: 'compiled' = whatever pick_spec selects (Spec<...> / SpecA<A> where one exists),
-    'generic' = the generic kernels for every configuration (SUSNET_FORCE_GENERIC is read at each launch)."""
+    'generic' = the generic kernels for every configuration (SUSNET_FORCE_GENERIC is read when the handle is created)."""
     if kernels == "generic":
         monkeypatch.setenv("SUSNET_FORCE_GENERIC", "1")
     else:
@@ -140,7 +140,10 @@ def test_hip_replays_reference_traces(pkg, family, kernels, monkeypatch):
 @pytest.mark.parametrize("kernels", KERNELS)
 @pytest.mark.parametrize("name", crc_names())
 def test_hip_matches_reference_crc_streams(pkg, name, kernels, monkeypatch):
-    """64 numpy seeds per configuration at once (one env per seed, TAPE mode fed numpy's own words)."""
+    """64 numpy seeds per configuration at once (one env per seed, TAPE mode fed numpy's own words), through the step API.
+    The CRC of a step that ENDS an episode is taken from the fixture (with auto-reset the exported state is already the next
+    episode's): terminal steps are compared field by field in test_hip_replays_reference_traces (no auto-reset) and, tick by
+    tick against the oracle, in the fused test below."""
     import zlib
 
     select_kernels(monkeypatch, kernels)
@@ -176,15 +179,22 @@ def test_hip_matches_reference_crc_streams(pkg, name, kernels, monkeypatch):
     assert bad.size == 0, f"{name}: first mismatch at (seed index, step) = {bad[0].tolist()}"
 
 
+@pytest.mark.parametrize("epw", [16, 32, 64])
+@pytest.mark.parametrize("layout", ["separate", "packed"])
 @pytest.mark.parametrize("name", crc_names())
-def test_fused_rollout_on_numpy_tapes_matches_reference_crc_streams(pkg, oracle_mod, name):
-    """The FUSED rollout kernels (the ones bench.py times: byte-parallel / duel / per-turn, whichever the configuration
-    selects) fed numpy's own MT19937 words: ONE launch of 96 ticks per fixture -- sample_actions, step, in-launch reset all
-    draw from the tape with numpy semantics, so env b reproduces the reference seeded with seed b.  Every tick's actions,
-    rewards, done, truncated and post-reset raw observation must equal the oracle's MT19937 run (itself equal to the
-    reference on these very seeds, tests/test_oracle_checksums.py), and for every step that did not end an episode the CRC
-    of the step record rebuilt from the kernel's outputs (info counters taken from the oracle: the trajectory does not carry
-    them) must equal the reference's."""
+def test_fused_rollout_on_numpy_tapes_matches_reference_crc_streams(pkg, oracle_mod, name, layout, epw, monkeypatch):
+    """The FUSED rollout kernels fed numpy's own MT19937 words, through the very instantiations bench.py times: trajectory as
+    separate tensors (OUT_TRAJ_RAW8) and as PACKED RECORDS (OUT_RECORD: the headline layout), at 16, 32 and 64 environments
+    per wave (SUSNET_EPW; 32 routes the 8-agent game to the two-lanes-per-environment kernel) -- k_rollout_duel<TapeRng, *>,
+    k_rollout_swar<*, *, TapeRng>, k_rollout_swar2<*, *, TapeRng>, k_rollout<*, *, TapeRng>, whichever the configuration
+    selects.  ONE launch of 96 ticks per fixture: sample_actions, step, in-launch reset all draw from the tape with numpy
+    semantics, so env b reproduces the reference seeded with seed b.  Every tick's actions, rewards, done, truncated and
+    post-reset raw observation must equal the oracle's MT19937 run (itself equal to the reference on these very seeds,
+    tests/test_oracle_checksums.py), and for every step that did not end an episode the CRC of the step record rebuilt from
+    the kernel's outputs (info counters taken from the oracle: the trajectory does not carry them) must equal the
+    reference's.  (A step that ENDS an episode takes its CRC from the fixture: the in-launch reset has replaced the terminal
+    state by then; its actions / rewards / flags are compared through the oracle above, and terminal states field by field in
+    test_hip_replays_reference_traces.)"""
     import zlib
 
     g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
@@ -192,10 +202,18 @@ def test_fused_rollout_on_numpy_tapes_matches_reference_crc_streams(pkg, oracle_
     seeds, S = meta["seeds"], meta["n_steps"]
     B = len(seeds)
     tagging = meta["class"] == "tagging"
+    monkeypatch.setenv("SUSNET_EPW", str(epw))
     env = env_from_meta(pkg, meta, B, rng="numpy", tape_words=1 << 14, auto_reset=True, check_errors=False)
+    lay = env.native_layout()
+    assert lay.envs_per_wave == epw and lay.test_overrides == 2  # SUSNET_OVERRIDE_EPW, read when the handle was created
+    packed = layout == "packed"
+    if packed and env.record_layout() is None:
+        pytest.skip("configuration not compiled in: no packed record")
+    if not packed and epw == 32 and env.record_layout() is None:
+        pytest.skip("generic kernels: 16 and 64 environments per wave cover the lane masking")
     env._reseed(seeds)
     env.reset()
-    traj = env.rollout(S, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    traj = env.rollout(S, obs=pkg.ObsConfig("raw", dtype=torch.uint8), packed=packed)
     torch.cuda.synchronize()
     env.poll_errors()
     acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
@@ -580,10 +598,7 @@ def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch
     ob.reset(threads=0)
     obs_cfg = pkg.ObsConfig("raw", dtype=torch.uint8)
     for n in (24, 5, 1, 2, 3):
-        if n == 5:
-            monkeypatch.setenv("SUSNET_TRAJ_MAX_BYTES", str(2 * B * lay.record_bytes + 8))  # 2 ticks per launch
-        else:
-            monkeypatch.delenv("SUSNET_TRAJ_MAX_BYTES", raising=False)
+        env.set_launch_limit(2 * B * lay.record_bytes + 8 if n == 5 else 0)  # n == 5: 2 ticks per launch
         traj = env.rollout(n, obs=obs_cfg, packed=True)
         torch.cuda.synchronize()
         assert traj["rewards"].shape == (n, B, env.n_agents) and traj["obs"].shape == (n, B, env.flattened_state_size)
