@@ -14,6 +14,14 @@ src/replay_memory.py:96-143, minus the buffer).
                           HIP events around the SAME K launches (one number, one set of launches).
   --mode step           : the drop-in API; a bench step is one tick = two launches (`sample_actions` + `step`).
 
+The JSON line: `value` = env-steps/s of the named configuration (default cfg2 = BASELINE.json configs[1]).  `roofline`:
+`achieved` / `frac` are computed from the bytes a launch actually has to move -- the trajectory records it stores (the state
+of a fused rollout never leaves the chip; the committed PMC pass measures the same bytes: `traffic`); the figure SURVEY.md
+section 8(d) defines for the one-step API (12A + 4J + 6 bytes per env-step, state read + written every step) is reported next
+to it as `survey_8d_*`.  `other_configs` holds the same measurement (5 warm-up + 20 timed launches) for the other BASELINE
+configurations: cfg3, cfg4 (the 8-GPU shard: 32 768 envs), tag5 and cfg5 (policy in the loop: eager and as a replayed
+hipGraph).
+
 N > 1: one rank per GPU (torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Started as a
 plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) the script launches the N ranks itself, before
 it touches the GPU.  The batch is sharded by contiguous global env ids, per-GPU batch fixed (weak scaling); the only
@@ -66,11 +74,14 @@ def algorithmic_bytes_per_step(A, J, N, obs):
     return b
 
 
-def stored_bytes_per_step(A, J, N, obs):
-    """What the fused rollout actually writes per env-step: actions u8 + rewards f32 + done + trunc + obs."""
+def stored_bytes_per_step(A, J, N, obs, raw_size=None, record_bytes=None):
+    """What the fused rollout writes per env-step: actions u8 + rewards f32 + done + truncated + the observation.
+    raw_size: flattened_state_size of the configuration (3A + 3J, + 2A + 1 with tagging); record_bytes: the packed record."""
+    if record_bytes:
+        return int(record_bytes)
     b = A + 4 * A + 2
     if obs == "raw":
-        b += 3 * A + (3 * J if J else 0)  # (+ 2A + 1 with tagging; not counted)
+        b += raw_size if raw_size is not None else 3 * A + (3 * J if J else 0)
     elif obs == "flat":
         b += 4 * A * 2 * N
     elif obs == "planes":
@@ -78,11 +89,11 @@ def stored_bytes_per_step(A, J, N, obs):
     return b
 
 
-def profiled_traffic(config, obs):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+def profiled_traffic(config, obs, packed, batch, ticks):
+    """HBM bytes per bench step of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_pmc_summary.json, written by tools/summarize_profiles.py: one entry per config, separate --pmc runs for
-    FETCH_SIZE and WRITE_SIZE, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  bench.py
-    cannot collect PMCs itself."""
+    FETCH_SIZE and WRITE_SIZE, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  bench.py cannot
+    collect PMCs itself.  An entry only counts for the run it was profiled on: same config, trajectory layout, batch, ticks."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
@@ -91,6 +102,11 @@ def profiled_traffic(config, obs):
     try:
         d = json.load(open(files[-1]))
         d = d.get(config, d if config == "cfg2" else {})  # (round-1 summaries held cfg2 only, at top level)
+        cmd = d.get("command")  # (round >= 3 summaries: what the profiled command was)
+        if cmd is not None and obs == "raw" and (bool(cmd.get("packed")) != bool(packed) or cmd.get("batch") != batch or cmd.get("ticks") != ticks):
+            return None, None
+        if cmd is None and obs == "raw" and not packed:  # (older summaries profiled the packed default)
+            return None, None
         wkey = {"raw": "pmc_WRITE_SIZE", "planes": "pmc_W_planes", "flat": "pmc_W_flat"}.get(obs)
         # (per bench step: a step whose record array would pass 2 GiB runs as several consecutive launches)
         pick = lambda grp, ctr: next(v[ctr]["mean_per_launch"] * v.get("launches_per_bench_step", 1) for k, v in d[grp].items() if "k_rollout" in k)
@@ -99,6 +115,39 @@ def profiled_traffic(config, obs):
         return (w + 2.0 * f) * 1024.0, os.path.basename(files[-1])
     except (KeyError, StopIteration, ValueError, TypeError):
         return None, None
+
+
+KERNEL_NAMES = {"cfg2": "k_rollout_duel<PhiloxRng, OUT>", "cfg3": "k_rollout_swar<Spec<3,4,..>, OUT, PhiloxRng>",
+                "cfg4": "k_rollout_swar2<Spec<8,4,..>, OUT, PhiloxRng>", "tag5": "k_rollout_swar<Spec<5,5,2,..>, OUT, PhiloxRng>"}
+
+
+def roofline_block(config, spec, B, ticks, obs, packed, raw_size, record_bytes, avg_launch_s, pair_us=None, with_traffic=True):
+    """The dominant kernel's roofline figures for one fused launch of `ticks` ticks over B envs."""
+    A, J, N = spec["A"], spec["J"], spec["n"]
+    steps = B * ticks
+    b_stored = stored_bytes_per_step(A, J, N, obs, raw_size, record_bytes if packed else None)
+    b_8d = algorithmic_bytes_per_step(A, J, N, obs)
+    achieved = steps * b_stored / avg_launch_s / 1e9
+    traffic, src = profiled_traffic(config, obs, packed, B, ticks) if with_traffic else (None, None)
+    kernel = KERNEL_NAMES.get(config, "k_rollout")
+    if config == "cfg4" and B != 32768:
+        kernel = "k_rollout_swar<Spec<8,4,..>, OUT, PhiloxRng>"
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_unit": "bytes per bench step (PMC: WRITE_SIZE + 2 x FETCH_SIZE)", "traffic_source": src,
+        "traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "bytes_per_env_step": b_stored, "bytes_per_launch": steps * b_stored,
+        "survey_8d_bytes_per_env_step": b_8d, "survey_8d_achieved": steps * b_8d / avg_launch_s / 1e9,
+        "survey_8d_frac": steps * b_8d / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+        "kernel": kernel, "env_steps_per_launch": steps, "avg_launch_us": avg_launch_s * 1e6, "avg_launch_us_event_pairs": pair_us,
+        "note": "achieved / frac = bytes the launch stores (trajectory records: the state of a fused rollout stays on chip) / "
+                "avg_launch_us / 8 TB/s; survey_8d_* = the same with SURVEY.md 8(d)'s 12A + 4J + 6 bytes per env-step (the one-step "
+                "API's state read + write, which a fused rollout does not perform: r01 / r02 lines reported this figure as frac); "
+                "avg_launch_us = HIP-event time of the timed region (events on the launch stream around the K timed launches) / K; "
+                "avg_launch_us_event_pairs = mean of 8 further launches bracketed one by one (cross-check, outside the timed "
+                "region); traffic = PMC bytes of the committed rocprofv3 pass of this command and layout (profiles/), null when "
+                "none matches",
+    }
 
 
 def make_env(pkg, spec, batch, seed, env_id_base, device, obs_cfg=None):
@@ -166,11 +215,22 @@ def self_launch(n_gpus: int) -> int:
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(launch_command(n_gpus, port, sys.argv[1:]), env=env)
+
+
+def launch_command(n_gpus: int, port: int, argv):
+    """The command `self_launch` runs: the driver's own contract (torch.distributed.run, one rank per GPU, 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(world: int, gpus: int):
+    """bench.py never reports a line for a GPU count other than the one it was asked for."""
+    if world != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but the launched world has {world} rank(s) (WORLD_SIZE); refusing to report "
+                         f"a line for a different GPU count")
 
 
 def main():
@@ -187,7 +247,7 @@ def main():
                     "the same fields, one or a few wide stores per lane instead of one narrow store per tensor), 0 = separate "
                     "trajectory tensors, -1 (default) = packed where the configuration has it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the step-API leg, the observation sweep and other_configs")
     args = ap.parse_args()
     assert args.gpus >= 1 and args.steps >= 1 and args.warmup >= 0 and args.ticks >= 1
 
@@ -204,18 +264,14 @@ def main():
         os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local = pkg.dist.init_from_env(backend)
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launched world has {world} rank(s) (WORLD_SIZE); refusing to report "
-                         f"a line for a different GPU count")
+    check_world(world, args.gpus)
     if world > 1:  # every rank must be there: the gathered world is what n_gpus reports
         seen = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
         dist.all_reduce(seen)
         assert int(seen.item()) == args.gpus, f"gathered {int(seen.item())} ranks, expected {args.gpus}"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    spec = CONFIGS[args.config]
-    A, J, N = spec["A"], spec["J"], spec["n"]
-    B = args.batch or spec["batch"]
+    coll_dev = device if backend == "nccl" else "cpu"
     seed = 1234
 
     def obs_config(mode):
@@ -252,28 +308,36 @@ def main():
             env.step(a)
         return 2 * n_ticks
 
-    used_packed = [False]
-
-    def measure(mode, obs_mode, K, W, ticks):
-        """W untimed + K timed bench steps.  fused: a step is one launch of `ticks` ticks; step / policy: one tick."""
+    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0):
+        """W untimed + K timed bench steps of one configuration.  fused: a step is one launch of `ticks` ticks; step / policy:
+        one tick (policy with graph_ticks > 0: the tick loop replayed as hipGraphs of graph_ticks ticks, K rounded up to whole graphs)."""
         oc = obs_config(obs_mode) if mode == "fused" else None
         step_obs = obs_config(obs_mode) if mode == "step" else None
         if mode == "policy":
             step_obs = pkg.ObsConfig("flat", POLICY_COMPONENTS)
         env = make_env(pkg, spec, B, seed, rank * B, device, obs_cfg=step_obs)
         env.reset()
-        packed = (mode == "fused" and obs_mode == "raw" and args.packed != 0 and env.record_layout() is not None)
-        if args.packed == 1 and mode == "fused" and obs_mode == "raw":
+        lay = env.record_layout()
+        packed = (mode == "fused" and obs_mode == "raw" and want_packed != 0 and lay is not None)
+        if want_packed == 1 and mode == "fused" and obs_mode == "raw":
             assert packed, "this configuration has no packed record mode"
-        used_packed[0] = packed if mode == "fused" and obs_mode == args.obs else used_packed[0]
         bufs = env.alloc_rollout(ticks, obs=oc, packed=packed) if mode == "fused" else None
         if mode == "policy":
             model = pkg.policy.reference_imposter_mlp(env, POLICY_COMPONENTS, seed=0)
             pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS)
+            if graph_ticks > 0:
+                graph, _ = pr.capture(graph_ticks)
+                K = (K + graph_ticks - 1) // graph_ticks * graph_ticks
+                W = (W + graph_ticks - 1) // graph_ticks * graph_ticks
 
-            def runner(n):
-                pr.run(n)
-                return n
+                def runner(n):
+                    for _ in range(n // graph_ticks):
+                        graph.replay()
+                    return n // graph_ticks
+            else:
+                def runner(n):
+                    pr.run(n)
+                    return n
         else:
             runner = (lambda n: run_fused(env, n, ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
         runner(W)
@@ -293,33 +357,41 @@ def main():
             run_fused(env, 8, ticks, bufs, pairs)
             torch.cuda.synchronize(device)
             pair_us = sum(a.elapsed_time(b) for a, b in pairs) * 1e3 / len(pairs)
+        launch_us_ranks = None
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
+            mine = torch.tensor([dev_ms * 1e3 / K], dtype=torch.float64, device=coll_dev)
+            allv = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            launch_us_ranks = [float(v.item()) for v in allv]
         env.poll_errors()
         metrics = pkg.dist.node_metrics(env)  # the ONE collective: all-gather of the episode totals
-        return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, pair_us=pair_us)
+        return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, pair_us=pair_us, packed=packed, steps=K, warmup=W,
+                    raw_size=env.flattened_state_size, record_bytes=lay.record_bytes if lay is not None else None,
+                    launch_us_ranks=launch_us_ranks)
 
     K, W = args.steps, args.warmup
+    spec = CONFIGS[args.config]
+    A = spec["A"]
+    B = args.batch or spec["batch"]
     if spec.get("policy"):
         args.mode, args.obs = "policy", "flat"
     ticks_per_step = args.ticks if args.mode == "fused" else 1
-    res = measure(args.mode, args.obs, K, W, args.ticks)
+    res = measure(spec, B, args.mode, args.obs, K, W, args.ticks, args.packed)
     steps_per_launch = B * ticks_per_step          # env-steps one launch of the dominant kernel processes (this rank)
     total_steps = steps_per_launch * world * K
     value = total_steps / res["seconds"]
-    # roofline of the dominant kernel: algorithmic bytes per launch / its average duration over the TIMED region
-    # (HIP events on the launch stream around the K launches; fused: K back-to-back k_rollout launches and nothing else)
+    # roofline of the dominant kernel: bytes per launch / its average duration over the TIMED region (HIP events on the launch
+    # stream around the K launches; fused: K back-to-back k_rollout launches and nothing else)
     avg_launch_s = (res["device_ms"] / 1e3) / K
-    b_alg = algorithmic_bytes_per_step(A, J, N, args.obs)
-    b_stored = stored_bytes_per_step(A, J, N, args.obs)
-    if used_packed[0]:
-        b_stored = (b_stored + 3) // 4 * 4  # the packed record is padded to a multiple of 4 bytes
-    achieved = steps_per_launch * b_alg / avg_launch_s / 1e9
-    traffic, traffic_src = (None, None)
-    if args.mode == "fused" and B == spec["batch"] and args.ticks == 512 and world == 1:
-        traffic, traffic_src = profiled_traffic(args.config, args.obs)
+    roof = roofline_block(args.config, spec, B, ticks_per_step, args.obs, res["packed"], res["raw_size"], res["record_bytes"], avg_launch_s,
+                          res["pair_us"], with_traffic=(args.mode == "fused" and world == 1))
+    if args.mode == "step":
+        roof["kernel"] = "k_sample_philox + k_step<PhiloxRng, Spec>"
+    if res["launch_us_ranks"]:
+        roof["avg_launch_us_per_rank"] = {"min": min(res["launch_us_ranks"]), "max": max(res["launch_us_ranks"]), "all": res["launch_us_ranks"]}
     line = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": res["seconds"] * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -329,40 +401,23 @@ def main():
                    "step_definition": (f"one susnet_rollout launch = {ticks_per_step} lockstep ticks x {B} envs per GPU" if args.mode == "fused"
                                        else "one lockstep tick (sample_actions + step)"),
                    "env_steps_per_bench_step": steps_per_launch * world,
-                   "trajectory_layout": "packed record per env-step" if used_packed[0] else "separate tensors",
+                   "trajectory_layout": "packed record per env-step" if res["packed"] else "separate tensors",
                    "rng": "philox4x32-10 in-kernel", "auto_reset": True, "parallelism": f"dp{world}",
                    "agent_steps_per_s": value * A},
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-            "stored_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "algorithmic_bytes_per_launch": steps_per_launch * b_alg, "stored_bytes_per_launch": steps_per_launch * b_stored,
-            # (the names rocprofv3 reports for these launches: profiles/rNN_<config>_kernel_stats.csv)
-            "kernel": ({"cfg2": "k_rollout_duel<PhiloxRng, OUT>", "cfg3": "k_rollout_swar<Spec<3,4,..>, OUT>",
-                        "cfg4": "k_rollout_swar2<Spec<8,4,..>, OUT>" if B == 32768 else "k_rollout_swar<Spec<8,4,..>, OUT>",
-                        "tag5": "k_rollout_swar<Spec<5,5,2,..>, OUT>"}.get(args.config, "k_rollout")
-                       if args.mode == "fused" else "k_step<PhiloxRng, Spec>"),
-            "algorithmic_bytes_per_env_step": b_alg, "stored_bytes_per_env_step": b_stored,
-            "achieved_stored_GBs": steps_per_launch * b_stored / avg_launch_s / 1e9,
-            "env_steps_per_launch": steps_per_launch, "avg_launch_us": avg_launch_s * 1e6,
-            "avg_launch_us_event_pairs": res["pair_us"],
-            "note": "avg_launch_us = HIP-event time of the timed region (events on the launch stream around the K timed launches) / K: "
-                    "the launches `value` is made of; avg_launch_us_event_pairs = mean of 8 further launches bracketed one by one "
-                    "(cross-check, outside the timed region); frac = algorithmic bytes (SURVEY 8d) / avg_launch_us / 8 TB/s; "
-                    "traffic / stored_frac = PMC bytes (WRITE_SIZE + 2 x FETCH_SIZE) of the committed rocprofv3 pass of this command "
-                    "(profiles/), null when none matches",
-        },
+        "roofline": roof,
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
     del res
     if args.mode == "policy":
-        line["roofline"].update(achieved=None, frac=None, kernel="k_step<PhiloxRng, Spec<3,4,..>> + hipBLASLt GEMMs",
+        line["roofline"].update(achieved=None, frac=None, survey_8d_achieved=None, survey_8d_frac=None,
+                                kernel="k_step<PhiloxRng, Spec<3,4,..>> + hipBLASLt GEMMs",
                                 note="policy loop: per-tick time is dominated by the 5 fp32 GEMMs and host launch gaps, not by "
                                      "the env kernel; no single-kernel roofline is claimed for this config")
-    if rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy":
+    secondary = rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy"
+    if secondary:
         other = "step" if args.mode == "fused" else "fused"
         k2 = 512 if other == "step" else 8
-        r2 = measure(other, args.obs, k2, 64 if other == "step" else 2, args.ticks)
+        r2 = measure(spec, B, other, args.obs, k2, 64 if other == "step" else 2, args.ticks, args.packed)
         per2 = B * (1 if other == "step" else args.ticks)
         line["secondary"] = {"mode": other, "value": per2 * k2 / r2["seconds"], "unit": "env-steps/s",
                              "ms_per_tick": r2["seconds"] * 1e3 / (k2 * (1 if other == "step" else args.ticks)),
@@ -386,24 +441,54 @@ def main():
             line["secondary"]["hip_graph_replay"] = {"value": B * 4096 / dt, "unit": "env-steps/s", "ms_per_tick": dt * 1e3 / 4096,
                                                      "ticks_per_graph": gt, "nodes_per_tick": env_g.graph_nodes_per_tick()}
             del env_g, graph
-    if rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy":
         # the same rollout with the reference's float32 feature layouts fused in (HBM-write bound)
         line["obs_modes"] = []
         for om in ("flat", "planes"):
             if om == args.obs:
                 continue
             k3, t3 = 4, min(args.ticks, 128)  # planes f32 at 128 ticks is already an 11 GB trajectory
-            r3 = measure("fused", om, k3, 1, t3)
+            r3 = measure(spec, B, "fused", om, k3, 1, t3)
             per_launch_s = (r3["device_ms"] / 1e3) / k3
-            bs = stored_bytes_per_step(A, J, N, om)
-            ba = algorithmic_bytes_per_step(A, J, N, om)
+            rb = roofline_block(args.config, spec, B, t3, om, False, r3["raw_size"], None, per_launch_s, with_traffic=False)
             line["obs_modes"].append({
                 "obs": om + ("(onehot_pos)" if om == "flat" else "") + " f32", "value": B * t3 * k3 / r3["seconds"], "unit": "env-steps/s",
-                "algorithmic_bytes_per_env_step": ba, "stored_bytes_per_env_step": bs,
-                "achieved_GBs": B * t3 * ba / per_launch_s / 1e9, "frac": B * t3 * ba / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                "bytes_per_env_step": rb["bytes_per_env_step"], "achieved_GBs": rb["achieved"], "frac": rb["frac"],
+                "survey_8d_bytes_per_env_step": rb["survey_8d_bytes_per_env_step"], "survey_8d_frac": rb["survey_8d_frac"],
                 "ticks_per_launch": t3, "avg_launch_us": per_launch_s * 1e6})
             del r3
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the other BASELINE configurations, each measured like the headline (5 warm-up + 20 timed launches of 512 ticks)
+        line["other_configs"] = []
+        for name in ("cfg3", "cfg4", "tag5", "cfg5"):
+            if name == args.config:
+                continue
+            sp = CONFIGS[name]
+            if sp.get("policy"):
+                entry = {"config": name, "workload": sp["workload"], "unit": "env-steps/s"}
+                for label, gt in (("eager", 0), ("hip_graph_replay", 8)):
+                    rp = measure(sp, sp["batch"], "policy", "flat", 64, 16, 1, graph_ticks=gt)
+                    entry[label] = {"value": sp["batch"] * rp["steps"] / rp["seconds"], "us_per_tick": rp["seconds"] * 1e6 / rp["steps"],
+                                    "ticks_timed": rp["steps"], **({"ticks_per_graph": gt} if gt else {})}
+                    del rp
+                entry["value"] = max(entry["eager"]["value"], entry["hip_graph_replay"]["value"])
+                entry["kernel"] = "k_export (roles) + hipBLASLt GEMMs / PReLU (torch-ROCm fp32) + k_sample_philox + k_step<PhiloxRng, Spec<3,4,..>>"
+                line["other_configs"].append(entry)
+                continue
+            ro = measure(sp, sp["batch"], "fused", "raw", 20, 5, 512)
+            launch_s = (ro["device_ms"] / 1e3) / 20
+            rb = roofline_block(name, sp, sp["batch"], 512, "raw", ro["packed"], ro["raw_size"], ro["record_bytes"], launch_s, ro["pair_us"])
+            line["other_configs"].append({
+                "config": name, "workload": sp["workload"], "value": sp["batch"] * 512 * 20 / ro["seconds"], "unit": "env-steps/s",
+                "steps": 20, "warmup": 5, "ticks_per_launch": 512, "batch": sp["batch"],
+                "trajectory_layout": "packed record per env-step" if ro["packed"] else "separate tensors",
+                "avg_launch_us": rb["avg_launch_us"], "avg_launch_us_event_pairs": rb["avg_launch_us_event_pairs"], "kernel": rb["kernel"],
+                "bytes_per_env_step": rb["bytes_per_env_step"], "achieved_GBs": rb["achieved"], "frac": rb["frac"],
+                "survey_8d_bytes_per_env_step": rb["survey_8d_bytes_per_env_step"], "survey_8d_frac": rb["survey_8d_frac"],
+                "traffic": rb["traffic"], "traffic_frac": rb["traffic_frac"], "traffic_source": rb["traffic_source"],
+                "episodes": ro["metrics"].get("episodes"), "episode_steps": ro["metrics"].get("episode_steps")})
+            del ro
+    if world > 1:
+        dist.barrier()  # the timed region and its collectives are over on every rank before rank 0 spends host time below
+    if rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(spec)
     elif rank == 0:
         line["cpu_baseline"] = None

@@ -207,6 +207,55 @@ class PolicyRollout:
         return {k: torch.stack(v) for k, v in out.items()} if record else {}
 
 
+    @torch.no_grad()
+    def capture(self, n_ticks: int = 8, record: bool = False):
+        """The policy tick -- {roles refresh, network forward, argmax, crew sampling, where, env step} x ``n_ticks`` -- as ONE
+        hipGraph (reference loop shape: visualize.py:547-582, one Python iteration per tick).  Everything a tick touches is
+        device-resident (the env's step counter included: ``device_tick``), so ``graph.replay()`` advances the rollout by
+        ``n_ticks`` ticks with a single launch from the host instead of ~20 eager launches per tick.
+
+        Returns ``(graph, outputs)``; with ``record=True`` ``outputs`` holds static ``actions / rewards / done / truncated /
+        obs_before`` tensors with a leading ``[n_ticks]`` dimension that every replay overwrites (parity tests).  Needs an env
+        built with ``rng='philox', check_errors=False, export_state=False`` (both would synchronise inside the capture)."""
+        env = self.env
+        assert env.rng_kind == "philox", "graph replay needs the counter-based production stream"
+        assert not env.check_errors and not env.export_state, "construct the env with check_errors=False, export_state=False"
+        env.device_tick(True)
+        B, A = env.batch, env.n_agents
+        out: Dict[str, torch.Tensor] = {}
+        if record:
+            out = {"actions": torch.zeros(n_ticks, B, A, dtype=torch.int64, device=env.device),
+                   "rewards": torch.zeros(n_ticks, B, A, dtype=torch.float32, device=env.device),
+                   "done": torch.zeros(n_ticks, B, dtype=torch.bool, device=env.device),
+                   "truncated": torch.zeros(n_ticks, B, dtype=torch.bool, device=env.device),
+                   "obs_before": torch.zeros(n_ticks, *env.obs.shape, dtype=env.obs.dtype, device=env.device)}
+
+        def tick(k):
+            if record:
+                out["obs_before"][k].copy_(env.obs)
+            a = self.act()
+            _, rew, done, trunc, _ = env.step(a)
+            if record:
+                out["actions"][k].copy_(a)
+                out["rewards"][k].copy_(rew)
+                out["done"][k].copy_(done)
+                out["truncated"][k].copy_(trunc)
+
+        cur = torch.cuda.current_stream(env.device)
+        side = torch.cuda.Stream(env.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up on a side stream, as torch's capture rules ask (these ticks count: the rollout advances)
+            for k in range(2):
+                tick(k % n_ticks)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for k in range(n_ticks):
+                tick(k)
+        self.captured_warmup_ticks = 2
+        return graph, out
+
+
 class WindowedPolicyRollout:
     """Acting loop over a device-resident window of the last ``sequence_length`` flattened states per env.
 

@@ -81,3 +81,43 @@ def test_all_gather_totals_single_process_is_identity():
     pkg = importlib.import_module("sus-net_amd")
     v = torch.arange(12, dtype=torch.int64)
     assert torch.equal(pkg.dist.all_gather_totals(v), v.unsqueeze(0))
+
+
+# ---- bench.py's N > 1 control flow (no GPU needed: everything up to the first device call) -----------------------------------
+def _bench_module():
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_self_launch_builds_the_drivers_command():
+    """`python bench.py --gpus N` started without the torch.distributed.run environment launches the N ranks itself, with the
+    driver's own contract: one node, N processes, rendezvous on 127.0.0.1, its own flags passed through."""
+    bench = _bench_module()
+    cmd = bench.launch_command(4, 23456, ["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "23456"
+    k = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    # a world that differs from --gpus is refused before a line can be printed
+    bench.check_world(4, 4)
+    with pytest.raises(SystemExit, match="refusing to report"):
+        bench.check_world(2, 4)
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus_under_gloo(tmp_path):
+    """Two real ranks (torch.distributed.run, gloo rendezvous on 127.0.0.1) started with --gpus 3: every rank stops at the
+    world check -- non-zero exit, the refusal on stderr, no JSON line on stdout."""
+    import subprocess
+    import sys
+
+    bench = _bench_module()
+    env = dict(os.environ, SUSNET_BENCH_BACKEND="gloo", SUSNET_BENCH_ONE_DEVICE="1")
+    cmd = bench.launch_command(2, _free_port(), ["--gpus", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"])
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0
+    assert "refusing to report" in p.stderr and '{"metric"' not in p.stdout

@@ -1024,6 +1024,48 @@ def test_policy_rollout_matches_oracle_on_recorded_actions(pkg, oracle_mod):
         ob.reset(mask=(odone | otrunc).astype(bool))
 
 
+def test_captured_policy_tick_replays_against_the_oracle(pkg, oracle_mod):
+    """PolicyRollout.capture: the whole policy tick as a hipGraph.  Replays are checked like the eager loop above -- fused flat
+    observation, MLP argmax in the imposter slot, Philox crew draws mirrored in the oracle, rewards / done bit for bit -- for the
+    two eager warm-up ticks and three replays of a 7-tick graph (21 ticks: episode ends and in-step resets included)."""
+    B, seed, n = 512, 21, 7
+    comps = ["onehot_pos", "alive_crew", "closest_crew"]
+    env, ob = make_pair(pkg, oracle_mod, "base_1v2_j4_14", B, seed, auto_reset=True, check_errors=False, export_state=False,
+                        obs=pkg.ObsConfig("flat", comps))
+    env.reset()
+    ob.reset()
+    model = pkg.policy.reference_imposter_mlp(env, comps, seed=3)
+    runner = pkg.PolicyRollout(env, model, crew_model=None, components=comps)
+    spatial = torch.zeros(B, 1, 1, device=env.device)
+
+    def check_tick(obs_before, a, rew, done, label):
+        np.testing.assert_array_equal(np_(obs_before), ob.obs_flat(comps), err_msg=f"fused flat obs, {label}")
+        want = model(spatial, obs_before).argmax(1)
+        oa = ob.sample_actions()
+        imp = ob.export()["imp"].astype(bool)
+        oa[imp] = np_(want)
+        np.testing.assert_array_equal(np_(a), oa, err_msg=f"actions, {label}")
+        orew, odone, otrunc, rc = ob.step(oa)
+        assert rc == 0
+        assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"rewards, {label}"
+        np.testing.assert_array_equal(np_(done), odone.astype(bool), err_msg=f"done, {label}")
+        ob.reset(mask=(odone | otrunc).astype(bool))
+
+    graph, out = runner.capture(n, record=True)
+    torch.cuda.synchronize()
+    # the capture's eager warm-up ticks advanced the rollout: they wrote slots 0 and 1 of the record
+    for k in range(runner.captured_warmup_ticks):
+        check_tick(out["obs_before"][k], out["actions"][k], out["rewards"][k], out["done"][k], f"warm-up tick {k}")
+    ends = 0
+    for rep in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in range(n):
+            check_tick(out["obs_before"][k], out["actions"][k], out["rewards"][k], out["done"][k], f"replay {rep} tick {k}")
+        ends += int(out["done"].sum()) + int(out["truncated"].sum())
+    assert int(env.tick) == runner.captured_warmup_ticks + 3 * n
+
+
 def test_windowed_spatialdqn_policy_rollout(pkg, oracle_mod):
     """SpatialDQN (CNN + RNN over a T = 3 window of flattened states) acting for every agent through the Perspective
     featurizer, epsilon-greedy: the window follows np.roll / refill-on-reset (train.py:318-322, 388-389, 452-457) with

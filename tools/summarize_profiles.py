@@ -21,11 +21,15 @@ for cdir in sorted(glob.glob(f"{root}/*")):
         shutil.copy(stats[0], f"profiles/{tag}_{cfg}_kernel_stats.csv")
     # the JSON line bench.py printed inside the profiled --stats run
     log = f"{cdir}/stats.log"
+    per = {}
     if os.path.exists(log):
         for ln in open(log, errors="replace"):
             if ln.startswith('{"metric"'):
                 open(f"profiles/{tag}_{cfg}_bench_under_rocprofv3.json", "w").write(ln)
-    per = {}
+                c = json.loads(ln)["config"]
+                # what was profiled: bench.py attaches these PMC bytes only to a run of the same layout / batch / ticks
+                per["command"] = {"packed": c.get("trajectory_layout", "").startswith("packed"), "batch": c.get("batch_per_gpu"),
+                                  "ticks": c.get("ticks_per_launch")}
     for d in sorted(glob.glob(f"{cdir}/pmc_*")):
         if not os.path.isdir(d):
             continue
@@ -38,7 +42,7 @@ for cdir in sorted(glob.glob(f"{root}/*")):
                 dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         out = {}
         for k, cs in agg.items():
-            if "rollout" not in k and "k_step" not in k and "k_sample" not in k:
+            if not any(x in k for x in ("rollout", "k_step", "k_sample", "k_featurize", "k_ring", "k_scent", "k_observe")):
                 continue
             out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in cs.items()}
             # (every counter row of a dispatch repeats its timestamps: average over dispatches, not rows)
@@ -84,5 +88,5 @@ for cfg, per in summary.items():
         line["roofline"]["traffic"] = t
         line["roofline"]["traffic_source"] = f"{tag}_pmc_summary.json"
         if line["roofline"].get("avg_launch_us"):
-            line["roofline"]["stored_frac"] = t / (line["roofline"]["avg_launch_us"] * 1e-6) / 8e12
+            line["roofline"]["traffic_frac"] = t / (line["roofline"]["avg_launch_us"] * 1e-6) / 8e12
         json.dump(line, open(name, "w"))
