@@ -134,6 +134,21 @@ struct State {
     int64_t tape_len;
 };
 
+// The stepping kernels take (Consts, State, <args>, ObsArgs) by value.  A fused rollout needs State's thirteen pointers twice: in
+// its prologue (load the environments) and in its epilogue (store them); held in scalar registers across the tick loop they are
+// 26 SGPRs that push other values into spill lanes.  The epilogue therefore reads the struct AGAIN from the kernel-argument
+// segment, through a pointer the compiler cannot connect to the earlier loads (a handful of scalar loads, once per launch).
+constexpr uint32_t kStateArgOffset = (uint32_t)((sizeof(Consts) + alignof(State) - 1) / alignof(State) * alignof(State));
+template <class T>
+__device__ __forceinline__ T kernarg_reload(uint32_t byte_offset) {
+    typedef const __attribute__((address_space(4))) char *kernarg_ptr;
+    kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    T out;
+    __builtin_memcpy(&out, p + byte_offset, sizeof(T)); // (scalar loads: the address is wave-uniform, the segment constant)
+    return out;
+}
+
 // Packing of a tick's bounded draws into 32-bit words of the ACTION stream (production protocol; restated in
 // oracle/susnet_oracle.c so_action_layout).  The draws are the A action draws in agent order (base.py:326-330) and, with a
 // shuffled action order (np.random.shuffle, base.py:372-374), the A - 1 draws k = 1 .. A-1 (range k + 1) that place agent k
@@ -213,13 +228,6 @@ struct HasGroupWords { static constexpr bool value = !S::kGeneric && S::kStaticA
 // word = out[cursor & 3].  Identical mapping in oracle/susnet_oracle.c (philox_word).
 // a ^ b ^ c in ONE instruction (v_bitop3_b32, truth table 0x96): a Philox round is two multiplies and two of these
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
-// A wave-uniform value the compiler must treat as new at this point: the ten round keys of a Philox block (key + r * constant,
-// scalar registers) are then recomputed where a block is generated -- 18 scalar additions -- instead of being hoisted out of the
-// tick loop, where they held 18 SGPRs for the whole launch and pushed other values into spill lanes.
-__device__ __forceinline__ uint32_t fresh_scalar(uint32_t v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
 struct PhiloxRng {
     static constexpr bool kNumpy = false;
     uint32_t k0, k1, e0, e1;
@@ -235,7 +243,7 @@ struct PhiloxRng {
     }
     __device__ __forceinline__ void gen(uint64_t b) {
         uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32), c2 = e0, c3 = e1;
-        uint32_t a = fresh_scalar(k0), d = fresh_scalar(k1);
+        uint32_t a = k0, d = k1;
 #pragma unroll
         for (int r = 0; r < 10; r++) {
             uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -278,7 +286,7 @@ struct ActionStream {
     __device__ __forceinline__ void init() { blk = ~0ull; w0 = w1 = w2 = w3 = 0; rem = 0; }
     __device__ __forceinline__ void gen(const PhiloxRng &r, uint64_t b) {
         uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32) | kActionStreamTag, c2 = r.e0, c3 = r.e1;
-        uint32_t a = fresh_scalar(r.k0), d = fresh_scalar(r.k1);
+        uint32_t a = r.k0, d = r.k1;
 #pragma unroll
         for (int q = 0; q < 10; q++) {
             uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
 // OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
 // uint8 observation (the populate()-shaped record)
 enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4 };
+// the replay feed (term_obs, roles) only exists next to the full trajectory with the raw uint8 observation (susnet_rollout refuses
+// it elsewhere): the other instantiations carry neither the two pointers nor their per-tick tests
+__host__ __device__ constexpr bool kFeed(int out) { return out == OUT_TRAJ_RAW8; }
 // OUT_TRAJ = OUT_TRAJ_RAW8 without an observation; OUT_RECORD = the OUT_TRAJ_RAW8 fields packed into ONE record per
 // env-step (rewards f32[A] | actions u8[A] | done | truncated | raw obs u8[F], padded to a dword): a lane stores its
 // record with one or two wide stores through a single buffer descriptor instead of six stores through five
@@ -392,10 +395,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 if (pt != nullptr) *pt = trunc ? 1 : 0;
             }
             STAMP(4);
-            if (a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)S::imp(c, e.imp);
+            if (kFeed(OUT) && a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)S::imp(c, e.imp);
             if (__builtin_expect(done || trunc, 0)) {
                 life.add_episode(e, trunc);
-                if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
                     const int F = o.F;
                     uint8_t *p = a.term_obs + ((int64_t)tick * c.B + b) * F;
                     if constexpr (S::kRawF > 0) {
@@ -637,11 +640,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 if (pd != nullptr) *pd = done ? 1 : 0;
                 if (pt != nullptr) *pt = trunc ? 1 : 0;
             }
-            if (a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)swar_imp_bits(w);
+            if (kFeed(OUT) && a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)swar_imp_bits(w);
             KSTAMP(2);
             if (__builtin_expect(done || trunc, 0)) {
                 life.add_episode(e, trunc);
-                if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
                     uint32_t trow[(kRawF + 3) / 4];
                     raw_row_swar<S>(w, trow, (uint32_t)c.tag_interval);
                     store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
@@ -710,11 +713,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         }
 #endif
     if (active) {
+        const State se = kernarg_reload<State>(kStateArgOffset); // (not `s`: see kernarg_reload)
         from_swar<S>(c, w, st, e);
-        store_env<S>(c, s, st, b, e, true);
-        finish_rng(s, b, rng);
-        life.flush(c, s, b);
-        if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+        store_env<S>(c, se, st, b, e, true);
+        finish_rng(se, b, rng);
+        life.flush(c, se, b);
+        if (c.dev_tick) se.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     }
 }
 
@@ -834,10 +838,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             drec.st128(16u * h, __float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3]));
             drec.st32(4u * A + 4u * h, act);
         }
-        if (a.roles != nullptr && h == 0u) a.roles[(int64_t)tick * c.B + b] = (uint16_t)w.imp_bits;
+        if (kFeed(OUT) && a.roles != nullptr && h == 0u) a.roles[(int64_t)tick * c.B + b] = (uint16_t)w.imp_bits;
         if (__builtin_expect(done || trunc, 0)) { // (both lanes of the pair: done / truncated are the environment's)
             life.add_episode(e, trunc);
-            if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+            if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
                 Swar<S> f;
                 gather_swar2<S>(w, f);
                 uint32_t trow[(kRawF + 3) / 4];
@@ -885,10 +889,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
         from_swar<S>(c, f, st, e);
     }
     if (h == 0u) {
-        store_env<S>(c, s, st, b, e, true);
-        finish_rng(s, b, rng);
-        life.flush(c, s, b);
-        if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+        const State se = kernarg_reload<State>(kStateArgOffset); // (not `s`: see kernarg_reload)
+        store_env<S>(c, se, st, b, e, true);
+        finish_rng(se, b, rng);
+        life.flush(c, se, b);
+        if (c.dev_tick) se.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     }
 }
 
@@ -974,10 +979,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             dd.st8(0u, done);
             dt.st8(0u, trunc);
         }
-        if (a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)1u; // the imposter is agent 0 (pred_prey.py:52-66, shuffle off)
+        if (kFeed(OUT) && a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)1u; // the imposter is agent 0 (pred_prey.py:52-66, shuffle off)
         if (__builtin_expect((done | trunc) != 0u, 0)) {
             life.add_episode(e, trunc != 0u);
-            if (a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+            if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
                 PtrDst tp{a.term_obs + ((int64_t)tick * c.B + b) * 6};
                 tp.st32(0u, d.pq - k01);
                 tp.st16(4u, (d.al & 1u) | ((d.al & 2u) << 7));
@@ -1010,11 +1015,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             tick++;
         }
     }
+    const State se = kernarg_reload<State>(kStateArgOffset); // (not `s`: see kernarg_reload)
     from_duel(d, st, e);
-    store_env<S>(c, s, st, b, e, true);
-    finish_rng(s, b, rng);
-    life.flush(c, s, b);
-    if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
+    store_env<S>(c, se, st, b, e, true);
+    finish_rng(se, b, rng);
+    life.flush(c, se, b);
+    if (c.dev_tick) se.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
 }
 
 // configurations compiled in (BASELINE.json configs 2, 3/5, 4); anything else runs the generic kernels
