@@ -358,15 +358,17 @@ class OracleBatch:
             self.L.so_obs_raw(C.byref(self.envs[b]), out[b].ctypes.data_as(C.POINTER(C.c_double)))
         return out
 
-    def obs_flat(self, components) -> np.ndarray:
+    def obs_flat(self, components, envs=None) -> np.ndarray:
+        """FlatFeaturizer rows of every env (or of the env indices `envs`: big batches check a sample)."""
         comp = np.array([FLAT[c] if isinstance(c, str) else int(c) for c in components], dtype=np.int32)
         cp = comp.ctypes.data_as(C.POINTER(C.c_int32))
         n = self.L.so_obs_flat_size(C.byref(self.envs[0]), cp, len(comp))
         if n < 0:
             raise ValueError("unknown flat component")
-        out = np.zeros((self.B, n), dtype=np.float32)
-        for b in range(self.B):
-            rc = self.L.so_obs_flat(C.byref(self.envs[b]), cp, len(comp), out[b].ctypes.data_as(C.POINTER(C.c_float)))
+        idx = range(self.B) if envs is None else [int(b) for b in envs]
+        out = np.zeros((len(idx), n), dtype=np.float32)
+        for k, b in enumerate(idx):
+            rc = self.L.so_obs_flat(C.byref(self.envs[b]), cp, len(comp), out[k].ctypes.data_as(C.POINTER(C.c_float)))
             if rc < 0:
                 raise ValueError(f"flat component not applicable to this config (rc={rc})")
         return out

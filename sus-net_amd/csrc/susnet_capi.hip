@@ -812,7 +812,14 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool traj = all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8;
     const bool traj_noobs = all_traj && o.mode == SUSNET_OBS_NONE;
     const uint64_t AB = (uint64_t)env->c.A * (uint64_t)env->c.B;
-    const uint64_t tick_bytes = a.record ? (uint64_t)env->c.B * (uint64_t)a.record_bytes : std::max<uint64_t>(4u * AB, (uint64_t)o.tick_stride);
+    // the compiled-in float32 FlatFeaturizer layouts (susnet_flat.h): `onehot_pos` on the 1v1 9x9 game without walls, `onehot_pos +
+    // alive_crew + closest_crew` on the 1v2 14x14 game, next to the full trajectory, on the production stream
+    const bool flat1 = spec == 2 && env->c.duel_fast && env->c.N == 9 && o.ncomp == 1 && o.comp[0] == SUSNET_F_ONEHOT_POS;
+    const bool flat3 = spec == 3 && env->c.N == 14 && o.ncomp == 3 && o.comp[0] == SUSNET_F_ONEHOT_POS && o.comp[1] == SUSNET_F_ALIVE_CREW &&
+                       o.comp[2] == SUSNET_F_CLOSEST_CREW;
+    const bool traj_flat = all_traj && !tape && o.mode == SUSNET_OBS_FLAT && o.dtype == SUSNET_F32 && (flat1 || flat3) && !a.term_obs && !a.roles;
+    const uint64_t obs_tick_bytes = (uint64_t)o.tick_stride * (o.dtype == SUSNET_F32 ? 4u : 1u);
+    const uint64_t tick_bytes = a.record ? (uint64_t)env->c.B * (uint64_t)a.record_bytes : std::max<uint64_t>(4u * AB, traj_flat ? obs_tick_bytes : (uint64_t)o.tick_stride);
     const uint64_t limit = env->launch_limit; // (susnet_set_launch_limit; tests exercise the chunking on small batches)
     const uint64_t fit = limit / tick_bytes;
     if (a.record && fit < 1) return fail(env, SUSNET_E_INVALID, "susnet_rollout: one tick of records exceeds 2 GiB");
@@ -820,13 +827,14 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
                     : (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
                     : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
+                    : (traj_flat && fit >= 1)               ? OUT_TRAJ_FLAT
                                                             : OUT_ANY;
     if ((a.term_obs || a.roles) && !(all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8))
         return fail(env, SUSNET_E_INVALID, "susnet_rollout: term_obs / roles go with the full trajectory and the raw uint8 observation");
     if (tape && out != OUT_TRAJ_RAW8 && out != OUT_RECORD)
         return fail(env, SUSNET_E_INVALID, "susnet_rollout on a TAPE handle stores the full trajectory with the raw uint8 observation, as separate "
                                       "tensors or as packed records (nothing else)");
-    const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
+    const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD || out == OUT_TRAJ_FLAT) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);
         a.tick_base = env->ticks + (uint64_t)t0;
@@ -836,7 +844,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             a.rewards += (uint64_t)chunk * AB;
             a.done += (uint64_t)chunk * (uint64_t)env->c.B;
             a.trunc += (uint64_t)chunk * (uint64_t)env->c.B;
-            if (o.out) o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (uint64_t)o.tick_stride;
+            if (o.out) o.out = static_cast<uint8_t *>(o.out) + (uint64_t)chunk * (out == OUT_TRAJ_FLAT ? obs_tick_bytes : (uint64_t)o.tick_stride);
             if (a.term_obs) a.term_obs += (uint64_t)chunk * (uint64_t)o.tick_stride;
             if (a.roles) a.roles += (uint64_t)chunk * (uint64_t)env->c.B;
         }

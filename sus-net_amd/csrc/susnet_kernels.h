@@ -12,6 +12,7 @@
 #include "susnet_swar.h"
 #include "susnet_swar2.h"
 #include "susnet_duel.h"
+#include "susnet_flat.h"
 
 namespace susnet {
 
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
 // that is instruction-fetch bound): OUT_ANY = whatever pointers are non-null / any observation mode;
 // OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
 // uint8 observation (the populate()-shaped record)
-enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4 };
+enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4, OUT_TRAJ_FLAT = 5 };
+// OUT_TRAJ_FLAT = OUT_TRAJ + the float32 FlatFeaturizer row of the configuration's compiled-in layout (susnet_flat.h)
 // the replay feed (term_obs, roles) only exists next to the full trajectory with the raw uint8 observation (susnet_rollout refuses
 // it elsewhere): the other instantiations carry neither the two pointers nor their per-tick tests
 __host__ __device__ constexpr bool kFeed(int out) { return out == OUT_TRAJ_RAW8; }
@@ -528,8 +530,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     Env e = {};
     RNG rng = make_rng<RNG>(c, s, active ? b : 0);
     if (active) load_env<S>(c, s, st, b, e);
-    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
-    if ((kTraj || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
+    constexpr bool kFlat = OUT == OUT_TRAJ_FLAT; // (cooperative feature stores: every lane stays)
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ || kFlat;
+    if (((kTraj && !kFlat) || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
     W w;
     to_swar<S>(c, st, e, w);
     uint64_t tick_base = a.tick_base;
@@ -550,6 +553,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
     BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * kRawF));
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    // OUT_TRAJ_FLAT: the wave's float32 feature rows [B][F], written cooperatively (susnet_flat.h); base = the wave's first row
+    using FlatRowT = typename FlatFor<S>::Row;
+    BufDst dflat = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride * 4u, (uint32_t)b0 * (uint32_t)(FlatRowT::F * 4));
+    FlatRowT frow;
+    frow.clear();
     constexpr bool kRec = OUT == OUT_RECORD; // one packed record per env-step: rewards f32[A] | actions u8[A] | raw obs u8[F] | done | truncated | 0-padding
     constexpr int kRecDwords = RecordLayout<S>::kDwords;
     BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
@@ -667,6 +675,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
                 store_packed_bytes<kRawF>(dobs, row);
             }
+            if constexpr (kFlat) { // the feature row of the state after the step (and after an in-launch reset)
+                uint32_t fx[A], fy[A], fal[A];
+#pragma unroll
+                for (int i = 0; i < A; i++) {
+                    const uint32_t cell = (w.xy[i / 4] >> (8 * (i & 3))) & 0xffu;
+                    fx[i] = cell & 15u;
+                    fy[i] = cell >> 4;
+                    fal[i] = (w.al[i / 4] >> (8 * (i & 3))) & 1u;
+                }
+                frow.build(fx, fy, fal);
+            }
             if (kRec) { // (byte moves between statically known positions: the compiler folds them into v_perm / v_alignbyte)
                 uint32_t row[(kRawF + 3) / 4];
                 raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
@@ -702,6 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             if (active) from_swar<S>(c, w, st, e);
             write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
         }
+        if constexpr (kFlat) flat_store_wave(frow, T.stage, tid, nrows, dflat.r, dflat.vo + (uint32_t)tick * (slab_o * 4u));
     };
 #pragma clang loop unroll(disable)
     for (int tick = 0; tick < a.n_ticks; tick++) tick_body(tick);
@@ -912,29 +932,38 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     typename StoreFor<S>::type st;
     Tables T = setup_lds<S>(c, smem, tid, st);
     Env e = {};
-    if (!active) return; // no cooperative work past this point
-    load_env<S>(c, s, st, b, e);
-    RNG rng = make_rng<RNG>(c, s, b);
+    // OUT_TRAJ_FLAT stores the feature rows cooperatively, so every lane stays: a lane without an environment (ragged last
+    // wave, fewer than 64 environments per wave) mirrors environment 0 and its stores are dropped by the buffer range check
+    constexpr bool kFlat = OUT == OUT_TRAJ_FLAT;
+    if (!kFlat && !active) return; // no cooperative work past this point
+    const int nrows = (int)((c.B - b0) < c.epw ? (c.B - b0) : c.epw);
+    const int64_t bl = active ? b : 0;
+    const uint32_t ghost = active ? 0u : 0x7fffff00u; // added to per-lane buffer offsets: past the end of every array
+    load_env<S>(c, s, st, bl, e);
+    RNG rng = make_rng<RNG>(c, s, bl);
     ActionStream as;
     as.init();
     Duel d;
     to_duel(st, e, d);
     const DuelConsts k = make_duel_consts(c);
     uint64_t tick_base = a.tick_base;
-    if (c.dev_tick) tick_base = uniform64(s.tickw[active ? b : b0]); // (every env holds the same count)
+    if (c.dev_tick) tick_base = uniform64(s.tickw[bl]); // (every env holds the same count)
     LifeAcc life;
     life.clear();
-    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ;
+    constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ || kFlat;
     constexpr bool kRec = OUT == OUT_RECORD; // one 20-byte record per env-step: rewards | actions done truncated | x0 y0 x1 y1 | alive0 alive1 0 0
     const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     const uint64_t B = (uint64_t)c.B;
-    BufDst drec = make_buf_dst(a.record, nt * 20u * B, (uint32_t)b * 20u);
-    BufDst da = make_buf_dst(a.actions, nt * 2u * B, (uint32_t)b * 2u);
-    BufDst dr = make_buf_dst(a.rewards, nt * 8u * B, (uint32_t)b * 8u);
-    BufDst dd = make_buf_dst(a.done, nt * B, (uint32_t)b);
-    BufDst dt = make_buf_dst(a.trunc, nt * B, (uint32_t)b);
-    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)b * 6u);
+    BufDst drec = make_buf_dst(a.record, nt * 20u * B, (uint32_t)bl * 20u);
+    BufDst da = make_buf_dst(a.actions, nt * 2u * B, (uint32_t)bl * 2u + ghost);
+    BufDst dr = make_buf_dst(a.rewards, nt * 8u * B, (uint32_t)bl * 8u + ghost);
+    BufDst dd = make_buf_dst(a.done, nt * B, (uint32_t)bl + ghost);
+    BufDst dt = make_buf_dst(a.trunc, nt * B, (uint32_t)bl + ghost);
+    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)bl * 6u);
     const uint32_t slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
+    // OUT_TRAJ_FLAT: the wave's float32 feature rows [B][36] (susnet_flat.h); base = the wave's first row
+    using FlatRowT = typename FlatFor<S>::Row;
+    BufDst dflat = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride * 4u, (uint32_t)b0 * (uint32_t)(FlatRowT::F * 4));
     if (a.n_ticks > 0) {
         clear_info_if_fresh(e); // once per launch instead of once per tick
         rng.align();            // the first step aligns the event-stream cursor; later steps find it aligned (see below)
@@ -1003,6 +1032,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             drec.st128(0u, __float_as_uint(r0), __float_as_uint(r1), a0 | (a1 << 8) | (done << 16) | (trunc << 24), d.pq - k01);
             drec.st32(16u, (d.al & 1u) | ((d.al & 2u) << 7));
         }
+        if constexpr (kFlat) { // onehot_pos of the state after the step (and after an in-launch reset)
+            const uint32_t pos = d.pq - k01;
+            const uint32_t fx[2] = {pos & 0xffu, (pos >> 16) & 0xffu}, fy[2] = {(pos >> 8) & 0xffu, pos >> 24}, fal[2] = {d.al & 1u, d.al >> 1};
+            FlatRowT frow;
+            frow.build(fx, fy, fal);
+            flat_store_wave(frow, T.stage, tid, nrows, dflat.r, dflat.vo + (uint32_t)tick * (slab_o * 4u));
+        }
     };
     constexpr int kGroup = RNG::kNumpy ? 0 : 4 * kDuelTicksPerWord;
     int tick = 0;
@@ -1015,6 +1051,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             tick++;
         }
     }
+    if (kFlat && !active) return;
     const State se = kernarg_reload<State>(kStateArgOffset); // (not `s`: see kernarg_reload)
     from_duel(d, st, e);
     store_env<S>(c, se, st, b, e, true);
@@ -1042,8 +1079,9 @@ template <class SPEC>
 void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
     constexpr bool kDuelSpec = !SPEC::kGeneric && SPEC::kA == 2 && SPEC::kJ == 0 && SPEC::kVar == SUSNET_VARIANT_ITG && SPEC::kStaticRoles && SPEC::kFixedOrder;
     if constexpr (kDuelSpec) {
-        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD)) { // susnet_duel.h
-            if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
+        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD || out == OUT_TRAJ_FLAT)) { // susnet_duel.h
+            if (out == OUT_TRAJ_FLAT) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_FLAT>), g, blk, sh, st, c, s, a, o);
+            else if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
             else if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_NONE>), g, blk, sh, st, c, s, a, o);
@@ -1064,7 +1102,9 @@ void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t
         }
     }
     if constexpr (UseSwar<SPEC>::value) {
-        if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_RECORD, TapeRng>), g, blk, sh, st, c, s, a, o);
+        if (out == OUT_TRAJ_FLAT) {
+            if constexpr (FlatFor<SPEC>::kOk) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_FLAT>), g, blk, sh, st, c, s, a, o);
+        } else if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_RECORD, TapeRng>), g, blk, sh, st, c, s, a, o);
         else if (tape) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8, TapeRng>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_NONE>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);

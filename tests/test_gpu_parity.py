@@ -875,6 +875,48 @@ def test_featurize_matches_oracle_on_tagging_rows(pkg, oracle_mod):
     assert torch.equal(flat, traj3["obs"])
 
 
+@pytest.mark.parametrize("name,comps,B", [("itg_1v1_nowalls", ["onehot_pos"], 1000), ("itg_1v1_nowalls", ["onehot_pos"], 65536 + 40),
+                                          ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], 1000),
+                                          ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], 65536 + 8)])
+def test_compiled_in_flat_feature_rollouts_match_the_oracle(pkg, oracle_mod, name, comps, B):
+    """The specialised float32 FlatFeaturizer writers of the fused rollout (susnet_flat.h: rows built as bit masks, stored
+    cooperatively) for the two layouts the reference's experiments use: every tick's actions / rewards / flags and the feature
+    rows of the post-step (post-reset) state against the oracle's restatement of the reference featurizers, at 16 and 64
+    environments per wave with a ragged last wave, and across a chunked launch."""
+    T, seed = (40 if B < 4096 else 6), 17
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
+    env.reset()
+    ob.reset(threads=0)
+    cfg = pkg.ObsConfig("flat", comps)
+    F = {"itg_1v1_nowalls": 36, "base_1v2_j4_14": 88}[name]
+    # big batches: the rows of a sample of envs (the first and the last, ragged, waves and a random draw)
+    pick = np.arange(B) if B < 4096 else np.unique(np.concatenate([np.arange(256), np.arange(B - 300, B), np.random.default_rng(3).integers(0, B, 600)]))
+    for n in (T, 3):
+        env.set_launch_limit(7 * B * F * 4 + 64 if n == T and B < 4096 else 0)  # small batch: 7 ticks per launch
+        traj = env.rollout(n, obs=cfg)
+        torch.cuda.synchronize()
+        assert traj["obs"].shape == (n, B, F) and traj["obs"].dtype == torch.float32
+        obs = np_(traj["obs"])
+        for s in range(n):
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(traj["actions"])[s], oa, err_msg=f"{name} actions tick {s}")
+            orew, odone, otrunc, _ = ob.step(oa, threads=0)
+            assert np.array_equal(np_(traj["rewards"])[s].astype(np.float64).view(np.uint64), orew.view(np.uint64))
+            np.testing.assert_array_equal(np_(traj["done"])[s], odone.astype(bool))
+            np.testing.assert_array_equal(np_(traj["truncated"])[s], otrunc.astype(bool))
+            ob.reset(mask=(odone | otrunc).astype(bool))
+            np.testing.assert_array_equal(obs[s][pick], ob.obs_flat(comps, envs=pick), err_msg=f"{name} flat features tick {s}")
+    env._export(full=True)
+    compare_full_state(env, ob, f"{name} after flat-feature rollouts")
+    # the generic writer (any component list: here with one more component) agrees on the shared columns
+    env2, _ = make_pair(pkg, oracle_mod, name, min(B, 2048), seed, auto_reset=True, check_errors=False)
+    env3, _ = make_pair(pkg, oracle_mod, name, min(B, 2048), seed, auto_reset=True, check_errors=False)
+    env2.reset(); env3.reset()
+    a = env2.rollout(12, obs=cfg)["obs"]
+    b = env3.rollout(12, obs=pkg.ObsConfig("flat", comps + ["coord_pos"]))["obs"]
+    assert torch.equal(a, b[:, :, :F])
+
+
 def test_small_attribute_mirrors(pkg):
     """crew_idxs (base.py:283), agent_rewards (base.py:369,387), compute_state_dims (base.py:565-579: values recorded
     from the reference for FourRoomEnv(1, 2, 4) and FourRoomEnvWithTagging(1, 4, 5), its 2x2 quirk included)."""
