@@ -186,6 +186,49 @@ __global__ __launch_bounds__(kBlock) void k_featurize(Consts c, const void *rows
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
 
+// susnet_featurize for the two compiled-in float32 FlatFeaturizer layouts (susnet_flat.h): a lane parses the few fields its row
+// needs (cells and alive flags lead every flattened state, base.py:234-235), builds the row's bit mask, and the wave writes its 64
+// rows cooperatively.  The generic kernel above zero-fills a byte image, walks a run-time component list and expands the image;
+// it keeps serving every other layout.
+template <class ROW>
+__global__ __launch_bounds__(kBlock) void k_featurize_flat(Consts c, const void *rows, int dtype, int64_t n_rows, int S_row, uint32_t *err, float *out) {
+    extern __shared__ uint32_t smem[];
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+    const int nrows = (int)((n_rows - b0) < kBlock ? (n_rows - b0) : kBlock);
+    constexpr int A = ROW::A, N = ROW::N;
+    ROW row;
+    row.clear();
+    if (b < n_rows) {
+        const int64_t base = b * S_row;
+        int v[3 * A];
+        if (dtype == SUSNET_U8) { // (wave-uniform: one branch for all the row's loads, which then issue back to back)
+#pragma unroll
+            for (int k = 0; k < 3 * A; k++) v[k] = (int)static_cast<const uint8_t *>(rows)[base + k];
+        } else if (dtype == SUSNET_F32) {
+#pragma unroll
+            for (int k = 0; k < 3 * A; k++) v[k] = (int)static_cast<const float *>(rows)[base + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3 * A; k++) v[k] = row_value(rows, dtype, base + k);
+        }
+        uint32_t x[A], y[A], al[A];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            ok = ok && (unsigned)v[2 * i] < (unsigned)N && (unsigned)v[2 * i + 1] < (unsigned)N;
+            x[i] = (uint32_t)v[2 * i] & 15u;
+            y[i] = (uint32_t)v[2 * i + 1] & 15u;
+            al[i] = v[2 * A + i] != 0 ? 1u : 0u;
+        }
+        if (ok) row.build(x, y, al);
+        else atomicOr(err, SUSNET_ERRBIT_ROW); // the row stays all zeros, like the generic kernel's
+    }
+    // a buffer of this wave's rows only: no 2 GiB limit on the whole output
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(out + b0 * ROW::F, 0, nrows * ROW::F * 4, 0x00020000);
+    flat_store_wave(row, smem, tid, nrows, r, 0u);
+}
+
 static int pick_spec(const Consts &c, bool float_exact, bool force_generic) {
     if (!float_exact) return 0; // compiled-in kernels do the reward arithmetic in float32
     if (force_generic) return 0; // (tests: the same fixtures through the generic LDS-table kernels)
@@ -910,6 +953,7 @@ struct RingArgs {
     susnet_ring_io io;
     int64_t B, n0, n1; // envs; first / one-past-last transition (n = tick * B + env) this launch writes
     int32_t A, S, n_imp;
+    int32_t rows_per_wave; // 64, or fewer when 64 rows of 2 x trajectory_size x S bytes would not fit the LDS images
 };
 // the flattened state an env's window holds at virtual tick u (= the state after tick u; u < 0: the carried-in window)
 __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t u, int64_t b) {
@@ -917,7 +961,7 @@ __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t 
     if (u < 0) return r.io.window + ((size_t)b * Tw + (size_t)(Tw + u < 0 ? 0 : Tw + u)) * r.S; // window[Tw - 1] = state before tick 0
     return r.io.obs + ((size_t)u * r.B + b) * r.S;
 }
-// One wave per 64 consecutive transitions.  Lane r gathers what its row needs into flat images in LDS, laid out exactly as the
+// One wave per 64 consecutive transitions (32 / 16 / 8 for long windows: RingArgs::rows_per_wave).  Lane r gathers what its row needs into flat images in LDS, laid out exactly as the
 // wave's 64 rows lie in each ring tensor (row-major; `states` and `next_states`: Tw * S bytes per row, the Tw - 1 shared states
 // written to both; actions, rewards, done, imposters likewise), and the wave then writes every tensor as ONE linear range:
 // 16 bytes per lane and step, no index arithmetic.  Two things made the first version slow (3.1-3.5 TB/s, 82 % of the wave cycles
@@ -929,15 +973,16 @@ constexpr int kRingFlagsUnroll = 8;
 __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A, NI = r.n_imp;
-    const int64_t n_first = r.n0 + (int64_t)blockIdx.x * 64, n = n_first + lane;
-    const int rows = (int)((r.n1 - n_first) < 64 ? (r.n1 - n_first) : 64);
+    const int R = r.rows_per_wave;
+    const int64_t n_first = r.n0 + (int64_t)blockIdx.x * R, n = n_first + lane;
+    const int rows = (int)((r.n1 - n_first) < R ? (r.n1 - n_first) : R);
     const int TS = Tw * S;
-    const int img = (64 * TS + 15) & ~15; // bytes of one state image (padded: the vector loops read up to 3 bytes past the last row)
+    const int img = (R * TS + 15) & ~15; // bytes of one state image (padded: the vector loops read up to 3 bytes past the last row)
     uint8_t *st_img = reinterpret_cast<uint8_t *>(smem), *nx_img = st_img + img;
-    float *rew_img = reinterpret_cast<float *>(nx_img + img);         // [64][A]
-    uint8_t *act_img = reinterpret_cast<uint8_t *>(rew_img + 64 * A); // [64][A] (+ pad)
-    uint8_t *done_img = act_img + ((64 * A + 15) & ~15);              // [64]
-    int16_t *imp_img = reinterpret_cast<int16_t *>(done_img + 64);    // [64][NI]
+    float *rew_img = reinterpret_cast<float *>(nx_img + img);        // [R][A]
+    uint8_t *act_img = reinterpret_cast<uint8_t *>(rew_img + R * A); // [R][A] (+ pad)
+    uint8_t *done_img = act_img + ((R * A + 15) & ~15);              // [R]
+    int16_t *imp_img = reinterpret_cast<int16_t *>(done_img + 64);   // [R][NI]
     if (lane < rows) {
         const int64_t t = n / r.B, b = n % r.B;
         // most recent episode boundary before tick t within the window's reach (the episode's first state is obs[e]); all flag
@@ -960,22 +1005,40 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
         const uint32_t dn = r.io.done[t * r.B + b], tr = r.io.truncated[t * r.B + b];
         const uint32_t role_bits = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << NI) - 1u);
         uint8_t *my_st = st_img + (size_t)lane * TS, *my_nx = nx_img + (size_t)lane * TS;
+        // a state row = S consecutive bytes at an arbitrary address: fetched as S / 4 UNALIGNED dwords + a byte tail (gfx950
+        // serves unaligned global loads) -- a row of 21 bytes is 6 load instructions instead of 21; the LDS images take bytes
+        const int S4 = S >> 2;
         for (int k = 0; k < Tw; k++) { // replay_memory.py:108-113, 122-127
             int64_t u = t - Tw + k;
             if (u < e) u = e;
             const uint8_t *src = ring_state(r, u, b);
-            if (k == 0) {
-                for (int f = 0; f < S; f++) my_st[f] = src[f];
-            } else {
-                for (int f = 0; f < S; f++) {
-                    const uint8_t v = src[f];
-                    my_st[k * S + f] = v;
-                    my_nx[(k - 1) * S + f] = v;
+            uint8_t *d0 = my_st + k * S, *d1 = k > 0 ? my_nx + (k - 1) * S : nullptr;
+            for (int j = 0; j < S4; j++) {
+                uint32_t v;
+                __builtin_memcpy(&v, src + 4 * j, 4);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    d0[4 * j + q] = (uint8_t)(v >> (8 * q));
+                    if (d1) d1[4 * j + q] = (uint8_t)(v >> (8 * q));
                 }
+            }
+            for (int f = 4 * S4; f < S; f++) {
+                const uint8_t v = src[f];
+                d0[f] = v;
+                if (d1) d1[f] = v;
             }
         }
         const uint8_t *nxt = ((dn | tr) ? r.io.term_obs : r.io.obs) + ((size_t)t * r.B + b) * S;
-        for (int f = 0; f < S; f++) my_nx[(Tw - 1) * S + f] = nxt[f];
+        {
+            uint8_t *d = my_nx + (Tw - 1) * S;
+            for (int j = 0; j < S4; j++) {
+                uint32_t v;
+                __builtin_memcpy(&v, nxt + 4 * j, 4);
+#pragma unroll
+                for (int q = 0; q < 4; q++) d[4 * j + q] = (uint8_t)(v >> (8 * q));
+            }
+            for (int f = 4 * S4; f < S; f++) d[f] = nxt[f];
+        }
         for (int i = 0; i < A; i++) {
             act_img[lane * A + i] = r.io.actions[((size_t)t * r.B + b) * A + i];
             rew_img[lane * A + i] = r.io.rewards[((size_t)t * r.B + b) * A + i];
@@ -1079,12 +1142,19 @@ extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, voi
     const int64_t total = (int64_t)io->n_ticks * r.B;
     r.n0 = total > io->max_size ? total - io->max_size : 0; // (earlier rows would be overwritten by later ones of this same launch)
     r.n1 = total;
-    // the row images of k_ring_append: states, next_states (bytes), rewards (f32), actions (bytes), done, imposters (i16)
-    const size_t sh = 2 * (((size_t)64 * (size_t)io->trajectory_size * (size_t)r.S + 15) & ~(size_t)15) + (size_t)64 * r.A * 4 +
-                      (((size_t)64 * r.A + 15) & ~(size_t)15) + 64 + (size_t)64 * r.n_imp * 2 + 16;
-    if (sh > 64 * 1024) return fail(SUSNET_E_INVALID, "susnet_ring_append: trajectory_size x state size too large");
+    // the row images of k_ring_append: states, next_states (bytes), rewards (f32), actions (bytes), done, imposters (i16); a wave
+    // takes 64 rows, or 32 / 16 / 8 when the window is long (trajectory_size x S bytes per row, twice): the reference's
+    // ReplayBuffer accepts any trajectory_size (replay_memory.py:33-44)
+    auto images = [&](size_t R) {
+        return 2 * ((R * (size_t)io->trajectory_size * (size_t)r.S + 15) & ~(size_t)15) + R * r.A * 4 + ((R * r.A + 15) & ~(size_t)15) + 64 +
+               R * r.n_imp * 2 + 16;
+    };
+    r.rows_per_wave = 64;
+    while (r.rows_per_wave > 8 && images((size_t)r.rows_per_wave) > 64 * 1024) r.rows_per_wave /= 2;
+    const size_t sh = images((size_t)r.rows_per_wave);
+    if (sh > 64 * 1024) return fail(SUSNET_E_INVALID, "susnet_ring_append: trajectory_size x state size too large (8 rows of the window exceed 64 KiB)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t waves = (r.n1 - r.n0 + 63) / 64;
+    const int64_t waves = (r.n1 - r.n0 + r.rows_per_wave - 1) / r.rows_per_wave;
     hipLaunchKernelGGL(k_ring_append, dim3((unsigned)waves), dim3(64), sh, st, r);
     hipLaunchKernelGGL(k_ring_window, dim3((unsigned)((r.B + 63) / 64)), dim3(64), 0, st, r);
     HIP_TRY(hipGetLastError());
@@ -1115,9 +1185,26 @@ extern "C" int susnet_featurize(susnet_env *env, const void *rows, int32_t rows_
     if (n_rows == 0) return SUSNET_OK;
     ObsArgs o;
     if (int rc = build_obs(env, obs, o, n_rows)) return rc;
+    const dim3 g((unsigned)((n_rows + kBlock - 1) / kBlock));
+    const Consts &c = env->c;
+    if (o.mode == SUSNET_OBS_FLAT && o.dtype == SUSNET_F32 && !env->force_generic) { // the compiled-in layouts (susnet_flat.h)
+        using Row1 = FlatRow<FEAT_ONEHOT, 2, 9>;
+        using Row3 = FlatRow<FEAT_ONEHOT_ALIVE_CLOSEST, 3, 14>;
+        if (c.A == 2 && c.N == 9 && o.ncomp == 1 && o.comp[0] == SUSNET_F_ONEHOT_POS) {
+            hipLaunchKernelGGL(k_featurize_flat<Row1>, g, dim3(kBlock), 64 * Row1::MW * 4, static_cast<hipStream_t>(stream), c, rows, (int)rows_dtype,
+                               n_rows, (int)env->layout.obs_raw_size, env->s.err, static_cast<float *>(o.out));
+            HIP_TRY(hipGetLastError());
+            return SUSNET_OK;
+        }
+        if (c.A == 3 && c.N == 14 && o.ncomp == 3 && o.comp[0] == SUSNET_F_ONEHOT_POS && o.comp[1] == SUSNET_F_ALIVE_CREW && o.comp[2] == SUSNET_F_CLOSEST_CREW) {
+            hipLaunchKernelGGL(k_featurize_flat<Row3>, g, dim3(kBlock), 64 * Row3::MW * 4, static_cast<hipStream_t>(stream), c, rows, (int)rows_dtype,
+                               n_rows, (int)env->layout.obs_raw_size, env->s.err, static_cast<float *>(o.out));
+            HIP_TRY(hipGetLastError());
+            return SUSNET_OK;
+        }
+    }
     size_t sh = lds_bytes(env, o, false);
     CHECK_LDS(sh);
-    const dim3 g((unsigned)((n_rows + kBlock - 1) / kBlock));
     hipLaunchKernelGGL(k_featurize, g, dim3(kBlock), sh, static_cast<hipStream_t>(stream), env->c, rows, (int)rows_dtype, n_rows,
                        (int)env->layout.obs_raw_size, env->s.err, o);
     HIP_TRY(hipGetLastError());

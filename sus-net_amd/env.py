@@ -297,8 +297,10 @@ class BatchedFourRoomEnv:
         A, N = self.n_agents, self.n_rows
         shape1 = (*lead, A + 2, N, N) if oc.mode == "planes" else (*lead, A, A + 2, N, N) if oc.mode == "persp" else (*lead, f1.value)
         shape2 = (*lead, A, f2.value // A) if oc.mode == "persp" else (*lead, f2.value)
-        out = torch.zeros(shape1, dtype=oc.dtype, device=self.device)
-        out2 = torch.zeros(shape2, dtype=oc.dtype, device=self.device) if f2.value else None
+        # (every observation kernel writes every row in full -- rows it rejects as zeros -- so the buffers are not pre-filled:
+        # a memset of a 700 MB feature batch cost as much as the kernel that fills it)
+        out = torch.empty(shape1, dtype=oc.dtype, device=self.device)
+        out2 = torch.empty(shape2, dtype=oc.dtype, device=self.device) if f2.value else None
         spec.out = out.data_ptr()
         spec.out2 = out2.data_ptr() if out2 is not None else None
         return spec, out, out2

@@ -855,6 +855,46 @@ def test_featurize_flattened_state_windows_matches_reference_fixtures(pkg, oracl
             env.poll_errors()
 
 
+@pytest.mark.parametrize("fixture,comps", [("feat_itg_1v1_nowalls", ["onehot_pos"]),
+                                           ("feat_base14_1v2_j4", ["onehot_pos", "alive_crew", "closest_crew"])])
+def test_compiled_in_featurize_layouts_match_reference_fixtures(pkg, fixture, comps, monkeypatch):
+    """The specialised susnet_featurize kernels (k_featurize_flat<FlatRow<..>>: the two FlatFeaturizer layouts the reference's
+    experiments use) on the reference's own flattened states, in every accepted row dtype, against the reference featurizers'
+    golden vectors; ragged tail, a bad row, and bit-equality with the generic kernel (a handle created under
+    SUSNET_FORCE_GENERIC) on rows from a fused rollout."""
+    g = load_golden(f"{GOLDEN_DIR}/{fixture}.npz")
+    meta = g["meta"]
+    env = env_from_meta(pkg, meta, 8, rng="philox")  # the handle only supplies the configuration
+    env.reset()
+    n = len(g["raw"])
+    want = np.concatenate([g["flat_" + c] for c in comps], axis=1)
+    rows64 = torch.from_numpy(g["raw"])
+    for dt in (torch.float64, torch.float32, torch.uint8, torch.int32, torch.int64):
+        got = np_(env.featurize(rows64.to(dt), pkg.ObsConfig("flat", comps)))
+        assert got.shape == want.shape and got.view(np.uint32).tolist() == want.view(np.uint32).tolist(), (fixture, dt)
+    assert n % 64 != 0 or np.array_equal(np_(env.featurize(rows64[:70], pkg.ObsConfig("flat", comps))), want[:70])  # ragged tail
+    bad = rows64[:70].clone()
+    bad[5, 1] = 99.0  # y far outside the grid
+    with pytest.raises(IndexError):
+        env.featurize(bad, pkg.ObsConfig("flat", comps))
+    env.check_errors = False
+    got = np_(env.featurize(bad, pkg.ObsConfig("flat", comps)))
+    assert not got[5].any() and np.array_equal(got[6], want[6]) and np.array_equal(got[4], want[4])
+    with pytest.raises(IndexError):
+        env.poll_errors()
+    # rows of real rollout states: specialised == generic kernel, bit for bit
+    env.check_errors = True
+    roll = env_from_meta(pkg, meta, 4096 + 24, rng="philox", auto_reset=True)
+    roll.reset()
+    rows = roll.rollout(9, obs=pkg.ObsConfig("raw", dtype=torch.uint8))["obs"].reshape(-1, roll.flattened_state_size)
+    monkeypatch.setenv("SUSNET_FORCE_GENERIC", "1")
+    gen = env_from_meta(pkg, meta, 8, rng="philox")
+    assert gen.native_layout().test_overrides & 1
+    gen.reset()
+    for dt in (torch.uint8, torch.float32):
+        assert torch.equal(env.featurize(rows.to(dt), pkg.ObsConfig("flat", comps)), gen.featurize(rows.to(dt), pkg.ObsConfig("flat", comps)))
+
+
 def test_featurize_matches_oracle_on_tagging_rows(pkg, oracle_mod):
     """Rows with the tagging fields (used, tag_counts, timer_left): raw rows written by the fused rollout of a
     tagging game go back through susnet_featurize and must give the fused planes observation of the same states."""
@@ -1191,16 +1231,21 @@ def test_native_replay_ring_matches_reference_populate(pkg, name):
     np.testing.assert_array_equal(np_(buf.imposters[:n]), np.sort(g["imposters"], axis=1), err_msg="imposters")
 
 
-def test_native_replay_ring_batched_matches_a_host_rebuild(pkg):
+@pytest.mark.parametrize("game,T", [("base_1v2", 3), ("tagging_1v4", 14), ("base_2v6", 29)])
+def test_native_replay_ring_batched_matches_a_host_rebuild(pkg, game, T):
     """Many envs, odd launch lengths, a ring smaller than the run: every row the ring holds equals what replaying the
     trajectory on the host with ReplayBuffer.populate's rules gives (window roll, first state repeated after a reset, true
-    terminal next state, `done` only), at position (rows added so far) % max_size."""
-    B, T, max_size = 300, 3, 4000
-    env = pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False)
+    terminal next state, `done` only), at position (rows added so far) % max_size.  The long windows (14 x 41 bytes, 29 x 36
+    bytes per row) do not fit 64 rows into the kernel's LDS images: a wave then takes 32 / 16 rows (RingArgs::rows_per_wave)."""
+    B, max_size = 300, 4000
+    mk = {"base_1v2": lambda: pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False),
+          "tagging_1v4": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 5, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False),
+          "base_2v6": lambda: pkg.BatchedFourRoomEnv(2, 6, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False)}[game]
+    env = mk()
     S, A = env.flattened_state_size, env.n_agents
-    buf = pkg.DeviceReplayBuffer(max_size, S, T, A, 1, device=env.device)
+    buf = pkg.DeviceReplayBuffer(max_size, S, T, A, env.n_imposters, device=env.device)
     # host model: same env / seed stepped through the fused rollout in the same launch pattern
-    env2 = pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False)
+    env2 = mk()
     raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
     env2.reset()
     first = np_(env2.observe(raw8))

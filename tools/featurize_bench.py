@@ -23,7 +23,8 @@ def main():
     for name, oc, rows in (("flat f32 (policy components) from u8 rows", pkg.ObsConfig("flat", POLICY_COMPONENTS, dtype=torch.float32), rows_u8),
                            ("flat f32 from f32 rows (replay batch)", pkg.ObsConfig("flat", POLICY_COMPONENTS, dtype=torch.float32), rows_u8.float()),
                            ("planes f32 from u8 rows", pkg.ObsConfig("planes", dtype=torch.float32), rows_u8[: 1 << 19])):
-        out = env.featurize(rows, oc)
+        for _ in range(3):  # (the caching allocator needs two live output blocks before a call stops reaching hipMalloc)
+            out = env.featurize(rows, oc)
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(5):
