@@ -16,6 +16,12 @@ Two ways to fill the ring:
   exactly ``ReplayBuffer.populate``'s window / terminal-state semantics (pinned against the reference's own buffers,
   tests/golden/replay_*.npz).
 * ``populate`` / ``add_batch``: per-tick torch glue over the step API (kept for callers that step the env themselves).
+
+One documented difference: ``imposters`` holds each episode's imposter indices in ASCENDING order (the kernels carry the
+roles as a bitmask).  The reference stores ``env.imposter_idxs`` in numpy's draw order (``np.random.choice``, base.py:274),
+so with ``n_imposters >= 2`` and ``shuffle_imposter_index`` a row can read ``[5, 2]`` there and ``[2, 5]`` here -- the same
+set; every consumer in the reference (train.py:398-416) uses the row as a set (``agent_idx in imposters``).  With one
+imposter, and with the shuffle off, the rows are identical.
 """
 from __future__ import annotations
 

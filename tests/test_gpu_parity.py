@@ -1227,8 +1227,12 @@ def test_native_replay_ring_matches_reference_populate(pkg, name):
     np.testing.assert_array_equal(np_(buf.actions[:n]), g["actions"].astype(np.int64), err_msg="actions")
     assert np_(buf.rewards[:n]).view(np.uint32).tolist() == g["rewards"].view(np.uint32).tolist(), "rewards"
     np.testing.assert_array_equal(np_(buf.dones[:n]), g["dones"].astype(bool), err_msg="dones")
-    # (the reference keeps numpy's draw order of the imposter indices, the ring stores them ascending)
-    np.testing.assert_array_equal(np_(buf.imposters[:n]), np.sort(g["imposters"], axis=1), err_msg="imposters")
+    # the reference keeps numpy's draw order of the imposter indices, the ring stores them ascending (sus-net_amd/replay.py): the
+    # rows are compared as they are wherever the order is defined by the data (one imposter, or no shuffle), as sets otherwise
+    if meta["n_imposters"] == 1 or not meta["kwargs"].get("shuffle_imposter_index", True):
+        np.testing.assert_array_equal(np_(buf.imposters[:n]), g["imposters"], err_msg="imposters")
+    else:
+        np.testing.assert_array_equal(np_(buf.imposters[:n]), np.sort(g["imposters"], axis=1), err_msg="imposters (as sets)")
 
 
 @pytest.mark.parametrize("game,T", [("base_1v2", 3), ("tagging_1v4", 14), ("base_2v6", 29)])
