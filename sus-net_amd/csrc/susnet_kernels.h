@@ -570,24 +570,27 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     GW gw;
     gw.init(kGroupWordsWord<S>(), tid);
     // SOFTWARE PIPELINE (production stream): a tick's actions and turn ranks depend on nothing but the tick index and the
-    // episode's roles, so tick t + 1 is sampled while tick t steps -- the LDS round trips of the words, of the rank tables and of
-    // the step's own lookups overlap instead of queueing up behind one another (28 % of the wave's cycles were parked on
-    // s_waitcnt with the stages in sequence).  A reset at tick t changes the roles: the lanes that reset re-derive their
-    // actions and ranks of tick t + 1 from the same words inside the (rare) reset branch.
+    // episode's roles, so tick t + 1 is sampled while tick t steps, in three stages placed where other work covers their LDS
+    // round trips (with the stages in sequence 28 % of the wave's cycles were parked on s_waitcnt):
+    //   A  top of tick t          read the words of tick t + 1 (refill the group first if t + 1 starts one)
+    //   B  middle of tick t       (after the kill section) action digits of t + 1 from those words, rank-table reads ISSUED
+    //   C  top of tick t + 1      rank bytes from the table words that arrived long ago
+    // A reset at tick t changes the roles: the lanes that reset redo B from the same words inside the (rare) reset branch.
 #ifdef SUSNET_STAMPS
     unsigned long long wseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wseg2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wprev = 0;
 #define KSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); wseg[k] += tn - wprev; wprev = tn; } while (0)
 #else
 #define KSTAMP(k) do {} while (0)
 #endif
-    uint32_t act_n[NW], R_n[NW];
+    uint32_t act_n[NW];
+    RankRaw raw_n = {0u, 0u, 0u, 0u};
     TickWords<GW::W> tw_n;
 #pragma unroll
-    for (int q = 0; q < NW; q++) act_n[q] = R_n[q] = 0u;
+    for (int q = 0; q < NW; q++) act_n[q] = 0u;
 #pragma unroll
     for (int k = 0; k < GW::W; k++) tw_n.wd[k] = 0u;
     tw_n.rem = 0u;
-    auto sample_tick = [&](int tick, bool first) __attribute__((always_inline)) {
+    auto stage_a = [&](int tick, bool first) __attribute__((always_inline)) {
         if constexpr (!RNG::kNumpy) {
             const uint64_t gt = tick_base + (uint64_t)tick;
             const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
@@ -597,13 +600,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             }
 #pragma unroll
             for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
-            TickWords<GW::W> tw = tw_n;
-            sample_actions_swar<S, 0>(c, w, rng, tw, gt, act_n);
-            if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R_n);
-            else identity_ranks<S>(R_n);
         }
     };
-    if (!RNG::kNumpy && active && a.n_ticks > 0) sample_tick(0, true);
+    auto stage_b = [&]() __attribute__((always_inline)) {
+        if constexpr (!RNG::kNumpy) {
+            TickWords<GW::W> tw = tw_n;
+            sample_actions_swar<S, 0>(c, w, rng, tw, 0ull, act_n);
+            if constexpr (RankLut<S>::kOk) raw_n = ranks_lut_issue<S, 0>(rng, tw, 0ull);
+        }
+    };
+    if (!RNG::kNumpy && active && a.n_ticks > 0) {
+        stage_a(0, true);
+        stage_b();
+    }
     auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) { // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index, nothing loop-carried
             const uint32_t t32 = (uint32_t)tick;
@@ -625,8 +634,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 wprev = __builtin_readcyclecounter();
 #endif
 #pragma unroll
-                for (int q = 0; q < NW; q++) { act[q] = act_n[q]; R[q] = R_n[q]; }
-                sample_tick(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
+                for (int q = 0; q < NW; q++) act[q] = act_n[q];
+                if constexpr (RankLut<S>::kOk) ranks_lut_finish<S>(raw_n, R); // stage C
+                else identity_ranks<S>(R);
+                stage_a(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
                 KSTAMP(0);
             }
             if (kTraj) store_packed_bytes<A>(da, act);
@@ -634,9 +645,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             float rr[A];
             bool done, trunc;
 #ifdef SUSNET_STAMPS
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2, stage_b);
 #else
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, nullptr, stage_b);
 #endif
             KSTAMP(1);
             if (kTraj) {
@@ -659,12 +670,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 }
                 reset_env<S>(c, T, st, tid, e, rng);
                 to_swar<S>(c, st, e, w);
-                if constexpr (!RNG::kNumpy) { // new roles: the next tick's actions again, from the words already fetched -- and its
-                    // turn ranks, whose digits continue what the action draws (role-dependent ranges) left of their last word
-                    TickWords<GW::W> tw = tw_n;
-                    sample_actions_swar<S, 0>(c, w, rng, tw, 0ull, act_n);
-                    if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, 0ull, R_n);
-                }
+                // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
+                // continue what the action draws (role-dependent ranges) left of their last word
+                stage_b();
                 // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed
                 if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
                 else zero_metrics(e);
@@ -793,14 +801,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     using GW = GroupWords<S::kAw.W, true>;
     GW gw;
     gw.init(kGroupWordsWord<S>(), tid);
-    // SOFTWARE PIPELINE: tick t + 1 is sampled (words, action digits, turn ranks) while tick t steps; a reset re-derives the
-    // next tick's actions for the new roles from the words already fetched (see k_rollout_swar)
-    uint32_t act_n = 0u, R_n = 0u;
+    // SOFTWARE PIPELINE in three stages, each placed where its LDS round trip is covered by other work (with the stages in
+    // sequence 29 % of the wave's cycles were parked on s_waitcnt):
+    //   A  top of tick t          read the words of tick t + 1 (refill the group first if t + 1 starts one)
+    //   B  middle of tick t       (after the kill section) action digits of t + 1 from those words, rank-table reads ISSUED
+    //   C  top of tick t + 1      rank bytes from the table words that arrived long ago
+    // A reset at tick t re-derives B for the new roles from the words already fetched.
+    uint32_t act_n = 0u;
+    RankRaw raw_n = {0u, 0u, 0u, 0u};
     TickWords<GW::W> tw_n;
 #pragma unroll
     for (int k = 0; k < GW::W; k++) tw_n.wd[k] = 0u;
     tw_n.rem = 0u;
-    auto sample_tick = [&](int tick, bool first) __attribute__((always_inline)) {
+    auto stage_a = [&](int tick, bool first) __attribute__((always_inline)) {
         if constexpr (!RNG::kNumpy) {
             const uint64_t gt = tick_base + (uint64_t)tick;
             const uint32_t pos = (uint32_t)gt & (uint32_t)(GW::G - 1);
@@ -810,15 +823,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             }
 #pragma unroll
             for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
-            TickWords<GW::W> tw = tw_n;
-            uint32_t R2[2];
-            act_n = sample_actions_pair<S, 0>(w, rng, tw, gt);
-            if constexpr (RankLut<S>::kOk) ranks_from_lut<S, 0>(rng, tw, gt, R2);
-            else identity_ranks<S>(R2);
-            R_n = h ? R2[1] : R2[0];
         }
     };
-    if (!RNG::kNumpy && a.n_ticks > 0) sample_tick(0, true);
+    auto stage_b = [&]() __attribute__((always_inline)) {
+        if constexpr (!RNG::kNumpy) {
+            TickWords<GW::W> tw = tw_n;
+            act_n = sample_actions_pair<S, 0>(w, rng, tw, 0ull);
+            if constexpr (RankLut<S>::kOk) raw_n = ranks_lut_issue<S, 0>(rng, tw, 0ull);
+        }
+    };
+    if (!RNG::kNumpy && a.n_ticks > 0) {
+        stage_a(0, true);
+        stage_b();
+    }
     auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) {
             const uint32_t t32 = (uint32_t)tick;
@@ -839,25 +856,27 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             act = h ? a2[1] : a2[0];
             R = h ? R2[1] : R2[0];
         } else {
+            uint32_t R2[2];
+            if constexpr (RankLut<S>::kOk) ranks_lut_finish<S>(raw_n, R2); // stage C
+            else identity_ranks<S>(R2);
             act = act_n;
-            R = R_n;
-            sample_tick(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
+            R = h ? R2[1] : R2[0];
+            stage_a(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
         }
         float rr[4];
         bool done, trunc;
-        step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc);
+        if constexpr (RNG::kNumpy) step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc);
+        else step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, stage_b);
+        // (the rewards come out of LDS lookups issued at the very end of the step: they are stored LAST, behind everything else
+        // the tick writes, so that nothing waits for them)
         if (kTraj) {
             da.st32(0u, act);
-            store_row_f32<4>(dr, rr);
             if (h == 0u) {
                 dd.st8(0u, done ? 1u : 0u);
                 dt.st8(0u, trunc ? 1u : 0u);
             }
         }
-        if (kRec) { // rewards f32[8] | actions u8[8] | ...: my four of each
-            drec.st128(16u * h, __float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3]));
-            drec.st32(4u * A + 4u * h, act);
-        }
+        if (kRec) drec.st32(4u * A + 4u * h, act); // rewards f32[8] | actions u8[8] | ...: my four of each
         if (kFeed(OUT) && a.roles != nullptr && h == 0u) a.roles[(int64_t)tick * c.B + b] = (uint16_t)w.imp_bits;
         if (__builtin_expect(done || trunc, 0)) { // (both lanes of the pair: done / truncated are the environment's)
             life.add_episode(e, trunc);
@@ -870,16 +889,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             }
             reset_env<S>(c, T, st, tid, e, rng);
             to_swar2<S>(c, st, e, h, w);
-            if constexpr (!RNG::kNumpy) { // new roles: the next tick's actions again, from the words already fetched -- and its turn
-                // ranks, whose digits continue what the action draws (role-dependent ranges) left of their last word
-                TickWords<GW::W> tw = tw_n;
-                act_n = sample_actions_pair<S, 0>(w, rng, tw, 0ull);
-                if constexpr (RankLut<S>::kOk) {
-                    uint32_t R2[2];
-                    ranks_from_lut<S, 0>(rng, tw, 0ull, R2);
-                    R_n = h ? R2[1] : R2[0];
-                }
-            }
+            // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
+            // continue what the action draws (role-dependent ranges) left of their last word
+            if constexpr (!RNG::kNumpy) stage_b();
             if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
             else zero_metrics(e);
         }
@@ -899,7 +911,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             drec.st32(5u * A + 16u + 4u * h, w.al & k01);
             if (h == 0u)
                 drec.st128(5u * A + 24u, w.jobs_obs[0], w.jobs_obs[1], w.jd, (done ? 1u : 0u) | (trunc ? 0x100u : 0u));
+            drec.st128(16u * h, __float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3]));
         }
+        if (kTraj) store_row_f32<4>(dr, rr);
     };
 #pragma clang loop unroll(disable)
     for (int tick = 0; tick < a.n_ticks; tick++) tick_body(tick);

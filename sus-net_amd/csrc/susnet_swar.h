@@ -301,8 +301,13 @@ __device__ __forceinline__ void build_rank_lut(uint32_t *smem, int tid) {
     }
 }
 
-template <class S, int POS, int NW, class AS = ActionStream>
-__device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, AS &as, uint64_t tick, uint32_t (&R)[NW]) {
+// The two table reads of a tick, issued (ranks_lut_issue) and turned into rank bytes (ranks_lut_finish) separately: the fused
+// rollouts issue them one tick ahead, in the middle of the previous tick's step, so their LDS round trip is never waited for.
+struct RankRaw {
+    uint32_t lo, hi, flo, fhi;
+};
+template <class S, int POS, class AS = ActionStream>
+__device__ __forceinline__ RankRaw ranks_lut_issue(PhiloxRng &rng, AS &as, uint64_t tick) {
     using L = RankLut<S>;
     constexpr int A = L::A;
     const uint64_t W = (uint64_t)S::kAw.W;
@@ -310,37 +315,55 @@ __device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, AS &as, uint64_t 
         return POS >= 0 ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * W, (POS >= 0 ? POS : 0) * S::kAw.W + k)
                         : as.word(rng, tick * W + (uint64_t)k);
     };
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    RankRaw raw = {0u, 0u, 0u, 0u};
     uint32_t w = as.rem; // what the tick's action draws left of their last word
     if (S::kAw.word[A] != S::kAw.word[A - 1]) w = fetch(S::kAw.word[A]);
     const uint64_t p1 = (uint64_t)w * (uint64_t)L::P1;
     w = (uint32_t)p1;
     const uint32_t a1 = lds_table_addr(kRankLut1Word) + (uint32_t)(p1 >> 32) * (4u * L::kW1);
-    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
-    const uint32_t lo = *(lds_u32_ptr)(uintptr_t)a1;
-    uint32_t hi = 0;
-    if (L::kW1 > 1) hi = *(lds_u32_ptr)(uintptr_t)(a1 + 4u);
-    if (L::K2 == 0) {
-        R[0] = lo | k80;
-        if (NW > 1) R[NW - 1] = hi | k80;
-    } else {
+    raw.lo = *(lds_u32_ptr)(uintptr_t)a1;
+    if (L::kW1 > 1) raw.hi = *(lds_u32_ptr)(uintptr_t)(a1 + 4u);
+    if (L::K2 > 0) {
         if (S::kAw.word[A + L::K1] != S::kAw.word[A + L::K1 - 1]) w = fetch(S::kAw.word[A + L::K1]);
         const uint64_t p2 = (uint64_t)w * (uint64_t)L::P2;
         w = (uint32_t)p2;
         const uint32_t a2 = lds_table_addr(kRankLut2Word) + (uint32_t)(p2 >> 32) * 8u;
-        const uint32_t flo = *(lds_u32_ptr)(uintptr_t)a2, fhi = *(lds_u32_ptr)(uintptr_t)(a2 + 4u);
-        R[0] = __builtin_amdgcn_perm(fhi, flo, lo);                         // final rank of agents 0 .. 3
-        const uint32_t t = __builtin_amdgcn_perm(fhi, flo, hi);             // byte 0: agent 4
-        if (NW > 1) R[NW - 1] = __builtin_amdgcn_perm(fhi, t, 0x07060500u); // agent 4 | agents 5 .. 7
+        raw.flo = *(lds_u32_ptr)(uintptr_t)a2;
+        raw.fhi = *(lds_u32_ptr)(uintptr_t)(a2 + 4u);
     }
     as.rem = w;
+    return raw;
+}
+template <class S, int NW>
+__device__ __forceinline__ void ranks_lut_finish(const RankRaw &raw, uint32_t (&R)[NW]) {
+    using L = RankLut<S>;
+    if (L::K2 == 0) {
+        R[0] = raw.lo | k80;
+        if (NW > 1) R[NW - 1] = raw.hi | k80;
+    } else {
+        R[0] = __builtin_amdgcn_perm(raw.fhi, raw.flo, raw.lo);                 // final rank of agents 0 .. 3
+        const uint32_t t = __builtin_amdgcn_perm(raw.fhi, raw.flo, raw.hi);     // byte 0: agent 4
+        if (NW > 1) R[NW - 1] = __builtin_amdgcn_perm(raw.fhi, t, 0x07060500u); // agent 4 | agents 5 .. 7
+    }
+}
+template <class S, int POS, int NW, class AS = ActionStream>
+__device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, AS &as, uint64_t tick, uint32_t (&R)[NW]) {
+    const RankRaw raw = ranks_lut_issue<S, POS>(rng, as, tick);
+    ranks_lut_finish<S>(raw, R);
 }
 
 // One step.  act: role-relative action bytes (valid for their roles); R: turn ranks (byte = rank | 0x80).
 // Rewards go to rr[] (float32: the compiled-in kernels are only selected when every reward constant is float-exact).
-template <class S, class RNG>
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+// mid(): called between the kill section and the job section -- the fused rollouts put the next tick's sampling there (its
+// multiplies and table reads fill the waits of this tick's own lookups)
+template <class S, class RNG, class MID = NoMid>
 __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar<S> &w, Env &e, RNG &rng, const uint32_t (&act)[Swar<S>::NW],
                                           const uint32_t (&R)[Swar<S>::NW], float (&rr)[Swar<S>::A], bool &done, bool &trunc,
-                                          unsigned long long *sg = nullptr) {
+                                          unsigned long long *sg = nullptr, MID &&mid = MID()) {
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycles of the step's sections, one wave
     unsigned long long sprev = __builtin_readcyclecounter();
 #define WSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); if (sg) sg[k] += tn - sprev; sprev = tn; } while (0)
@@ -477,6 +500,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     // final positions: a victim that had not acted yet stays where it was
 #pragma unroll
     for (int q = 0; q < NW; q++) w.xy[q] = sel_bytes(ff_from80(pend80[q]), w.xy[q], newt[q]);
+    mid();
 
     WSTAMP(1);
     // ---- FIX (base.py:518-524) / SABOTAGE (527-533): first job on the agent's own cell (544-546; job cells are distinct) ------

@@ -110,9 +110,9 @@ __device__ __forceinline__ void gather_swar2(const Swar2<S> &w, Swar<S> &f) {
 }
 
 // One step; act / R: MY word of the action bytes and of the turn ranks.  rr: the rewards of my four agents.
-template <class S, class RNG>
+template <class S, class RNG, class MID = NoMid>
 __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e, RNG &rng, uint32_t act, uint32_t R, float (&rr)[4], bool &done,
-                                           bool &trunc) {
+                                           bool &trunc, MID &&mid = MID()) {
     using W = Swar2<S>;
     constexpr int A = W::A, J = W::J, NI = W::NI;
     const uint32_t h = w.h;
@@ -202,6 +202,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
         }
     }
     w.xy = sel_bytes(ff_from80(pend80), w.xy, newt); // a victim that had not acted yet stays where it was
+    mid(); // (the fused rollout samples the next tick here: see step_swar)
 
     // ---- FIX (base.py:518-524) / SABOTAGE (527-533), in agent space (see susnet_swar.h) ----------------------------------------
     uint32_t fc80 = 0, sc80 = 0;
