@@ -11,6 +11,7 @@
  *                          FourRoomEnvWithTagging.__init__ src/environment/tagging.py:10-60
  *   susnet_reset           FourRoomEnv.reset               src/environment/base.py:251-324 (tagging.py:62-101)
  *   susnet_sample_actions  FourRoomEnv.sample_actions      src/environment/base.py:326-330
+ *   susnet_policy_actions  run_game's acting step          src/visualize.py:547-562 (train.py:355-381, epsilon = 0)
  *   susnet_step            FourRoomEnv.step                src/environment/base.py:332-407 (tagging.py:120-235)
  *                          + _agent_step 462-533, check_win_condition 409-460 (pred_prey.py:78-99),
  *                            _merge_rewards 553-563, EnvMetricHandler src/metrics.py:35-64
@@ -297,6 +298,18 @@ int susnet_tick(susnet_env *env, const uint64_t *set, uint64_t *get, void *strea
 int susnet_reset(susnet_env *env, const uint8_t *mask /* [B] or NULL = all */, const susnet_obs_spec *obs,
                  void *stream);
 int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t dtype, int32_t layout, void *stream);
+
+/* Greedy policy actions of one tick -- the acting step of the reference's policy loops (run_game, src/visualize.py:547-562:
+ * every agent takes the argmax of ITS TEAM's Q-network; train.py:355-381 with epsilon = 0):
+ *   actions[b][i] = argmax_k q_imposter[b][k]   if agent i is an imposter of environment b
+ *                 = argmax_k q_crew[b][k]       otherwise
+ * q_imposter / q_crew: float32 [B][n_actions_imposter] / [B][n_actions_crew], one row per environment (all agents of an
+ * environment share the flat observation, FlatFeaturizer model_ready.py:356-367); ties go to the lowest index, like
+ * torch.argmax / np.argmax.  q_crew = NULL: the crew draws uniformly random role-valid indices from the production action
+ * stream -- exactly what susnet_sample_actions would return for them (PHILOX handles only).  One launch instead of the
+ * role export + argmax + sample + dtype copy + where of the eager loop; actions_out as for susnet_sample_actions. */
+int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, void *actions_out, int32_t dtype,
+                          int32_t layout, void *stream);
 int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream);
 int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
 int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);

@@ -106,6 +106,61 @@ __global__ __launch_bounds__(kBlock) void k_sample_philox(Consts c, State s, voi
     sample_actions_env<S>(c, sink, e, rng, as, uniform64(tick_word));
 }
 
+// susnet_policy_actions: the acting step of the policy loops (visualize.py:547-562) in one launch.  Like k_sample_philox it
+// needs of an environment only its roles and the tick; an agent's action is the argmax of its team's Q row (first maximum,
+// like torch.argmax), or -- q_crew == NULL -- the crew's draw from the action stream.  The draws are made for EVERY agent and
+// the imposters' are overwritten: the digits of a word depend on the draws before them, so the crew's values are exactly the
+// ones susnet_sample_actions returns.
+struct PolicyActionSink {
+    void *out;
+    int32_t dtype;
+    int64_t sa, k0;
+    uint32_t roles, a_imp, a_crew; // a_crew = ~0u: keep the sampled index
+    __device__ __forceinline__ void set_act(int i, uint32_t sampled) const {
+        const uint32_t a = ((roles >> i) & 1u) ? a_imp : (a_crew != ~0u ? a_crew : sampled);
+        store_action(out, dtype, (int64_t)i * sa + k0, a);
+    }
+};
+__device__ __forceinline__ uint32_t argmax_row(const float *q, int n) {
+    uint32_t best = 0;
+    float hi = q[0];
+    for (int k = 1; k < n; k++) {
+        const float v = q[k];
+        if (v > hi) { hi = v; best = (uint32_t)k; }
+    }
+    return best;
+}
+__global__ __launch_bounds__(kBlock) void k_policy_actions(Consts c, State s, const float *q_imp, const float *q_crew, int n_imp_actions,
+                                                           int n_crew_actions, void *out, int32_t dtype, int64_t sa, int64_t sb, uint64_t tick) {
+    using S = GenericSpec;
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; // (< Bp: rows are padded, every lane may load its roles)
+    uint32_t roles = (1u << c.n_imp) - 1u; // fixed roles: the first n_imposters agents (base.py:286-290 without the shuffle)
+    if (c.shuffle_imp) {
+        uint32_t w[SUSNET_MAX_AGENTS];
+#pragma unroll
+        for (int i = 0; i < SUSNET_MAX_AGENTS; i++) w[i] = (uint32_t)s.agent[(size_t)(i < c.A ? i : c.A - 1) * c.Bp + b];
+        roles = 0;
+#pragma unroll
+        for (int i = 0; i < SUSNET_MAX_AGENTS; i++) roles |= (i < c.A ? (w[i] >> 9) & 1u : 0u) << i;
+    }
+    uint64_t tick_word = tick;
+    if (c.dev_tick) tick_word = s.tickw[b];
+    if (b >= c.B) return;
+    PolicyActionSink sink = {out, dtype, sa, b * sb, roles, argmax_row(q_imp + b * n_imp_actions, n_imp_actions),
+                             q_crew ? argmax_row(q_crew + b * n_crew_actions, n_crew_actions) : ~0u};
+    if (q_crew) {
+        for (int i = 0; i < c.A; i++) sink.set_act(i, 0u);
+        return;
+    }
+    Env e = {};
+    e.imp = roles;
+    PhiloxRng rng;
+    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0ull);
+    ActionStream as;
+    as.init();
+    sample_actions_env<S>(c, sink, e, rng, as, uniform64(tick_word));
+}
+
 // Device-resident step counter (susnet_device_tick): one copy per environment, read and advanced by the lane that owns the
 // environment inside the stepping kernels themselves -- no launch of its own, no word that one workgroup writes while another reads.
 __global__ void k_fill_tick(Consts c, State s, uint64_t tick) {
@@ -650,6 +705,12 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
         }
         o.F = F;
         o.words1 = img_words(kBlock * F, 8);
+        if (spec->dtype == SUSNET_F32) { // the compiled-in layouts (susnet_flat.h): kernels that have the writer use it
+            if (c.A == 2 && c.N == 9 && o.ncomp == 1 && o.comp[0] == SUSNET_F_ONEHOT_POS) o.flat_feat = FEAT_ONEHOT;
+            if (c.A == 3 && c.N == 14 && o.ncomp == 3 && o.comp[0] == SUSNET_F_ONEHOT_POS && o.comp[1] == SUSNET_F_ALIVE_CREW &&
+                o.comp[2] == SUSNET_F_CLOSEST_CREW)
+                o.flat_feat = FEAT_ONEHOT_ALIVE_CLOSEST;
+        }
     } else if (spec->mode == SUSNET_OBS_PLANES || spec->mode == SUSNET_OBS_PERSP) {
         o.F = (c.A + 2) * c.N * c.N;
         o.F2 = c.A + c.J + (c.variant == SUSNET_VARIANT_TAGGING ? c.A : 0);
@@ -734,6 +795,21 @@ extern "C" int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t
         hipLaunchKernelGGL(k_sample<TapeRng>, grid_for(env), dim3(kBlock), sh, st, env->c, env->s, actions_out, dtype, sa, sb, env->ticks);
     else
         hipLaunchKernelGGL(k_sample_philox, grid_for(env), dim3(kBlock), 0, st, env->c, env->s, actions_out, dtype, sa, sb, env->ticks);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, void *actions_out, int32_t dtype,
+                                     int32_t layout, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!q_imposter || !actions_out) return fail(SUSNET_E_INVALID, "susnet_policy_actions: null q_imposter / actions_out");
+    if (dtype != SUSNET_U8 && dtype != SUSNET_I32 && dtype != SUSNET_I64) return fail(SUSNET_E_INVALID, "actions dtype must be U8/I32/I64");
+    if (!q_crew && env->cfg.rng_mode != SUSNET_RNG_PHILOX)
+        return fail(SUSNET_E_INVALID, "susnet_policy_actions: a random crew (q_crew = NULL) draws from the production stream: PHILOX handles only");
+    int64_t sa, sb;
+    if (int rc = strides_for(env, layout, sa, sb)) return rc;
+    hipLaunchKernelGGL(k_policy_actions, grid_for(env), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->c, env->s, q_imposter, q_crew,
+                       (int)env->layout.n_actions_imposter, (int)env->layout.n_actions_crew, actions_out, dtype, sa, sb, env->ticks);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }

@@ -242,6 +242,26 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         finish_rng(s, b, rng);
     }
     int nrows = (int)((c.B - b0) < kBlock ? (c.B - b0) : kBlock);
+    if constexpr (FlatFor<S>::kOk) { // the policy loop's observation: the compiled-in float32 feature row (susnet_flat.h)
+        if (o.flat_feat == FlatFor<S>::kFeat) {
+            using Row = typename FlatFor<S>::Row;
+            Row row;
+            row.clear();
+            if (active) {
+                uint32_t fx[Row::A], fy[Row::A], fal[Row::A];
+#pragma unroll
+                for (int i = 0; i < Row::A; i++) {
+                    fx[i] = st.xy(i) & 15u;
+                    fy[i] = st.xy(i) >> 4;
+                    fal[i] = (e.alive >> i) & 1u;
+                }
+                row.build(fx, fy, fal);
+            }
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(o.out) + b0 * Row::F, 0, nrows * Row::F * 4, 0x00020000);
+            flat_store_wave(row, T.stage, tid, nrows, r, 0u);
+            return;
+        }
+    }
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
 }
 

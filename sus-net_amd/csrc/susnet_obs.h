@@ -26,6 +26,8 @@ struct ObsArgs {
     int32_t F, F2;          // elements per env of out / out2
     int32_t Fi, F2i;        // elements per env of the LDS images (= F, F2 except PERSP: the planes image feeds A rotated copies)
     int32_t words1, words2; // LDS staging words of segment 1 / 2 (whole wave)
+    int32_t flat_feat;      // FLAT float32 whose component list is one of the compiled-in layouts (susnet_flat.h FEAT_*), else 0
+    int32_t pad_;
     void *out, *out2;
     int64_t tick_stride, tick_stride2; // rollout: elements between consecutive ticks
 };

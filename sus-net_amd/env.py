@@ -462,6 +462,24 @@ class BatchedFourRoomEnv:
             L.check(self.lib.susnet_sample_actions(self._h, buf.data_ptr(), dtype, layout, self._stream()))
         return buf
 
+    def policy_actions(self, q_imposter: torch.Tensor, q_crew: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Greedy actions of one tick (visualize.py:547-562): every imposter takes ``argmax(q_imposter[b])``, every crew member
+        ``argmax(q_crew[b])`` -- or, with ``q_crew=None``, its uniformly random draw from the action stream (what
+        ``sample_actions()`` returns for it).  One launch (``susnet_policy_actions``); returns ``out`` (default: an int64
+        ``[B, A]`` buffer the env keeps)."""
+        assert q_imposter.dtype == torch.float32 and tuple(q_imposter.shape) == (self.batch, self.n_imposter_actions) and q_imposter.is_contiguous()
+        if q_crew is not None:
+            assert q_crew.dtype == torch.float32 and tuple(q_crew.shape) == (self.batch, self.n_crew_actions) and q_crew.is_contiguous()
+        if out is None:
+            if getattr(self, "_policy_actions_buf", None) is None:
+                self._policy_actions_buf = torch.zeros(self.batch, self.n_agents, dtype=torch.int64, device=self.device)
+            out = self._policy_actions_buf
+        dtype, layout, buf = self._describe_actions(out)
+        with self._on_device():
+            L.check(self.lib.susnet_policy_actions(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None,
+                                                   buf.data_ptr(), dtype, layout, self._stream()))
+        return buf
+
     def _describe_actions(self, a: torch.Tensor):
         if a is self._actions_view:
             return L.U8, L.LAYOUT_AB, a

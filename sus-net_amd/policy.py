@@ -180,17 +180,20 @@ class PolicyRollout:
 
     @torch.no_grad()
     def act(self) -> torch.Tensor:
+        """One tick's actions: the network forward(s) through stock PyTorch-ROCm, then ONE kernel (``susnet_policy_actions``) that
+        reads the episode's roles from the env's state, takes each team's argmax and -- without a crew network -- the crew's
+        draws from the action stream.  (The eager form of the same thing -- role export, argmax, sample_actions, dtype copy,
+        where -- was five launches and a tenth of the tick's GPU time.)"""
         env = self.env
-        if not env.export_state:
-            env.refresh_roles()  # auto-reset may have re-drawn the imposter indices (base.py:273-278)
         feats = env.obs  # [B, F] float32, refreshed by reset()/step()
-        a_imp = self.imposter_model(self._spatial, feats).argmax(dim=1)
-        if self.crew_model is None:
-            crew = env.sample_actions().to(torch.int64)  # [B, A] uniform role-valid (imposter slots overwritten)
-        else:
-            crew = self.crew_model(self._spatial, feats).argmax(dim=1).unsqueeze(1).expand(-1, env.n_agents)
-        torch.where(env.imposter_mask, a_imp.unsqueeze(1), crew, out=self._actions)
-        return self._actions
+        q_imp = self.imposter_model(self._spatial, feats)
+        q_crew = self.crew_model(self._spatial, feats) if self.crew_model is not None else None
+        if env.rng_kind != "philox" and q_crew is None:  # numpy tapes: the crew's draws come from the env's own words
+            if not env.export_state:
+                env.refresh_roles()
+            torch.where(env.imposter_mask, q_imp.argmax(dim=1).unsqueeze(1), env.sample_actions().to(torch.int64), out=self._actions)
+            return self._actions
+        return env.policy_actions(q_imp.contiguous(), q_crew.contiguous() if q_crew is not None else None, out=self._actions)
 
     @torch.no_grad()
     def run(self, n_steps: int, record: bool = False) -> Dict[str, torch.Tensor]:

@@ -1106,6 +1106,38 @@ def test_policy_rollout_matches_oracle_on_recorded_actions(pkg, oracle_mod):
         ob.reset(mask=(odone | otrunc).astype(bool))
 
 
+@pytest.mark.parametrize("name", ["base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v1_nowalls"])
+def test_policy_actions_kernel(pkg, oracle_mod, name):
+    """susnet_policy_actions (the acting step of visualize.py:547-562 in one launch): per team the argmax of its Q row -- first
+    maximum, like torch.argmax -- placed by the episode's roles; without a crew network the crew's slots hold exactly the draws
+    sample_actions() returns; every output dtype."""
+    B = 3000
+    env, ob = make_pair(pkg, oracle_mod, name, B, 5, auto_reset=True, check_errors=False)
+    env.reset()
+    ob.reset()
+    gen = torch.Generator(device=env.device)
+    gen.manual_seed(1)
+    for tick in range(4):
+        q_imp = torch.randn(B, env.n_imposter_actions, device=env.device, generator=gen)
+        q_crew = torch.randn(B, env.n_crew_actions, device=env.device, generator=gen)
+        q_imp[::7, 2] = q_imp[::7].max(dim=1).values  # ties: the first maximum wins
+        q_imp[::7, 1] = q_imp[::7, 2]
+        imp = torch.from_numpy(ob.export()["imp"].astype(bool)).to(env.device)
+        sampled = env.sample_actions().to(torch.int64).clone()
+        want_net = torch.where(imp, q_imp.argmax(1, keepdim=True), q_crew.argmax(1, keepdim=True))
+        want_rand = torch.where(imp, q_imp.argmax(1, keepdim=True), sampled)
+        np.testing.assert_array_equal(np_(sampled), ob.sample_actions())
+        for dt in (torch.int64, torch.int32, torch.uint8):
+            out = torch.zeros(B, env.n_agents, dtype=dt, device=env.device)
+            assert torch.equal(env.policy_actions(q_imp, q_crew, out=out).to(torch.int64), want_net), (name, dt)
+            assert torch.equal(env.policy_actions(q_imp, None, out=out).to(torch.int64), want_rand), (name, dt)
+        a = env.policy_actions(q_imp, None)  # the env's own int64 buffer; step it so that roles / ticks move on
+        env.step(a)
+        ob.step(np_(a))
+        done = ob.export()
+        ob.reset(mask=np_(env._done | env._trunc))
+
+
 def test_captured_policy_tick_replays_against_the_oracle(pkg, oracle_mod):
     """PolicyRollout.capture: the whole policy tick as a hipGraph.  Replays are checked like the eager loop above -- fused flat
     observation, MLP argmax in the imposter slot, Philox crew draws mirrored in the oracle, rewards / done bit for bit -- for the
