@@ -19,6 +19,8 @@ for cdir in sorted(glob.glob(f"{root}/*")):
     stats = glob.glob(f"{cdir}/stats/*/*kernel_stats.csv")
     if stats:
         shutil.copy(stats[0], f"profiles/{tag}_{cfg}_kernel_stats.csv")
+    if not cfg.startswith(("cfg", "tag")):  # (featurize / ring / writepath_*: tools/profile_aux.sh, tools/profile_writepath.sh: kernel stats only here)
+        continue
     # the JSON line bench.py printed inside the profiled --stats run
     log = f"{cdir}/stats.log"
     per = {}
@@ -74,6 +76,8 @@ for cdir in sorted(glob.glob(f"{root}/*")):
         w = roll("pmc_WRITE_SIZE")["WRITE_SIZE"]["mean_per_launch"]
         f = roll("pmc_FETCH_SIZE")["FETCH_SIZE"]["mean_per_launch"]
         per["traffic_bytes_per_launch"] = (w + 2.0 * f) * 1024.0
+        # (a bench step whose record array would pass 2 GiB runs as consecutive launches: tag5 takes two)
+        per["traffic_bytes_per_bench_step"] = per["traffic_bytes_per_launch"] * roll("pmc_WRITE_SIZE").get("launches_per_bench_step", 1)
     except (KeyError, StopIteration, ZeroDivisionError) as exc:
         per["derived_error"] = repr(exc)
     summary[cfg] = per
@@ -82,9 +86,9 @@ for cfg, per in summary.items():
     print(cfg, json.dumps(per.get("derived_per_wave_tick", per.get("derived_error"))), per.get("traffic_bytes_per_launch"))
     # bench lines kept next to this summary get the traffic of the SAME profiling session
     name = f"profiles/{tag}_{cfg}_bench_under_rocprofv3.json"
-    if os.path.exists(name) and per.get("traffic_bytes_per_launch"):
+    if os.path.exists(name) and per.get("traffic_bytes_per_bench_step"):
         line = json.load(open(name))
-        t = per["traffic_bytes_per_launch"]
+        t = per["traffic_bytes_per_bench_step"]
         line["roofline"]["traffic"] = t
         line["roofline"]["traffic_source"] = f"{tag}_pmc_summary.json"
         if line["roofline"].get("avg_launch_us"):
