@@ -487,7 +487,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     // word layout is compiled in, 12 for the 1v1 game (three ticks per word).  Inside a group every block generation and
     // word selection is static; ticks before the first group boundary of a launch and after its last full group run
     // through the run-time flavour.
-    constexpr int kGroup = (S::kGeneric || OUT == OUT_ANY || RNG::kNumpy) ? 0 : (S::kA == 2 ? 4 * kDuelTicksPerWord : (S::kStaticAw ? 4 : 0));
+    // (only fully compiled-in configurations: SpecA<2> -- two agents, everything else read at run time -- unrolled twelve ticks
+    // of its run-time-checked step into 35 000 instructions with 782 spilled SGPRs; it walks the stream tick by tick now)
+    constexpr int kGroup = (S::kGeneric || OUT == OUT_ANY || RNG::kNumpy || !S::kStaticAw) ? 0 : (S::kA == 2 ? 4 * kDuelTicksPerWord : 4);
     int tick = 0;
     while (tick < a.n_ticks) {
         if (kGroup > 0 && tick + kGroup <= a.n_ticks && ((tick_base + (uint64_t)tick) % (uint64_t)(kGroup > 0 ? kGroup : 1)) == 0ull) {
