@@ -12,6 +12,7 @@
  *   susnet_reset           FourRoomEnv.reset               src/environment/base.py:251-324 (tagging.py:62-101)
  *   susnet_sample_actions  FourRoomEnv.sample_actions      src/environment/base.py:326-330
  *   susnet_policy_actions  run_game's acting step          src/visualize.py:547-562 (train.py:355-381, epsilon = 0)
+ *   susnet_qnet_*          MLP.forward on the flat features src/models/dqn.py:72-108, 322-329
  *   susnet_step            FourRoomEnv.step                src/environment/base.py:332-407 (tagging.py:120-235)
  *                          + _agent_step 462-533, check_win_condition 409-460 (pred_prey.py:78-99),
  *                            _merge_rewards 553-563, EnvMetricHandler src/metrics.py:35-64
@@ -47,7 +48,7 @@
 extern "C" {
 #endif
 
-#define SUSNET_ABI_VERSION 3
+#define SUSNET_ABI_VERSION 4
 
 #define SUSNET_MAX_AGENTS 16
 #define SUSNET_MAX_JOBS 16
@@ -310,6 +311,27 @@ int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t dtype, int
  * role export + argmax + sample + dtype copy + where of the eager loop; actions_out as for susnet_sample_actions. */
 int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, void *actions_out, int32_t dtype,
                           int32_t layout, void *stream);
+
+/* The policy loop's Q-network -- the reference's MLP (src/models/dqn.py:72-108: make_mlp 322-329, Linear + nn.PReLU() with ONE
+ * slope per layer, no activation after the last Linear) on the FlatFeaturizer observation of the handle's CURRENT environments
+ * (model_ready.py:356-367) -- as one kernel: MLP.forward(spatial, env.obs) without the observation or any activation ever
+ * being written to memory (float32 throughout; layers 2.. on the f32-input matrix instructions, whose result is a k-ordered fmaf
+ * chain, so values agree with torch's to float32 summation-order differences).  Served: five Linear layers
+ * dims = [F, <=256, <=128, <=64, <=32, <=32] (the reference's [F, 256, 128, 64, 16, n_actions], notebooks/experiment_1v1.ipynb cell 1) on
+ * the two compiled-in feature layouts: components {ONEHOT_POS} on the 2-agent 9x9 game (F = 36) and {ONEHOT_POS, ALIVE_CREW,
+ * CLOSEST_CREW} on the 3-agent 14x14 game (F = 88).
+ *   susnet_qnet_packed_floats  size of the packed weight image (floats), or SUSNET_E_INVALID when the handle / components / dims are
+ *                              not served (callers then run the network themselves and hand Q rows to susnet_policy_actions);
+ *   susnet_qnet_pack           HOST: torch-layout weights[l] ([dims[l+1]][dims[l]] row-major), biases[l] ([dims[l+1]]), slopes
+ *                              ([n_dims - 2], the PReLU weights) -> packed (host buffer of that size; the caller copies it to the device:
+ *                              the library never allocates device memory);
+ *   susnet_qnet_forward        q_out [B][dims[n_dims-1]] float32 (device) from the packed image (device, 16-byte aligned). */
+int64_t susnet_qnet_packed_floats(const susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims,
+                                  int32_t n_dims);
+int susnet_qnet_pack(const susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                     const float *const *weights, const float *const *biases, const float *slopes, float *packed);
+int susnet_qnet_forward(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                        const float *packed, float *q_out, void *stream);
 int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream);
 int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
 int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libsusnet_hip.so"
 LIB_PATH = os.environ.get("SUSNET_LIB_PATH", os.path.join(PKG_DIR, LIB_NAME))  # override: A/B experiments only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_AGENTS, MAX_JOBS, MAX_GRID, N_METRICS, N_LIFETIME = 16, 16, 16, 13, 12
 
 VARIANT_BASE, VARIANT_ITG, VARIANT_TAGGING = 0, 1, 2
@@ -30,7 +30,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 # every symbol include/susnet.h declares
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
-    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_policy_actions", "susnet_step",
+    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_policy_actions", "susnet_qnet_packed_floats", "susnet_qnet_pack", "susnet_qnet_forward", "susnet_step",
     "susnet_rollout", "susnet_record_layout", "susnet_set_launch_limit", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append", "susnet_scent",
 ]
@@ -160,6 +160,9 @@ def lib():
     L.susnet_step.argtypes = [C.c_void_p, P(StepIO), C.c_void_p]
     L.susnet_rollout.argtypes = [C.c_void_p, P(RolloutIO), C.c_void_p]
     L.susnet_policy_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.susnet_qnet_packed_floats.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32]
+    L.susnet_qnet_pack.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, P(C.c_void_p), P(C.c_void_p), C.c_void_p, C.c_void_p]
+    L.susnet_qnet_forward.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.susnet_record_layout.argtypes = [C.c_void_p, P(RecordLayout)]
     L.susnet_set_launch_limit.argtypes = [C.c_void_p, C.c_uint64]
     L.susnet_observe.argtypes = [C.c_void_p, P(ObsSpec), C.c_void_p]
@@ -175,6 +178,7 @@ def lib():
     for name in EXPORTS:
         if name not in ("susnet_last_error", "susnet_destroy"):
             getattr(L, name).restype = C.c_int
+    L.susnet_qnet_packed_floats.restype = C.c_int64
     if L.susnet_abi_version() != ABI_VERSION:
         raise ImportError(f"ABI mismatch: library {L.susnet_abi_version()} vs binding {ABI_VERSION}")
     _lib = L

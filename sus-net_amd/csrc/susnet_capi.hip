@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "susnet_kernels.h"
+#include "susnet_qnet.h"
 
 namespace susnet {
 SUSNET_DECLARE(GenericSpec) SUSNET_DECLARE(SpecCfg2) SUSNET_DECLARE(SpecCfg3) SUSNET_DECLARE(SpecCfg4) SUSNET_DECLARE(SpecTag5)
@@ -812,6 +813,102 @@ extern "C" int susnet_policy_actions(susnet_env *env, const float *q_imposter, c
                        (int)env->layout.n_actions_imposter, (int)env->layout.n_actions_crew, actions_out, dtype, sa, sb, env->ticks);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
+}
+
+// ---- the policy loop's Q-network (susnet_qnet.h) ----
+// which compiled-in feature layout (susnet_flat.h) a component list on this handle is: 0 = none
+static int qnet_feat(const susnet_env *env, const int32_t *comp, int32_t ncomp) {
+    if (!env || !comp) return 0;
+    const Consts &c = env->c;
+    if (c.A == 2 && c.N == 9 && ncomp == 1 && comp[0] == SUSNET_F_ONEHOT_POS) return FEAT_ONEHOT;
+    if (c.A == 3 && c.N == 14 && c.n_imp == 1 && ncomp == 3 && comp[0] == SUSNET_F_ONEHOT_POS && comp[1] == SUSNET_F_ALIVE_CREW &&
+        comp[2] == SUSNET_F_CLOSEST_CREW)
+        return FEAT_ONEHOT_ALIVE_CLOSEST;
+    return 0;
+}
+template <class ROW>
+static bool qnet_dims_ok(const int32_t *dims, int32_t n_dims) {
+    using Q = QNet<ROW>;
+    const int cap[6] = {Q::F, Q::H1, Q::H2, Q::H3, Q::H4, Q::NO};
+    if (!dims || n_dims != 6 || dims[0] != Q::F) return false;
+    for (int l = 1; l < 6; l++)
+        if (dims[l] < 1 || dims[l] > cap[l]) return false;
+    return true;
+}
+// torch Linear weight [dn][dk] -> 32 x 32 blocks in [kb][nb] order; inside a block lane l holds, as four float4, the 16 k values of row
+// n = 32 nb + l % 32 in MFMA-step order: float4 q = columns 32 kb + 8 q + 4 (l / 32) + {0, 1, 2, 3}
+static void qnet_pack_dense(const float *W, int dk, int dn, int KP, int NP, float *dst) {
+    const int KB = KP / 32, NB = NP / 32;
+    for (int kb = 0; kb < KB; kb++)
+        for (int nb = 0; nb < NB; nb++)
+            for (int q = 0; q < 4; q++)
+                for (int l = 0; l < 64; l++)
+                    for (int r = 0; r < 4; r++) {
+                        const int n = 32 * nb + (l & 31), k = 32 * kb + 8 * q + 4 * (l >> 5) + r;
+                        dst[((((size_t)kb * NB + nb) * 4 + q) * 64 + l) * 4 + r] = (n < dn && k < dk) ? W[(size_t)n * dk + k] : 0.0f;
+                    }
+}
+template <class ROW>
+static void qnet_pack(const int32_t *d, const float *const *W, const float *const *Bv, const float *slopes, float *out) {
+    using Q = QNet<ROW>;
+    std::fill(out, out + Q::kPacked, 0.0f);
+    for (int f = 0; f < Q::F; f++) // layer 1, transposed: one row per feature (the zero row F + 1 stays zero)
+        for (int n = 0; n < d[1]; n++) out[Q::oW1 + f * Q::kRowStride + n] = W[0][(size_t)n * Q::F + f];
+    for (int n = 0; n < d[1]; n++) out[Q::oW1 + Q::F * Q::kRowStride + n] = Bv[0][n];
+    const int off_w[4] = {Q::oW2, Q::oW3, Q::oW4, Q::oW5}, off_b[4] = {Q::oB2, Q::oB3, Q::oB4, Q::oB5};
+    const int pad[6] = {Q::F, Q::H1, Q::H2, Q::H3, Q::H4, Q::NO};
+    for (int l = 1; l < 5; l++) {
+        qnet_pack_dense(W[l], d[l], d[l + 1], pad[l], pad[l + 1], out + off_w[l - 1]);
+        for (int n = 0; n < d[l + 1]; n++) out[off_b[l - 1] + n] = Bv[l][n];
+    }
+    for (int l = 0; l < 4; l++) out[Q::oSlope + l] = slopes[l];
+}
+using QRow1 = FlatRow<FEAT_ONEHOT, 2, 9>;
+using QRow3 = FlatRow<FEAT_ONEHOT_ALIVE_CLOSEST, 3, 14>;
+
+extern "C" int64_t susnet_qnet_packed_floats(const susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims,
+                                             int32_t n_dims) {
+    switch (qnet_feat(env, components, n_components)) {
+    case FEAT_ONEHOT: if (qnet_dims_ok<QRow1>(dims, n_dims)) return QNet<QRow1>::kPacked; break;
+    case FEAT_ONEHOT_ALIVE_CLOSEST: if (qnet_dims_ok<QRow3>(dims, n_dims)) return QNet<QRow3>::kPacked; break;
+    }
+    return fail(SUSNET_E_INVALID, "susnet_qnet: served are five Linear layers [F, <=256, <=128, <=64, <=32, <=32] on the compiled-in feature "
+                                  "layouts (onehot_pos on the 2-agent 9x9 game; onehot_pos + alive_crew + closest_crew on the 3-agent 14x14 game)");
+}
+
+extern "C" int susnet_qnet_pack(const susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                                const float *const *weights, const float *const *biases, const float *slopes, float *packed) {
+    const int64_t n = susnet_qnet_packed_floats(env, components, n_components, dims, n_dims);
+    if (n < 0) return (int)n;
+    if (!weights || !biases || !slopes || !packed) return fail(SUSNET_E_INVALID, "susnet_qnet_pack: null weights / biases / slopes / packed");
+    for (int l = 0; l < 5; l++)
+        if (!weights[l] || !biases[l]) return fail(SUSNET_E_INVALID, "susnet_qnet_pack: null layer");
+    if (qnet_feat(env, components, n_components) == FEAT_ONEHOT) qnet_pack<QRow1>(dims, weights, biases, slopes, packed);
+    else qnet_pack<QRow3>(dims, weights, biases, slopes, packed);
+    return SUSNET_OK;
+}
+
+template <class ROW>
+static int qnet_launch(susnet_env *env, const float *packed, float *q_out, int n_out, hipStream_t st) {
+    using Q = QNet<ROW>;
+    static bool lds_set = false; // 90 KB of LDS: above the 64 KB a kernel gets without asking
+    if (!lds_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet<ROW>), hipFuncAttributeMaxDynamicSharedMemorySize, Q::kLdsBytes));
+        lds_set = true;
+    }
+    const unsigned blocks = (unsigned)((env->c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
+    hipLaunchKernelGGL(k_qnet<ROW>, dim3(blocks), dim3(Q::kThreads), Q::kLdsBytes, st, env->c, env->s, packed, q_out, n_out);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+extern "C" int susnet_qnet_forward(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                                   const float *packed, float *q_out, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    const int64_t n = susnet_qnet_packed_floats(env, components, n_components, dims, n_dims);
+    if (n < 0) return (int)n;
+    if (!packed || !q_out || (reinterpret_cast<uintptr_t>(packed) & 15u)) return fail(SUSNET_E_INVALID, "susnet_qnet_forward: packed (16-byte aligned) / q_out");
+    if (qnet_feat(env, components, n_components) == FEAT_ONEHOT) return qnet_launch<QRow1>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
+    return qnet_launch<QRow3>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
 }
 
 extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream) {

@@ -95,6 +95,14 @@ class _NullCtx:
 _NULL_CTX = _NullCtx()
 
 
+class PackedQNet:
+    """Device image of a reference ``MLP`` in the layout ``susnet_qnet_forward`` reads (``SusEnv.qnet_pack``)."""
+
+    def __init__(self, components, cdims, dims, packed, host):
+        self.components, self.cdims, self.dims, self.packed, self.host = components, cdims, dims, packed, host
+        self.q_buf = {}
+
+
 class ObsConfig:
     """Which fused observation the kernels write next to every step / reset / rollout tick.
 
@@ -479,6 +487,41 @@ class BatchedFourRoomEnv:
             L.check(self.lib.susnet_policy_actions(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None,
                                                    buf.data_ptr(), dtype, layout, self._stream()))
         return buf
+
+    def qnet_pack(self, components: Sequence[str], weights, biases, slopes) -> Optional["PackedQNet"]:
+        """Pack a reference ``MLP`` (dqn.py:72-108: ``weights[l]`` ``[out, in]`` float32, ``biases[l]``, one PReLU slope per hidden
+        layer) for ``qnet_forward``.  Returns ``None`` when the library does not serve this handle / feature layout / layer stack
+        (callers then run the torch module and hand its Q rows to ``policy_actions``)."""
+        comps = (C.c_int32 * len(components))(*[L.FLAT_COMPONENTS[k] for k in components])
+        w = [np.ascontiguousarray(np.asarray(x, dtype=np.float32)) for x in weights]
+        b = [np.ascontiguousarray(np.asarray(x, dtype=np.float32)) for x in biases]
+        sl = np.ascontiguousarray(np.asarray(slopes, dtype=np.float32).reshape(-1))
+        dims = [int(w[0].shape[1])] + [int(x.shape[0]) for x in w]
+        if any(x.ndim != 2 for x in w) or any(w[l].shape[1] != dims[l] for l in range(len(w))) or any(b[l].shape != (dims[l + 1],) for l in range(len(w))) \
+                or sl.shape[0] != len(w) - 1:
+            return None
+        cdims = (C.c_int32 * len(dims))(*dims)
+        n = self.lib.susnet_qnet_packed_floats(self._h, comps, len(components), cdims, len(dims))
+        if n < 0:
+            return None
+        host = np.empty(int(n), dtype=np.float32)
+        wp = (C.c_void_p * len(w))(*[x.ctypes.data for x in w])
+        bp = (C.c_void_p * len(b))(*[x.ctypes.data for x in b])
+        L.check(self.lib.susnet_qnet_pack(self._h, comps, len(components), cdims, len(dims), wp, bp, sl.ctypes.data, host.ctypes.data))
+        return PackedQNet(comps, cdims, dims, torch.from_numpy(host).to(self.device), host)
+
+    def qnet_forward(self, net: "PackedQNet", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``MLP.forward`` on the CURRENT environments' flat features as one kernel (``susnet_qnet_forward``): ``[B, n_out]`` float32.
+        Reads the state, not ``env.obs``: neither the observation nor any activation goes through memory."""
+        if out is None:
+            out = net.q_buf.get(self.batch)
+            if out is None:
+                out = net.q_buf[self.batch] = torch.empty(self.batch, net.dims[-1], dtype=torch.float32, device=self.device)
+        assert out.dtype == torch.float32 and tuple(out.shape) == (self.batch, net.dims[-1]) and out.is_contiguous()
+        with self._on_device():
+            L.check(self.lib.susnet_qnet_forward(self._h, net.components, len(net.components), net.cdims, len(net.dims),
+                                                 net.packed.data_ptr(), out.data_ptr(), self._stream()))
+        return out
 
     def _describe_actions(self, a: torch.Tensor):
         if a is self._actions_view:

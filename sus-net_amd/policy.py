@@ -160,6 +160,20 @@ def reference_imposter_mlp(env, components: Sequence[str], seed: int = 0) -> MLP
     return model.to(env.device).eval()
 
 
+def pack_mlp(env, model, components: Sequence[str]):
+    """``env.qnet_pack`` of a reference ``MLP`` (Linear / nn.PReLU() alternating, dqn.py:322-329), or None if ``model`` is something
+    else or the library does not serve its shape on this env."""
+    if not isinstance(model, MLP):
+        return None
+    layers = list(model.model)
+    linears, acts = layers[0::2], layers[1::2]
+    if not all(isinstance(m, nn.Linear) and m.bias is not None for m in linears) or \
+            not all(isinstance(m, nn.PReLU) and m.weight.numel() == 1 for m in acts) or len(acts) != len(linears) - 1:
+        return None
+    cpu = lambda t: t.detach().to("cpu", torch.float32).numpy()
+    return env.qnet_pack(components, [cpu(m.weight) for m in linears], [cpu(m.bias) for m in linears], [float(m.weight.detach()) for m in acts])
+
+
 class PolicyRollout:
     """Greedy policy-in-the-loop stepping of a batched env.
 
@@ -170,10 +184,14 @@ class PolicyRollout:
     """
 
     def __init__(self, env, imposter_model: nn.Module, crew_model: Optional[nn.Module] = None,
-                 components: Sequence[str] = ("onehot_pos",)):
+                 components: Sequence[str] = ("onehot_pos",), fused: bool = True):
         assert env.obs_config.mode == "flat" and list(env.obs_config.components) == list(components), (
             "construct the env with obs=ObsConfig('flat', components) so that step() fuses the observation")
         self.env, self.imposter_model, self.crew_model = env, imposter_model, crew_model
+        # reference MLPs on a compiled-in feature layout run as ONE kernel from the state words to the Q row (susnet_qnet_forward);
+        # anything else (SpatialDQN, other layer stacks / layouts) goes through the torch module on env.obs
+        self.fused_imposter = pack_mlp(env, imposter_model, components) if fused else None
+        self.fused_crew = pack_mlp(env, crew_model, components) if fused and crew_model is not None else None
         B = env.batch
         self._spatial = torch.zeros(B, 1, 1, device=env.device)  # FlatFeaturizer's dummy spatial input
         self._actions = torch.zeros(B, env.n_agents, dtype=torch.int64, device=env.device)
@@ -186,8 +204,10 @@ class PolicyRollout:
         where -- was five launches and a tenth of the tick's GPU time.)"""
         env = self.env
         feats = env.obs  # [B, F] float32, refreshed by reset()/step()
-        q_imp = self.imposter_model(self._spatial, feats)
-        q_crew = self.crew_model(self._spatial, feats) if self.crew_model is not None else None
+        q_imp = env.qnet_forward(self.fused_imposter) if self.fused_imposter is not None else self.imposter_model(self._spatial, feats)
+        q_crew = None
+        if self.crew_model is not None:
+            q_crew = env.qnet_forward(self.fused_crew) if self.fused_crew is not None else self.crew_model(self._spatial, feats)
         if env.rng_kind != "philox" and q_crew is None:  # numpy tapes: the crew's draws come from the env's own words
             if not env.export_state:
                 env.refresh_roles()

@@ -8,6 +8,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -161,6 +162,55 @@ def test_obs_sizes_follow_the_reference_featurizers(pkg):
     assert f1.value == 3 * 28 + 2 + 2  # 84 + 2 + 2 = 88
     spec.components[0] = L.FLAT_COMPONENTS["room_loc"]  # 9x9 only (component.py:8-17)
     assert lib.susnet_obs_size(h, C.byref(spec), C.byref(f1), C.byref(f2)) == L.E_INVALID
+    lib.susnet_destroy(h)
+
+
+def test_qnet_pack_layout(pkg):
+    """susnet_qnet_pack (host code): the packed image of a reference MLP [88, 200, 100, 50, 16, 7] -- hidden widths that need padding --
+    against the layout include/susnet.h / susnet_qnet.h describe: layer 1 transposed (one padded row per feature, bias row, zero row),
+    layers 2.. as 32 x 32 blocks in [k block][row block] order whose lane l holds row 32 nb + l % 32 and, as four float4, the columns
+    32 kb + 8 q + 4 (l / 32) + r; unserved shapes are refused."""
+    L = pkg._lib
+    lib = L.lib()
+    h = C.c_void_p()
+    assert lib.susnet_create(C.byref(make_cfg(L, n_crew=2, grid_n=14)), C.byref(h)) == 0
+    comps = (C.c_int32 * 3)(*[L.FLAT_COMPONENTS[k] for k in ("onehot_pos", "alive_crew", "closest_crew")])
+    dims = [88, 200, 100, 50, 16, 7]
+    cd = (C.c_int32 * 6)(*dims)
+    n = lib.susnet_qnet_packed_floats(h, comps, 3, cd, 6)
+    pad = [88, 256, 128, 64, 32, 32]
+    RS = 256 + 4
+    sizes = [(88 + 2) * RS] + [pad[l] * pad[l + 1] + pad[l + 1] for l in range(1, 5)] + [4]
+    assert n == sum(sizes)
+    rng = np.random.default_rng(0)
+    W = [rng.standard_normal((dims[l + 1], dims[l])).astype(np.float32) for l in range(5)]
+    Bv = [rng.standard_normal(dims[l + 1]).astype(np.float32) for l in range(5)]
+    sl = rng.random(4).astype(np.float32)
+    out = np.full(n, np.nan, dtype=np.float32)
+    wp = (C.c_void_p * 5)(*[w.ctypes.data for w in W])
+    bp = (C.c_void_p * 5)(*[b.ctypes.data for b in Bv])
+    assert lib.susnet_qnet_pack(h, comps, 3, cd, 6, wp, bp, sl.ctypes.data, out.ctypes.data) == 0
+    w1 = out[:sizes[0]].reshape(90, RS)
+    np.testing.assert_array_equal(w1[:88, :200], W[0].T)
+    np.testing.assert_array_equal(w1[88, :200], Bv[0])
+    assert not w1[:, 200:].any() and not w1[89].any()
+    off = sizes[0]
+    for l in range(1, 5):
+        KP, NP = pad[l], pad[l + 1]
+        full = np.zeros((NP, KP), dtype=np.float32)
+        full[:dims[l + 1], :dims[l]] = W[l]
+        blk = out[off:off + KP * NP].reshape(KP // 32, NP // 32, 4, 64, 4)
+        kb, nb, q, lane, r = np.meshgrid(*[np.arange(k) for k in blk.shape], indexing="ij")
+        np.testing.assert_array_equal(blk, full[32 * nb + lane % 32, 32 * kb + 8 * q + 4 * (lane // 32) + r])
+        bias = np.zeros(NP, dtype=np.float32)
+        bias[:dims[l + 1]] = Bv[l]
+        np.testing.assert_array_equal(out[off + KP * NP:off + KP * NP + NP], bias)
+        off += KP * NP + NP
+    np.testing.assert_array_equal(out[off:], sl)
+    # refused: another depth, a layer wider than the compiled-in family, a feature layout without a compiled-in writer
+    assert lib.susnet_qnet_packed_floats(h, comps, 3, (C.c_int32 * 5)(88, 256, 128, 64, 7), 5) == L.E_INVALID
+    assert lib.susnet_qnet_packed_floats(h, comps, 3, (C.c_int32 * 6)(88, 512, 128, 64, 16, 7), 6) == L.E_INVALID
+    assert lib.susnet_qnet_packed_floats(h, comps, 1, cd, 6) == L.E_INVALID
     lib.susnet_destroy(h)
 
 

@@ -1138,6 +1138,45 @@ def test_policy_actions_kernel(pkg, oracle_mod, name):
         ob.reset(mask=np_(env._done | env._trunc))
 
 
+@pytest.mark.parametrize("name,comps,hidden", [
+    ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [256, 128, 64, 16]),  # BASELINE config 5's network
+    ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [200, 100, 50, 10]),  # widths that need padding
+    ("itg_1v1_nowalls", ["onehot_pos"], [256, 128, 64, 16]),                                # notebooks/experiment_1v1.ipynb
+])
+def test_qnet_forward_matches_torch_mlp(pkg, oracle_mod, name, comps, hidden):
+    """susnet_qnet_forward (state words -> Q rows in one kernel: layer 1 as a gather of W1 columns, layers 2..5 on the f32 matrix
+    instructions) against the reference-architecture torch MLP (dqn.py:72-108) evaluated on the env's own fused flat observation: values
+    to float32 summation-order tolerance, argmax equal except between numerically tied entries.  B is no multiple of the kernel's 256
+    environments per workgroup; a few policy ticks in between so that dead agents and fresh episodes occur."""
+    B = 5000 + 37
+    env, ob = make_pair(pkg, oracle_mod, name, B, 11, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
+    env.reset()
+    spatial = torch.zeros(B, 1, 1, device=env.device)
+    for which, n_out in (("imposter", env.n_imposter_actions), ("crew", env.n_crew_actions)):
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(4)
+            model = pkg.MLP([env.obs.shape[-1]] + hidden + [n_out]).to(env.device).eval()
+            with torch.no_grad():  # default PReLU slopes are all 0.25 and default biases small: make every parameter matter
+                for i, mod in enumerate(m for m in model.model if isinstance(m, torch.nn.PReLU)):
+                    mod.weight.fill_(0.1 + 0.2 * i)
+                for mod in (m for m in model.model if isinstance(m, torch.nn.Linear)):
+                    mod.bias.uniform_(-0.5, 0.5)
+        net = pkg.policy.pack_mlp(env, model, comps)
+        assert net is not None, "the compiled-in network family serves this stack"
+        for tick in range(6):
+            with torch.no_grad():
+                want = model(spatial, env.obs)
+            got = env.qnet_forward(net)
+            torch.cuda.synchronize()
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) <= 2e-5 * scale, (name, which, tick, float((got - want).abs().max()), scale)
+            ga, wa = got.argmax(1), want.argmax(1)
+            gap = want.gather(1, wa[:, None]) - want.gather(1, ga[:, None])
+            assert bool((gap <= 1e-5 * scale).all())
+            env.step(env.sample_actions())
+    assert pkg.policy.pack_mlp(env, pkg.MLP([env.obs.shape[-1], 64, 7]).to(env.device), comps) is None  # another depth: torch serves it
+
+
 def test_captured_policy_tick_replays_against_the_oracle(pkg, oracle_mod):
     """PolicyRollout.capture: the whole policy tick as a hipGraph.  Replays are checked like the eager loop above -- fused flat
     observation, MLP argmax in the imposter slot, Philox crew draws mirrored in the oracle, rewards / done bit for bit -- for the
@@ -1154,10 +1193,14 @@ def test_captured_policy_tick_replays_against_the_oracle(pkg, oracle_mod):
 
     def check_tick(obs_before, a, rew, done, label):
         np.testing.assert_array_equal(np_(obs_before), ob.obs_flat(comps), err_msg=f"fused flat obs, {label}")
-        want = model(spatial, obs_before).argmax(1)
+        q = model(spatial, obs_before)  # the torch module; the runner's Q rows come from susnet_qnet_forward (float32, another
+        want = q.argmax(1)              # summation order): its argmax may differ from torch's only between numerically tied rows
         oa = ob.sample_actions()
         imp = ob.export()["imp"].astype(bool)
-        oa[imp] = np_(want)
+        got = a[torch.from_numpy(imp).to(a.device)]
+        gap = q.gather(1, want[:, None]) - q.gather(1, got[:, None])
+        assert bool((gap <= 1e-5 * q.abs().max()).all()), f"imposter actions are the network's argmax, {label}"
+        oa[imp] = np_(got)
         np.testing.assert_array_equal(np_(a), oa, err_msg=f"actions, {label}")
         orew, odone, otrunc, rc = ob.step(oa)
         assert rc == 0
