@@ -852,9 +852,17 @@ template <class ROW>
 static void qnet_pack(const int32_t *d, const float *const *W, const float *const *Bv, const float *slopes, float *out) {
     using Q = QNet<ROW>;
     std::fill(out, out + Q::kPacked, 0.0f);
-    for (int f = 0; f < Q::F; f++) // layer 1, transposed: one row per feature (the zero row F + 1 stays zero)
+    // layer 1, transposed: one row per position bit (row kZero stays zero) ...
+    for (int f = 0; f < Q::kOneHot; f++)
         for (int n = 0; n < d[1]; n++) out[Q::oW1 + f * Q::kRowStride + n] = W[0][(size_t)n * Q::F + f];
-    for (int n = 0; n < d[1]; n++) out[Q::oW1 + Q::F * Q::kRowStride + n] = Bv[0][n];
+    // ... and one per combination v of the bits behind the one-hots: b1 + the columns of v's set bits, lowest first (float32 sums)
+    for (int v = 0; v < (1 << Q::kTailBits); v++)
+        for (int n = 0; n < d[1]; n++) {
+            float acc = Bv[0][n];
+            for (int bit = 0; bit < Q::kTailBits; bit++)
+                if ((v >> bit) & 1) acc += W[0][(size_t)n * Q::F + Q::kOneHot + bit];
+            out[Q::oW1 + (Q::kTail + v) * Q::kRowStride + n] = acc;
+        }
     const int off_w[4] = {Q::oW2, Q::oW3, Q::oW4, Q::oW5}, off_b[4] = {Q::oB2, Q::oB3, Q::oB4, Q::oB5};
     const int pad[6] = {Q::F, Q::H1, Q::H2, Q::H3, Q::H4, Q::NO};
     for (int l = 1; l < 5; l++) {

@@ -27,6 +27,7 @@
 
 #include "susnet_device.h"
 #include "susnet_flat.h"
+#include "susnet_kernels.h" // static_for
 
 namespace susnet {
 
@@ -38,58 +39,51 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class ROW>
 struct QNet {
     static constexpr int F = ROW::F, H1 = 256, H2 = 128, H3 = 64, H4 = 32, NO = 32;
-    static constexpr int kOnes = 2 * ROW::A + (ROW::F > ROW::kOneHot ? ROW::A : 0); // most set bits of a row (positions, alive flags, closest)
-    static constexpr int kRows = F + 2;      // + the bias row (index F) + an all-zero row (index F + 1) for absent bits
-    static constexpr int kRowStride = H1 + 4; // floats: consecutive feature rows start 4 banks apart
+    // LDS image of layer 1, one row of H1 floats per entry: rows 0 .. kOneHot - 1 = the W1 columns of the position one-hots; row kZero =
+    // all zeros (a dead agent's positions, component.py:226-240); rows kTail + v = b1 + the W1 columns of the set bits of v, v = the
+    // row's bits BEHIND the one-hots (alive flags, closest crew: 2^kTailBits combinations, summed on the host; no such bits: just b1).
+    // h1 = sum of 2 A position rows + ONE tail row: 2 A + 1 LDS reads per 16-byte slice instead of one per set bit + bias.
+    static constexpr int kOneHot = ROW::kOneHot, kTailBits = F - kOneHot, kZero = kOneHot, kTail = kOneHot + 1;
+    static constexpr int kGather = 2 * ROW::A + 1;
+    static constexpr int kRows = kTail + (1 << kTailBits);
+    static constexpr int kRowStride = H1 + 4; // floats: consecutive rows start 4 banks apart
     static constexpr int kW1 = kRows * kRowStride;
-    // packed image, in floats (susnet_qnet_pack writes it, the kernel reads it):
-    static constexpr int oW1 = 0, oW2 = oW1 + kW1, oB2 = oW2 + H1 * H2, oW3 = oB2 + H2, oB3 = oW3 + H2 * H3, oW4 = oB3 + H3, oB4 = oW4 + H3 * H4,
-                         oW5 = oB4 + H4, oB5 = oW5 + H4 * NO, oSlope = oB5 + NO, kPacked = oSlope + 4;
-    static constexpr int kLdsBytes = kW1 * 4;
+    // packed image, in floats (susnet_qnet_pack writes it, the kernel reads it).  First the part every workgroup copies to LDS
+    // (layer 1 transposed + the biases of layers 2..5), then ALL 32 x 32 weight blocks of layers 2..5 as one stream in the order the
+    // kernel consumes them, then the four PReLU slopes.
+    static constexpr int oW1 = 0, oB2 = oW1 + kW1, oB3 = oB2 + H2, oB4 = oB3 + H3, oB5 = oB4 + H4, kLdsFloats = oB5 + NO;
+    static constexpr int oW2 = kLdsFloats, oW3 = oW2 + H1 * H2, oW4 = oW3 + H2 * H3, oW5 = oW4 + H3 * H4, oSlope = oW5 + H4 * NO, kPacked = oSlope + 4;
+    static constexpr int kBlocks = (H1 * H2 + H2 * H3 + H3 * H4 + H4 * NO) / 1024; // of the stream
+    static constexpr int kLdsBytes = kLdsFloats * 4;
     static constexpr int kThreads = 256, kEnvsPerWave = 64, kEnvsPerBlock = 4 * kEnvsPerWave;
+    static_assert(kTailBits >= 0 && kTailBits <= 4 && kLdsFloats % 4 == 0 && H2 / 32 == 4 && (H1 / 32) % 2 == 0, "16-byte copies; the pipelined stage is written for this shape");
 };
 
-// positions of a row's set bits, ascending, padded with `fill`
-template <class ROW, int MAXONES>
-__device__ __forceinline__ void flat_row_ones(const ROW &row, uint32_t (&idx)[MAXONES], uint32_t fill) {
-    uint32_t w[ROW::MW];
+// torch.prelu: x > 0 ? x : slope * x.  UNIT (every slope of the network in [0, 1], the usual case: nn.PReLU() starts at 0.25): the same
+// value as max(x, slope * x) -- two instructions per element (the multiply packs) instead of three.
+template <bool UNIT>
+__device__ __forceinline__ float prelu(float x, float slope) {
+    if constexpr (UNIT) return __builtin_fmaxf(x, slope * x);
+    else return x > 0.0f ? x : slope * x;
+}
+template <bool UNIT>
+__device__ __forceinline__ void prelu16(f32x16 &v, float slope) {
 #pragma unroll
-    for (int i = 0; i < ROW::MW; i++) w[i] = row.m[i];
-#pragma unroll
-    for (int q = 0; q < MAXONES; q++) {
-        uint32_t f = fill;
-        bool found = false;
-#pragma unroll
-        for (int i = 0; i < ROW::MW; i++) {
-            const bool take = !found && w[i] != 0u;
-            f = take ? (uint32_t)(32 * i) + (uint32_t)__builtin_ctz(w[i] | 0x80000000u) : f;
-            w[i] = take ? (w[i] & (w[i] - 1u)) : w[i];
-            found = found || take;
-        }
-        idx[q] = f;
-    }
+    for (int i = 0; i < 16; i++) v[i] = prelu<UNIT>(v[i], slope);
 }
 
-__device__ __forceinline__ void prelu16(f32x16 &v, float slope) { // torch.prelu: x > 0 ? x : slope * x
+// HALF of a 32 x 32 weight block (float4 2 HALF and 2 HALF + 1 of the lane's 16 k values, MFMA steps 8 HALF .. 8 HALF + 7) times
+// T activation blocks: 8 T MFMAs on T independent accumulators
+template <int HALF, int T>
+__device__ __forceinline__ void mfma_half(const f32x4 (&w)[4], const f32x16 (&in)[T], f32x16 (&acc)[T]) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = v[i] > 0.0f ? v[i] : slope * v[i];
-}
-
-// one 32 x 32 weight block (lane: output row n = lane % 32; its 16 k values in MFMA-step order) times T activation blocks
-template <int T>
-__device__ __forceinline__ void mfma_block(const f32x4 (&w)[4], const f32x16 (&in)[T], f32x16 (&acc)[T]) {
-#pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 2 * HALF; q < 2 * HALF + 2; q++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int t = 0; t < T; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q][r], in[t][4 * q + r], acc[t], 0, 0, 0);
 }
-__device__ __forceinline__ void load_block(f32x4 (&w)[4], const f32x4 *blk, int lane) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) w[q] = blk[q * 64 + lane];
-}
-// accumulators start as the layer's bias: register 4 q + r of half h is row 8 q + 4 h + r of the block
+// accumulators start as the layer's bias (LDS): register 4 q + r of half h is row 8 q + 4 h + r of the block
 template <int T>
 __device__ __forceinline__ void bias_block(const float *bias, int nb, int h, f32x16 (&acc)[T]) {
 #pragma unroll
@@ -101,121 +95,144 @@ __device__ __forceinline__ void bias_block(const float *bias, int nb, int h, f32
             for (int t = 0; t < T; t++) acc[t][4 * q + r] = b[r];
     }
 }
-// a register-resident dense layer: in[KB][T] (activated) -> out[NB][T] (bias + sum, not yet activated); weight blocks in [kb][nb] order
-template <int KB, int NB, int T>
-__device__ __forceinline__ void dense(const float *wp, const float *bias, int lane, const f32x16 (&in)[KB][T], f32x16 (&out)[NB][T]) {
-    const int h = lane >> 5;
+// The weight stream: block b of the packed image lives in register buffer b % 4 and is requested two blocks (64 T MFMAs >= 4 000
+// cycles) before its first use, so an L2 round trip never stalls the matrix core; sched_barrier keeps the compiler from sinking a
+// request down to its use.
+struct WeightStream {
+    __amdgpu_buffer_rsrc_t r; // the stream as a raw buffer: the block offset rides in the scalar offset, the float4 index in the immediate
+    uint32_t lane16;          // 16 * lane
+    int lane;
+    template <int BUF>
+    __device__ __forceinline__ void request(f32x4 (&w)[4][4], int block, int last) const {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t so = (uint32_t)(block < last ? block : last) * 4096u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane16 + 1024u * q, so, 0);
+            w[BUF][q] = __builtin_bit_cast(f32x4, v);
+        }
+    }
+};
+// a register-resident dense layer on stream blocks B0 .. B0 + KB NB - 1 ([kb][nb] order): in[KB][T] (activated) -> out[NB][T] (bias + sum)
+template <int B0, int KB, int NB, int T, int LAST>
+__device__ __forceinline__ void dense(const WeightStream &ws, f32x4 (&w)[4][4], const float *bias, const f32x16 (&in)[KB][T], f32x16 (&out)[NB][T]) {
+    const int h = ws.lane >> 5;
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) bias_block<T>(bias, nb, h, out[nb]);
-    const f32x4 *blk = reinterpret_cast<const f32x4 *>(wp);
-#pragma unroll
-    for (int kb = 0; kb < KB; kb++)
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            f32x4 w[4];
-            load_block(w, blk + (kb * NB + nb) * 256, lane);
-            mfma_block<T>(w, in[kb], out[nb]);
+    static_for<0, KB * NB>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, kb = i / NB, nb = i % NB, b = B0 + i;
+        if constexpr (b % 2 == 0) { // (two requests at a time: every MFMA -> load transition costs issue cycles)
+            ws.template request<(b + 2) % 4>(w, b + 2, LAST);
+            ws.template request<(b + 3) % 4>(w, b + 3, LAST);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        mfma_half<0, T>(w[b % 4], in[kb], out[nb]);
+        mfma_half<1, T>(w[b % 4], in[kb], out[nb]);
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 // Q rows of the handle's CURRENT environments: q_out [B][n_out] float32.  256 threads = 4 waves (one per SIMD) share the LDS
 // image of layer 1; wave w of block g owns environments (4 g + w) * 64 ..; lane = (column m = lane % 32, half h = lane / 32) of each
 // of its two 32-environment tiles.
-template <class ROW>
-__global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk, float *q_out, int n_out) {
+template <class ROW, bool UNIT>
+__device__ __forceinline__ void qnet_wave(const Consts &c, const State &s, const float *pk, const float *w1, float *q_out, int n_out, int64_t b0, int lane) {
     using Q = QNet<ROW>;
-    constexpr int T = 2;
-    extern __shared__ float w1[];
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(pk + Q::oW1);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(w1);
-        for (int i = threadIdx.x; i < Q::kW1 / 4; i += Q::kThreads) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
-    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * Q::kEnvsPerWave;
-    if (b0 >= c.B) return; // (after the only barrier)
+    constexpr int T = 2, R = Q::kGather;
+    const int m = lane & 31, h = lane >> 5;
     const float slope1 = pk[Q::oSlope + 0], slope2 = pk[Q::oSlope + 1], slope3 = pk[Q::oSlope + 2], slope4 = pk[Q::oSlope + 3];
+    constexpr int kLast = Q::kBlocks - 1;
+    const WeightStream ws = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pk + Q::oW2), 0, Q::kBlocks * 4096, 0x00020000), (uint32_t)lane * 16u, lane};
+    f32x4 w[4][4]; // block b of the stream sits in w[b % 4]; blocks b + 2, b + 3 are requested while b, b + 1 are multiplied
+    ws.template request<0>(w, 0, kLast);
+    ws.template request<1>(w, 1, kLast);
 
-    // the <= kOnes feature rows of each tile's environment, as LDS addresses of this half's 16-byte column slice
-    const float *rowp[T][Q::kOnes];
+    // the R rows of each tile's environment, as LDS addresses of this half's 16-byte column slice
+    const float *rowp[T][R];
 #pragma unroll
     for (int t = 0; t < T; t++) {
         const int64_t b = b0 + 32 * t + m;
-        ROW row;
-        row.clear();
-        if (b < c.B) {
-            uint32_t fx[ROW::A], fy[ROW::A], fal[ROW::A];
+        uint32_t fx[ROW::A], fy[ROW::A], fal[ROW::A];
 #pragma unroll
-            for (int i = 0; i < ROW::A; i++) {
-                const uint32_t w = s.agent[(size_t)i * c.Bp + b];
-                fx[i] = w & 15u;
-                fy[i] = (w >> 4) & 15u;
-                fal[i] = (w >> 8) & 1u;
-            }
-            row.build(fx, fy, fal);
+        for (int i = 0; i < ROW::A; i++) {
+            const uint32_t aw = b < c.B ? (uint32_t)s.agent[(size_t)i * c.Bp + b] : 0u;
+            fx[i] = aw & 15u;
+            fy[i] = (aw >> 4) & 15u;
+            fal[i] = (aw >> 8) & 1u;
         }
-        uint32_t idx[Q::kOnes];
-        flat_row_ones<ROW, Q::kOnes>(row, idx, (uint32_t)(Q::F + 1));
+        ROW row; // the feature row itself (susnet_flat.h): only its bits behind the one-hots are needed, but they come from build()
+        row.build(fx, fy, fal);
+        uint32_t tail = 0;
+        if constexpr (Q::kTailBits > 0) {
+            static_assert(Q::kOneHot / 32 == (Q::F - 1) / 32, "the tail bits sit in one mask word");
+            tail = (row.m[Q::kOneHot / 32] >> (Q::kOneHot & 31)) & ((1u << Q::kTailBits) - 1u);
+        }
+        rowp[t][0] = w1 + (Q::kTail + tail) * Q::kRowStride + 4 * h;
 #pragma unroll
-        for (int q = 0; q < Q::kOnes; q++) rowp[t][q] = w1 + idx[q] * Q::kRowStride + 4 * h;
+        for (int i = 0; i < ROW::A; i++) { // component.py:226-240: [onehot_N(x) | onehot_N(y)] per agent, zeros if dead
+            rowp[t][1 + 2 * i] = w1 + (fal[i] ? (uint32_t)(i * 2 * ROW::N) + fx[i] : (uint32_t)Q::kZero) * Q::kRowStride + 4 * h;
+            rowp[t][2 + 2 * i] = w1 + (fal[i] ? (uint32_t)(i * 2 * ROW::N + ROW::N) + fy[i] : (uint32_t)Q::kZero) * Q::kRowStride + 4 * h;
+        }
     }
-    const float *biasp = w1 + Q::F * Q::kRowStride + 4 * h;
 
-    // layers 1 + 2: h1 block kb (32 features) by gather, then straight into layer 2 as its k block kb
+    // Layers 1 + 2.  h1 block kb (32 features x 64 environments: per tile and 8-column slice R 16-byte LDS reads, their sum, PReLU) is
+    // gathered and consumed at once as k block kb of layer 2.  v_mfma_f32_32x32x2_f32 holds the SIMD's vector issue for all of its 64
+    // cycles (tools/mfma_f32_fillers.hip: every VALU / LDS instruction placed beside it costs its full issue time, the first one after
+    // an MFMA 12 cycles more), so nothing hides in its shadow: a stage is a gather CLUSTER followed by 128 back-to-back MFMAs, never an
+    // interleaving, and the k loop is unrolled so that every LDS offset is an immediate.
     f32x16 a2[Q::H2 / 32][T];
 #pragma unroll
-    for (int nb = 0; nb < Q::H2 / 32; nb++) bias_block<T>(pk + Q::oB2, nb, h, a2[nb]);
-    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(pk + Q::oW2);
-    f32x4 wa[4], wb[4];
-    load_block(wa, w2, lane);
-#pragma unroll 1
-    for (int kb = 0; kb < Q::H1 / 32; kb++) {
+    for (int nb = 0; nb < Q::H2 / 32; nb++) bias_block<T>(w1 + Q::oB2, nb, h, a2[nb]);
+    static_for<0, Q::H1 / 32>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kc)::value;
+        ws.template request<2>(w, kb * 4 + 2, kLast);
+        ws.template request<3>(w, kb * 4 + 3, kLast);
         f32x16 hb[T];
 #pragma unroll
-        for (int t = 0; t < T; t++) {
+        for (int t = 0; t < T; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int col = kb * 32 + 8 * j; // (+ 4 h inside the row pointers)
-                f32x4 v = *reinterpret_cast<const f32x4 *>(biasp + col);
+                f32x4 v = *reinterpret_cast<const f32x4 *>(rowp[t][0] + kb * 32 + 8 * j);
 #pragma unroll
-                for (int q = 0; q < Q::kOnes; q++) v += *reinterpret_cast<const f32x4 *>(rowp[t][q] + col);
+                for (int q = 1; q < R; q++) v += *reinterpret_cast<const f32x4 *>(rowp[t][q] + kb * 32 + 8 * j);
 #pragma unroll
-                for (int r = 0; r < 4; r++) hb[t][4 * j + r] = v[r];
+                for (int r = 0; r < 4; r++) hb[t][4 * j + r] = prelu<UNIT>(v[r], slope1);
             }
-            prelu16(hb[t], slope1);
-        }
-        const f32x4 *blk = w2 + (size_t)kb * (Q::H2 / 32) * 256;
-        const f32x4 *nxt = w2 + (size_t)(kb + 1 < Q::H1 / 32 ? kb + 1 : kb) * (Q::H2 / 32) * 256;
-        static_assert(Q::H2 / 32 == 4, "the weight double buffer below is written for four row blocks");
-        load_block(wb, blk + 1 * 256, lane);
-        mfma_block<T>(wa, hb, a2[0]);
-        load_block(wa, blk + 2 * 256, lane);
-        mfma_block<T>(wb, hb, a2[1]);
-        load_block(wb, blk + 3 * 256, lane);
-        mfma_block<T>(wa, hb, a2[2]);
-        load_block(wa, nxt, lane);
-        mfma_block<T>(wb, hb, a2[3]);
-    }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half<0, T>(w[0], hb, a2[0]);
+        mfma_half<1, T>(w[0], hb, a2[0]);
+        mfma_half<0, T>(w[1], hb, a2[1]);
+        mfma_half<1, T>(w[1], hb, a2[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        ws.template request<0>(w, kb * 4 + 4, kLast);
+        ws.template request<1>(w, kb * 4 + 5, kLast);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half<0, T>(w[2], hb, a2[2]);
+        mfma_half<1, T>(w[2], hb, a2[2]);
+        mfma_half<0, T>(w[3], hb, a2[3]);
+        mfma_half<1, T>(w[3], hb, a2[3]);
+        __builtin_amdgcn_sched_barrier(0);
+    });
 #pragma unroll
     for (int nb = 0; nb < Q::H2 / 32; nb++)
 #pragma unroll
-        for (int t = 0; t < T; t++) prelu16(a2[nb][t], slope2);
+        for (int t = 0; t < T; t++) prelu16<UNIT>(a2[nb][t], slope2);
 
+    constexpr int kB3 = Q::H1 / 32 * 4, kB4 = kB3 + (Q::H2 / 32) * (Q::H3 / 32), kB5 = kB4 + (Q::H3 / 32) * (Q::H4 / 32);
     f32x16 a3[Q::H3 / 32][T];
-    dense<Q::H2 / 32, Q::H3 / 32, T>(pk + Q::oW3, pk + Q::oB3, lane, a2, a3);
+    dense<kB3, Q::H2 / 32, Q::H3 / 32, T, kLast>(ws, w, w1 + Q::oB3, a2, a3);
 #pragma unroll
     for (int nb = 0; nb < Q::H3 / 32; nb++)
 #pragma unroll
-        for (int t = 0; t < T; t++) prelu16(a3[nb][t], slope3);
+        for (int t = 0; t < T; t++) prelu16<UNIT>(a3[nb][t], slope3);
 
     f32x16 a4[Q::H4 / 32][T];
-    dense<Q::H3 / 32, Q::H4 / 32, T>(pk + Q::oW4, pk + Q::oB4, lane, a3, a4);
+    dense<kB4, Q::H3 / 32, Q::H4 / 32, T, kLast>(ws, w, w1 + Q::oB4, a3, a4);
 #pragma unroll
-    for (int t = 0; t < T; t++) prelu16(a4[0][t], slope4);
+    for (int t = 0; t < T; t++) prelu16<UNIT>(a4[0][t], slope4);
 
     f32x16 a5[Q::NO / 32][T];
-    dense<Q::H4 / 32, Q::NO / 32, T>(pk + Q::oW5, pk + Q::oB5, lane, a4, a5); // dqn.py:328: no activation after the last Linear
+    dense<kB5, Q::H4 / 32, Q::NO / 32, T, kLast>(ws, w, w1 + Q::oB5, a4, a5); // dqn.py:328: no activation after the last Linear
 
 #pragma unroll
     for (int t = 0; t < T; t++) {
@@ -228,6 +245,37 @@ __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk
             }
         }
     }
+}
+
+template <class ROW>
+__global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk, float *q_out, int n_out) {
+    using Q = QNet<ROW>;
+    extern __shared__ float w1[];
+    { // the LDS image: every load in flight before the first write (one memory round trip, not kFill of them)
+        constexpr int kFill = (Q::kLdsFloats / 4 + Q::kThreads - 1) / Q::kThreads;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(pk);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(w1);
+        f32x4 tmp[kFill];
+#pragma unroll
+        for (int i = 0; i < kFill; i++) {
+            const int k = (int)threadIdx.x + Q::kThreads * i;
+            tmp[i] = src[k < Q::kLdsFloats / 4 ? k : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < kFill; i++) {
+            const int k = (int)threadIdx.x + Q::kThreads * i;
+            if (k < Q::kLdsFloats / 4) dst[k] = tmp[i];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * Q::kEnvsPerWave;
+    if (b0 >= c.B) return; // (after the only barrier)
+    bool unit = true; // wave-uniform: scalar loads and compares
+#pragma unroll
+    for (int l = 0; l < 4; l++) unit = unit && pk[Q::oSlope + l] >= 0.0f && pk[Q::oSlope + l] <= 1.0f;
+    if (unit) qnet_wave<ROW, true>(c, s, pk, w1, q_out, n_out, b0, lane);
+    else qnet_wave<ROW, false>(c, s, pk, w1, q_out, n_out, b0, lane);
 }
 
 } // namespace susnet

@@ -167,8 +167,8 @@ def test_obs_sizes_follow_the_reference_featurizers(pkg):
 
 def test_qnet_pack_layout(pkg):
     """susnet_qnet_pack (host code): the packed image of a reference MLP [88, 200, 100, 50, 16, 7] -- hidden widths that need padding --
-    against the layout include/susnet.h / susnet_qnet.h describe: layer 1 transposed (one padded row per feature, bias row, zero row),
-    layers 2.. as 32 x 32 blocks in [k block][row block] order whose lane l holds row 32 nb + l % 32 and, as four float4, the columns
+    against the layout include/susnet.h / susnet_qnet.h describe: layer 1 transposed (one padded row per position bit, a zero row, and
+    one row per combination of the alive / closest bits = b1 + their columns), layers 2.. as 32 x 32 blocks in [k block][row block] order whose lane l holds row 32 nb + l % 32 and, as four float4, the columns
     32 kb + 8 q + 4 (l / 32) + r; unserved shapes are refused."""
     L = pkg._lib
     lib = L.lib()
@@ -180,8 +180,9 @@ def test_qnet_pack_layout(pkg):
     n = lib.susnet_qnet_packed_floats(h, comps, 3, cd, 6)
     pad = [88, 256, 128, 64, 32, 32]
     RS = 256 + 4
-    sizes = [(88 + 2) * RS] + [pad[l] * pad[l + 1] + pad[l + 1] for l in range(1, 5)] + [4]
-    assert n == sum(sizes)
+    rows = 84 + 1 + 16  # position bits, the zero row, 2^4 combinations of the four bits behind the one-hots
+    lds = rows * RS + sum(pad[2:])  # what a workgroup copies to LDS: layer 1 transposed, then the biases of layers 2..5
+    assert n == lds + sum(pad[l] * pad[l + 1] for l in range(1, 5)) + 4
     rng = np.random.default_rng(0)
     W = [rng.standard_normal((dims[l + 1], dims[l])).astype(np.float32) for l in range(5)]
     Bv = [rng.standard_normal(dims[l + 1]).astype(np.float32) for l in range(5)]
@@ -190,22 +191,30 @@ def test_qnet_pack_layout(pkg):
     wp = (C.c_void_p * 5)(*[w.ctypes.data for w in W])
     bp = (C.c_void_p * 5)(*[b.ctypes.data for b in Bv])
     assert lib.susnet_qnet_pack(h, comps, 3, cd, 6, wp, bp, sl.ctypes.data, out.ctypes.data) == 0
-    w1 = out[:sizes[0]].reshape(90, RS)
-    np.testing.assert_array_equal(w1[:88, :200], W[0].T)
-    np.testing.assert_array_equal(w1[88, :200], Bv[0])
-    assert not w1[:, 200:].any() and not w1[89].any()
-    off = sizes[0]
+    w1 = out[:rows * RS].reshape(rows, RS)
+    np.testing.assert_array_equal(w1[:84, :200], W[0].T[:84])
+    assert not w1[:, 200:].any() and not w1[84].any()
+    for v in range(16):
+        want = Bv[0].copy()
+        for bit in range(4):
+            if (v >> bit) & 1:
+                want = want + W[0][:, 84 + bit]  # float32, lowest bit first
+        np.testing.assert_array_equal(w1[85 + v, :200], want)
+    off = rows * RS
     for l in range(1, 5):
+        bias = np.zeros(pad[l + 1], dtype=np.float32)
+        bias[:dims[l + 1]] = Bv[l]
+        np.testing.assert_array_equal(out[off:off + pad[l + 1]], bias)
+        off += pad[l + 1]
+    assert off == lds
+    for l in range(1, 5):  # the weight stream: layers 2..5 back to back, 32 x 32 blocks in [k block][row block] order
         KP, NP = pad[l], pad[l + 1]
         full = np.zeros((NP, KP), dtype=np.float32)
         full[:dims[l + 1], :dims[l]] = W[l]
         blk = out[off:off + KP * NP].reshape(KP // 32, NP // 32, 4, 64, 4)
         kb, nb, q, lane, r = np.meshgrid(*[np.arange(k) for k in blk.shape], indexing="ij")
         np.testing.assert_array_equal(blk, full[32 * nb + lane % 32, 32 * kb + 8 * q + 4 * (lane // 32) + r])
-        bias = np.zeros(NP, dtype=np.float32)
-        bias[:dims[l + 1]] = Bv[l]
-        np.testing.assert_array_equal(out[off + KP * NP:off + KP * NP + NP], bias)
-        off += KP * NP + NP
+        off += KP * NP
     np.testing.assert_array_equal(out[off:], sl)
     # refused: another depth, a layer wider than the compiled-in family, a feature layout without a compiled-in writer
     assert lib.susnet_qnet_packed_floats(h, comps, 3, (C.c_int32 * 5)(88, 256, 128, 64, 7), 5) == L.E_INVALID
