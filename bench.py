@@ -57,11 +57,12 @@ CONFIGS = {
     # BASELINE.json configs[4]: cfg3's env driven by the reference-architecture MLP (no checkpoints ship with the
     # reference: seeded random init), greedy imposter + uniformly random crew, everything on the device
     "cfg5": dict(workload="cfg5: cfg3 env (1v2, 14x14 walled, 4 jobs) driven by MLP[88,256,128,64,16,7] imposter policy "
-                          "(torch-ROCm fp32 inference) + random crew, batch 65536/GPU",
+                          "(float32: susnet_qnet_forward, one HIP kernel on the f32-input MFMA) + random crew, batch 65536/GPU",
                  cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536, policy=True),
 }
 POLICY_COMPONENTS = ["onehot_pos", "alive_crew", "closest_crew"]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA, dense (= the f32 vector rate)
 
 
 def algorithmic_bytes_per_step(A, J, N, obs):
@@ -308,7 +309,7 @@ def main():
             env.step(a)
         return 2 * n_ticks
 
-    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0):
+    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0, policy_fused=True):
         """W untimed + K timed bench steps of one configuration.  fused: a step is one launch of `ticks` ticks; step / policy:
         one tick (policy with graph_ticks > 0: the tick loop replayed as hipGraphs of graph_ticks ticks, K rounded up to whole graphs)."""
         oc = obs_config(obs_mode) if mode == "fused" else None
@@ -324,7 +325,8 @@ def main():
         bufs = env.alloc_rollout(ticks, obs=oc, packed=packed) if mode == "fused" else None
         if mode == "policy":
             model = pkg.policy.reference_imposter_mlp(env, POLICY_COMPONENTS, seed=0)
-            pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS)
+            pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS, fused=policy_fused)
+            assert (pr.fused_imposter is not None) == policy_fused, "the reference MLP on this layout is served by susnet_qnet_forward"
             if graph_ticks > 0:
                 graph, _ = pr.capture(graph_ticks)
                 K = (K + graph_ticks - 1) // graph_ticks * graph_ticks
@@ -368,9 +370,29 @@ def main():
             launch_us_ranks = [float(v.item()) for v in allv]
         env.poll_errors()
         metrics = pkg.dist.node_metrics(env)  # the ONE collective: all-gather of the episode totals
+        qnet = None
+        if mode == "policy" and policy_fused:  # the network kernel by itself, outside the timed region: 50 launches between two events
+            net = pr.fused_imposter
+            for _ in range(5):
+                env.qnet_forward(net)
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            q0.record(stream)
+            for _ in range(50):
+                env.qnet_forward(net)
+            q1.record(stream)
+            torch.cuda.synchronize(device)
+            us = q0.elapsed_time(q1) * 1e3 / 50
+            pad = [net.dims[0], 256, 128, 64, 32, 32]
+            issued = 2.0 * B * sum(a * b for a, b in zip(pad[1:-1], pad[2:]))       # layers 2..5 at their padded widths: what the matrix core executes
+            model_flops = 2.0 * B * sum(a * b for a, b in zip(net.dims[:-1], net.dims[1:]))  # the reference MLP's own multiply-adds, layer 1 included
+            qnet = {"kernel": "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward)", "bound": "mfma", "avg_launch_us": us, "unit": "TFLOP/s",
+                    "peak": MFMA_F32_PEAK_TFLOPS, "achieved": issued / us / 1e6, "frac": issued / us / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                    "model_flops_per_launch": model_flops, "model_tflops": model_flops / us / 1e6,
+                    "note": "achieved = flops of the v_mfma_f32_32x32x2_f32 instructions issued (layers 2..5, padded widths) / launch time; layer 1 "
+                            "(35 % of the model's multiply-adds) is a gather of W1 columns and issues no MFMA, so model_tflops exceeds it"}
         return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, pair_us=pair_us, packed=packed, steps=K, warmup=W,
                     raw_size=env.flattened_state_size, record_bytes=lay.record_bytes if lay is not None else None,
-                    launch_us_ranks=launch_us_ranks)
+                    launch_us_ranks=launch_us_ranks, qnet=qnet)
 
     K, W = args.steps, args.warmup
     spec = CONFIGS[args.config]
@@ -407,12 +429,11 @@ def main():
         "roofline": roof,
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
+    if args.mode == "policy":  # the tick's dominant kernel is the Q-network: its roofline is the f32 matrix peak
+        line["roofline"] = dict(res["qnet"], traffic=None)
+        line["dtype"] = "f32"
+        line["config"]["policy_forward"] = "susnet_qnet_forward: one HIP kernel from the state words to the Q rows (float32, f32-input MFMA)"
     del res
-    if args.mode == "policy":
-        line["roofline"].update(achieved=None, frac=None, survey_8d_achieved=None, survey_8d_frac=None,
-                                kernel="k_step<PhiloxRng, Spec<3,4,..>> + hipBLASLt GEMMs",
-                                note="policy loop: per-tick time is dominated by the 5 fp32 GEMMs and host launch gaps, not by "
-                                     "the env kernel; no single-kernel roofline is claimed for this config")
     secondary = rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy"
     if secondary:
         other = "step" if args.mode == "fused" else "fused"
@@ -464,13 +485,17 @@ def main():
             sp = CONFIGS[name]
             if sp.get("policy"):
                 entry = {"config": name, "workload": sp["workload"], "unit": "env-steps/s"}
-                for label, gt in (("eager", 0), ("hip_graph_replay", 8)):
-                    rp = measure(sp, sp["batch"], "policy", "flat", 64, 16, 1, graph_ticks=gt)
+                for label, gt, fused in (("eager", 0, True), ("hip_graph_replay", 8, True), ("torch_modules_hip_graph_replay", 8, False)):
+                    rp = measure(sp, sp["batch"], "policy", "flat", 64, 16, 1, graph_ticks=gt, policy_fused=fused)
                     entry[label] = {"value": sp["batch"] * rp["steps"] / rp["seconds"], "us_per_tick": rp["seconds"] * 1e6 / rp["steps"],
                                     "ticks_timed": rp["steps"], **({"ticks_per_graph": gt} if gt else {})}
+                    if rp["qnet"] is not None:
+                        entry["roofline"] = rp["qnet"]
                     del rp
                 entry["value"] = max(entry["eager"]["value"], entry["hip_graph_replay"]["value"])
-                entry["kernel"] = "k_export (roles) + hipBLASLt GEMMs / PReLU (torch-ROCm fp32) + k_sample_philox + k_step<PhiloxRng, Spec<3,4,..>>"
+                entry["kernel"] = "k_qnet (susnet_qnet_forward: float32 Q-network, f32-input MFMA) + k_policy_actions + k_step<PhiloxRng, Spec<3,4,..>>"
+                entry["torch_modules_hip_graph_replay"]["note"] = ("the same tick with the network as torch modules (hipBLASLt f32 GEMMs + PReLU kernels on "
+                                                                   "the [B][88] observation): round 2's path, kept as the comparison")
                 line["other_configs"].append(entry)
                 continue
             ro = measure(sp, sp["batch"], "fused", "raw", 20, 5, 512)
