@@ -1151,6 +1151,7 @@ __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t 
 // the gather phase (flags first, unrolled without an early exit; then rows, actions, rewards, roles) and all global stores happen
 // after it.
 constexpr int kRingFlagsUnroll = 8;
+constexpr int kRingGroup = 3, kRingChunk = 8; // source states per load group; dwords of a state per load group
 __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A, NI = r.n_imp;
@@ -1170,15 +1171,17 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
         // loads are independent of each other
         int64_t e = -(1ll << 62);
         if (Tw <= kRingFlagsUnroll) {
-            uint32_t fl[kRingFlagsUnroll];
+            uint32_t fd[kRingFlagsUnroll], ft[kRingFlagsUnroll];
 #pragma unroll
-            for (int k = 1; k <= kRingFlagsUnroll; k++) {
-                const int64_t u = t - k;
-                fl[k - 1] = (k <= Tw && u >= 0) ? (uint32_t)(r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) : 0u;
+            for (int k = 1; k <= kRingFlagsUnroll; k++) { // every lane loads (tick clamped): no per-lane branch, no wait between the loads
+                const int64_t u = t - k < 0 ? 0 : t - k;
+                const bool want = k <= Tw; // (wave-uniform)
+                fd[k - 1] = want ? (uint32_t)r.io.done[u * r.B + b] : 0u;
+                ft[k - 1] = want ? (uint32_t)r.io.truncated[u * r.B + b] : 0u;
             }
 #pragma unroll
             for (int k = kRingFlagsUnroll; k >= 1; k--)
-                if (fl[k - 1]) e = t - k; // (descending k: the most recent boundary wins)
+                if ((fd[k - 1] | ft[k - 1]) != 0u && t - k >= 0) e = t - k; // (descending k: the most recent boundary wins)
         } else {
             for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
                 if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
@@ -1186,43 +1189,75 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
         const uint32_t dn = r.io.done[t * r.B + b], tr = r.io.truncated[t * r.B + b];
         const uint32_t role_bits = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << NI) - 1u);
         uint8_t *my_st = st_img + (size_t)lane * TS, *my_nx = nx_img + (size_t)lane * TS;
-        // a state row = S consecutive bytes at an arbitrary address: fetched as S / 4 UNALIGNED dwords + a byte tail (gfx950
-        // serves unaligned global loads) -- a row of 21 bytes is 6 load instructions instead of 21; the LDS images take bytes
-        const int S4 = S >> 2;
-        for (int k = 0; k < Tw; k++) { // replay_memory.py:108-113, 122-127
+        // The row needs Tw + 1 source states (replay_memory.py:108-113, 122-127): the window's Tw states -> states[k], and shifted by one
+        // -> next_states[k - 1]; the state after the tick (the terminal observation where the episode ended) -> next_states[Tw - 1].  A
+        // state = S consecutive bytes at an arbitrary address, fetched as UNALIGNED dwords (gfx950 serves them, global and LDS alike) + a
+        // byte tail.  All loads of a group of kRingGroup states are issued before the first LDS store: one memory round trip per group,
+        // not one per dword (the rolled load -> store loop this replaces made 18 dependent round trips per row and left the kernel
+        // latency-bound at 3.7 TB/s).
+        const uint8_t *nxt = ((dn | tr) ? r.io.term_obs : r.io.obs) + ((size_t)t * r.B + b) * S;
+        auto source = [&](int k) -> const uint8_t * {
+            if (k >= Tw) return nxt;
             int64_t u = t - Tw + k;
             if (u < e) u = e;
-            const uint8_t *src = ring_state(r, u, b);
-            uint8_t *d0 = my_st + k * S, *d1 = k > 0 ? my_nx + (k - 1) * S : nullptr;
-            for (int j = 0; j < S4; j++) {
-                uint32_t v;
-                __builtin_memcpy(&v, src + 4 * j, 4);
+            return ring_state(r, u, b);
+        };
+        for (int k0 = 0; k0 <= Tw; k0 += kRingGroup) {
+            for (int c0 = 0; c0 < S; c0 += 4 * kRingChunk) {
+                uint32_t v[kRingGroup][kRingChunk];
+                uint8_t tail[kRingGroup][3];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    d0[4 * j + q] = (uint8_t)(v >> (8 * q));
-                    if (d1) d1[4 * j + q] = (uint8_t)(v >> (8 * q));
+                for (int g = 0; g < kRingGroup; g++) {
+                    if (k0 + g > Tw) break; // (wave-uniform)
+                    const uint8_t *src = source(k0 + g) + c0;
+#pragma unroll
+                    for (int q = 0; q < kRingChunk; q++)
+                        if (c0 + 4 * q + 4 <= S) __builtin_memcpy(&v[g][q], src + 4 * q, 4);
+                    if (S - c0 < 4 * kRingChunk) { // the row ends in this chunk: its last S % 4 bytes
+                        const int f0 = (S - c0) & ~3;
+#pragma unroll
+                        for (int q = 0; q < 3; q++)
+                            if (f0 + q < S - c0) tail[g][q] = src[f0 + q];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < kRingGroup; g++) {
+                    const int k = k0 + g;
+                    if (k > Tw) break;
+                    uint8_t *d0 = k < Tw ? my_st + k * S + c0 : nullptr, *d1 = k > 0 ? my_nx + (k - 1) * S + c0 : nullptr;
+#pragma unroll
+                    for (int q = 0; q < kRingChunk; q++)
+                        if (c0 + 4 * q + 4 <= S) {
+                            if (d0) __builtin_memcpy(d0 + 4 * q, &v[g][q], 4);
+                            if (d1) __builtin_memcpy(d1 + 4 * q, &v[g][q], 4);
+                        }
+                    if (S - c0 < 4 * kRingChunk) {
+                        const int f0 = (S - c0) & ~3;
+#pragma unroll
+                        for (int q = 0; q < 3; q++)
+                            if (f0 + q < S - c0) {
+                                if (d0) d0[f0 + q] = tail[g][q];
+                                if (d1) d1[f0 + q] = tail[g][q];
+                            }
+                    }
                 }
             }
-            for (int f = 4 * S4; f < S; f++) {
-                const uint8_t v = src[f];
-                d0[f] = v;
-                if (d1) d1[f] = v;
-            }
         }
-        const uint8_t *nxt = ((dn | tr) ? r.io.term_obs : r.io.obs) + ((size_t)t * r.B + b) * S;
-        {
-            uint8_t *d = my_nx + (Tw - 1) * S;
-            for (int j = 0; j < S4; j++) {
-                uint32_t v;
-                __builtin_memcpy(&v, nxt + 4 * j, 4);
+        for (int i0 = 0; i0 < A; i0 += 8) { // (loads of eight agents in flight, then their LDS stores)
+            uint8_t av[8];
+            float rv[8];
 #pragma unroll
-                for (int q = 0; q < 4; q++) d[4 * j + q] = (uint8_t)(v >> (8 * q));
-            }
-            for (int f = 4 * S4; f < S; f++) d[f] = nxt[f];
-        }
-        for (int i = 0; i < A; i++) {
-            act_img[lane * A + i] = r.io.actions[((size_t)t * r.B + b) * A + i];
-            rew_img[lane * A + i] = r.io.rewards[((size_t)t * r.B + b) * A + i];
+            for (int q = 0; q < 8; q++)
+                if (i0 + q < A) {
+                    av[q] = r.io.actions[((size_t)t * r.B + b) * A + i0 + q];
+                    rv[q] = r.io.rewards[((size_t)t * r.B + b) * A + i0 + q];
+                }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (i0 + q < A) {
+                    act_img[lane * A + i0 + q] = av[q];
+                    rew_img[lane * A + i0 + q] = rv[q];
+                }
         }
         done_img[lane] = dn ? 1 : 0; // replay_memory.py:131: done, not truncation
         uint32_t m = role_bits;
@@ -1297,12 +1332,44 @@ __global__ __launch_bounds__(64) void k_ring_window(RingArgs r) {
         if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
     // in place, slots ascending: slot k of the new window comes from obs, or (launches shorter than the window) from slot
     // k + t > k of the old one, which has not been overwritten yet
+    // (a group's loads are all issued before its first store, as in k_ring_append: a slot read from the old window lies above every slot
+    // written so far)
     uint8_t *dst = r.io.window + (size_t)b * Tw * S;
-    for (int k = 0; k < Tw; k++) {
-        int64_t u = t - Tw + k;
-        if (u < e) u = e;
-        const uint8_t *src = ring_state(r, u, b);
-        for (int f = 0; f < S; f++) dst[k * S + f] = src[f];
+    for (int k0 = 0; k0 < Tw; k0 += kRingGroup) {
+        for (int c0 = 0; c0 < S; c0 += 4 * kRingChunk) {
+            uint32_t v[kRingGroup][kRingChunk];
+            uint8_t tail[kRingGroup][3];
+#pragma unroll
+            for (int g = 0; g < kRingGroup; g++) {
+                if (k0 + g >= Tw) break;
+                int64_t u = t - Tw + k0 + g;
+                if (u < e) u = e;
+                const uint8_t *src = ring_state(r, u, b) + c0;
+#pragma unroll
+                for (int q = 0; q < kRingChunk; q++)
+                    if (c0 + 4 * q + 4 <= S) __builtin_memcpy(&v[g][q], src + 4 * q, 4);
+                if (S - c0 < 4 * kRingChunk) {
+                    const int f0 = (S - c0) & ~3;
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+                        if (f0 + q < S - c0) tail[g][q] = src[f0 + q];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < kRingGroup; g++) {
+                if (k0 + g >= Tw) break;
+                uint8_t *d = dst + (k0 + g) * S + c0;
+#pragma unroll
+                for (int q = 0; q < kRingChunk; q++)
+                    if (c0 + 4 * q + 4 <= S) __builtin_memcpy(d + 4 * q, &v[g][q], 4);
+                if (S - c0 < 4 * kRingChunk) {
+                    const int f0 = (S - c0) & ~3;
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+                        if (f0 + q < S - c0) d[f0 + q] = tail[g][q];
+                }
+            }
+        }
     }
 }
 
