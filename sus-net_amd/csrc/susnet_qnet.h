@@ -136,7 +136,8 @@ __device__ __forceinline__ void dense(const WeightStream &ws, f32x4 (&w)[4][4], 
 // image of layer 1; wave w of block g owns environments (4 g + w) * 64 ..; lane = (column m = lane % 32, half h = lane / 32) of each
 // of its two 32-environment tiles.
 template <class ROW, bool UNIT>
-__device__ __forceinline__ void qnet_wave(const Consts &c, const State &s, const float *pk, const float *w1, float *q_out, int n_out, int64_t b0, int lane) {
+__device__ __forceinline__ void qnet_wave(const Consts &c, const uint32_t (&aw)[2][ROW::A], const float *pk, const float *w1, float *q_out, int n_out, int64_t b0,
+                                          int lane) {
     using Q = QNet<ROW>;
     constexpr int T = 2, R = Q::kGather;
     const int m = lane & 31, h = lane >> 5;
@@ -151,14 +152,12 @@ __device__ __forceinline__ void qnet_wave(const Consts &c, const State &s, const
     const float *rowp[T][R];
 #pragma unroll
     for (int t = 0; t < T; t++) {
-        const int64_t b = b0 + 32 * t + m;
         uint32_t fx[ROW::A], fy[ROW::A], fal[ROW::A];
 #pragma unroll
         for (int i = 0; i < ROW::A; i++) {
-            const uint32_t aw = b < c.B ? (uint32_t)s.agent[(size_t)i * c.Bp + b] : 0u;
-            fx[i] = aw & 15u;
-            fy[i] = (aw >> 4) & 15u;
-            fal[i] = (aw >> 8) & 1u;
+            fx[i] = aw[t][i] & 15u;
+            fy[i] = (aw[t][i] >> 4) & 15u;
+            fal[i] = (aw[t][i] >> 8) & 1u; // (an environment past the batch: all zero = every agent dead, nothing stored)
         }
         ROW row; // the feature row itself (susnet_flat.h): only its bits behind the one-hots are needed, but they come from build()
         row.build(fx, fy, fal);
@@ -251,6 +250,16 @@ template <class ROW>
 __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk, float *q_out, int n_out) {
     using Q = QNet<ROW>;
     extern __shared__ float w1[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * Q::kEnvsPerWave;
+    // the state words of this lane's two environments are requested first: they arrive while the LDS image is being filled
+    uint32_t aw[2][ROW::A];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int64_t b = b0 + 32 * t + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < ROW::A; i++) aw[t][i] = b < c.B ? (uint32_t)s.agent[(size_t)i * c.Bp + b] : 0u;
+    }
     { // the LDS image: every load in flight before the first write (one memory round trip, not kFill of them)
         constexpr int kFill = (Q::kLdsFloats / 4 + Q::kThreads - 1) / Q::kThreads;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(pk);
@@ -268,14 +277,12 @@ __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * Q::kEnvsPerWave;
     if (b0 >= c.B) return; // (after the only barrier)
     bool unit = true; // wave-uniform: scalar loads and compares
 #pragma unroll
     for (int l = 0; l < 4; l++) unit = unit && pk[Q::oSlope + l] >= 0.0f && pk[Q::oSlope + l] <= 1.0f;
-    if (unit) qnet_wave<ROW, true>(c, s, pk, w1, q_out, n_out, b0, lane);
-    else qnet_wave<ROW, false>(c, s, pk, w1, q_out, n_out, b0, lane);
+    if (unit) qnet_wave<ROW, true>(c, aw, pk, w1, q_out, n_out, b0, lane);
+    else qnet_wave<ROW, false>(c, aw, pk, w1, q_out, n_out, b0, lane);
 }
 
 } // namespace susnet
