@@ -493,7 +493,7 @@ def main():
                         entry["roofline"] = rp["qnet"]
                     del rp
                 entry["value"] = max(entry["eager"]["value"], entry["hip_graph_replay"]["value"])
-                entry["kernel"] = "k_qnet (susnet_qnet_forward: float32 Q-network, f32-input MFMA) + k_policy_actions + k_step<PhiloxRng, Spec<3,4,..>>"
+                entry["kernel"] = "k_qnet (susnet_qnet_forward: float32 Q-network, f32-input MFMA) + k_step<PhiloxRng, Spec<3,4,..>> (susnet_policy_step: argmax, crew draws and the step in one launch)"
                 entry["torch_modules_hip_graph_replay"]["note"] = ("the same tick with the network as torch modules (hipBLASLt f32 GEMMs + PReLU kernels on "
                                                                    "the [B][88] observation): round 2's path, kept as the comparison")
                 line["other_configs"].append(entry)

@@ -13,6 +13,7 @@
  *   susnet_sample_actions  FourRoomEnv.sample_actions      src/environment/base.py:326-330
  *   susnet_policy_actions  run_game's acting step          src/visualize.py:547-562 (train.py:355-381, epsilon = 0)
  *   susnet_qnet_*          MLP.forward on the flat features src/models/dqn.py:72-108, 322-329
+ *   susnet_policy_step     argmax per team + env.step        src/visualize.py:547-582
  *   susnet_step            FourRoomEnv.step                src/environment/base.py:332-407 (tagging.py:120-235)
  *                          + _agent_step 462-533, check_win_condition 409-460 (pred_prey.py:78-99),
  *                            _merge_rewards 553-563, EnvMetricHandler src/metrics.py:35-64
@@ -333,6 +334,11 @@ int susnet_qnet_pack(const susnet_env *env, const int32_t *components, int32_t n
 int susnet_qnet_forward(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
                         const float *packed, float *q_out, void *stream);
 int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream);
+/* susnet_policy_actions and susnet_step in ONE launch -- a tick of the acting loop (visualize.py:547-582: argmax per team, env.step):
+ * the stepping lane takes the teams' greedy actions from the Q rows itself (q_imposter / q_crew as for susnet_policy_actions; at most
+ * 16 actions per team) and steps with them; io->actions is an OUTPUT here (the actions taken, same dtypes / layouts; NULL: not kept),
+ * every other field of io as for susnet_step. */
+int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_step_io *io, void *stream);
 int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
 int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);
 int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *size_out, int32_t *size2_out);

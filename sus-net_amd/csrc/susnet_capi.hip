@@ -919,12 +919,22 @@ extern "C" int susnet_qnet_forward(susnet_env *env, const int32_t *components, i
     return qnet_launch<QRow3>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
 }
 
-extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream) {
+static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_imp, const float *q_crew, void *stream) {
     if (int rc = check_bound(env)) return rc;
-    if (!io || !io->actions) return fail(SUSNET_E_INVALID, "null actions");
+    if (!io || (!io->actions && !q_imp)) return fail(SUSNET_E_INVALID, "null actions");
     StepArgs a;
     std::memset(&a, 0, sizeof(a));
     a.actions = io->actions;
+    if (q_imp) {
+        a.q_imp = q_imp;
+        a.q_crew = q_crew;
+        a.n_qi = env->layout.n_actions_imposter;
+        a.n_qc = env->layout.n_actions_crew;
+        if (a.n_qi > kMaxPolicyActions || a.n_qc > kMaxPolicyActions)
+            return fail(SUSNET_E_INVALID, "susnet_policy_step: at most 16 actions per team (use susnet_policy_actions + susnet_step)");
+        if (!q_crew && env->cfg.rng_mode != SUSNET_RNG_PHILOX)
+            return fail(SUSNET_E_INVALID, "susnet_policy_step: a random crew (q_crew = NULL) draws from the production stream: PHILOX handles only");
+    }
     a.act_dtype = io->actions_dtype;
     if (a.act_dtype != SUSNET_U8 && a.act_dtype != SUSNET_I32 && a.act_dtype != SUSNET_I64)
         return fail(SUSNET_E_INVALID, "actions dtype must be U8/I32/I64");
@@ -965,6 +975,11 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
     HIP_TRY(hipGetLastError());
     env->ticks += 1;
     return SUSNET_OK;
+}
+extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream) { return step_impl(env, io, nullptr, nullptr, stream); }
+extern "C" int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_step_io *io, void *stream) {
+    if (!q_imposter) return fail(SUSNET_E_INVALID, "susnet_policy_step: null q_imposter");
+    return step_impl(env, io, q_imposter, q_crew, stream);
 }
 
 extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out) {

@@ -23,6 +23,31 @@ struct StepArgs {
     RewardSink rewards;
     uint8_t *done, *trunc;
     uint64_t tick; // steps taken so far (index of the action stream: the shuffled order of this step comes from it)
+    // susnet_policy_step: the actions are not an input but the greedy choice of the teams' Q rows (q_imp [B][n_qi], q_crew [B][n_qc] or
+    // NULL = the crew's draws from the action stream), made by the stepping lane itself and written to `actions` (NULL: not kept)
+    const float *q_imp, *q_crew;
+    int32_t n_qi, n_qc;
+};
+constexpr int kMaxPolicyActions = 16; // Q row lengths susnet_policy_step serves
+
+// what sample_actions_env writes through in a policy step: agent i takes its team's argmax (the crew's draw when it has no network),
+// into the per-lane store the step reads and into the caller's action buffer
+template <class Store>
+struct PolicyStepSink {
+    Store &st;
+    void *out;
+    int32_t dtype;
+    int64_t sa, k0;
+    uint32_t roles, a_imp, a_crew; // a_crew = ~0u: keep the sampled index
+    __device__ __forceinline__ void set_act(int i, uint32_t sampled) const {
+        const uint32_t a = ((roles >> i) & 1u) ? a_imp : (a_crew != ~0u ? a_crew : sampled);
+        st.set_act(i, a);
+        if (out) {
+            if (dtype == SUSNET_U8) reinterpret_cast<uint8_t *>(out)[(int64_t)i * sa + k0] = (uint8_t)a;
+            else if (dtype == SUSNET_I32) reinterpret_cast<int32_t *>(out)[(int64_t)i * sa + k0] = (int32_t)a;
+            else reinterpret_cast<int64_t *>(out)[(int64_t)i * sa + k0] = (int64_t)a;
+        }
+    }
 };
 
 struct RolloutArgs {
@@ -132,7 +157,18 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
     tl.issue(c, o.comp, tid);
     Env e = {};
     load_env<S>(c, s, st, b, e);
-    load_actions<S>(c, a, active ? b : 0, st);
+    const bool policy = a.q_imp != nullptr; // (wave-uniform) susnet_policy_step: Q rows instead of actions
+    float qi[kMaxPolicyActions], qc[kMaxPolicyActions];
+    if (policy) {
+        const int64_t bq = active ? b : 0;
+#pragma unroll
+        for (int k = 0; k < kMaxPolicyActions; k++) {
+            qi[k] = k < a.n_qi ? a.q_imp[bq * a.n_qi + k] : 0.0f;
+            qc[k] = (a.q_crew != nullptr && k < a.n_qc) ? a.q_crew[bq * a.n_qc + k] : 0.0f;
+        }
+    } else {
+        load_actions<S>(c, a, active ? b : 0, st);
+    }
     RNG rng = make_rng<RNG>(c, s, b);
     // step counter of the action stream: a kernel argument, or (graph-replayable launches) the env's own device word,
     // identical in every env -- read here, advanced below by the same lane
@@ -145,6 +181,24 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         bool done = false, trunc = false;
         uint32_t bits = 0;
         const uint64_t step_tick = uniform64(tick_word);
+        if (policy) { // visualize.py:547-562: every agent takes its team's argmax (first maximum, like torch.argmax)
+            uint32_t a_imp = 0, a_crew = a.q_crew != nullptr ? 0u : ~0u;
+            float hi = qi[0], hc = qc[0];
+#pragma unroll
+            for (int k = 1; k < kMaxPolicyActions; k++) {
+                if (k < a.n_qi && qi[k] > hi) { hi = qi[k]; a_imp = (uint32_t)k; }
+                if (a.q_crew != nullptr && k < a.n_qc && qc[k] > hc) { hc = qc[k]; a_crew = (uint32_t)k; }
+            }
+            PolicyStepSink<typename StoreFor<S>::type> sink = {st, const_cast<void *>(a.actions), a.act_dtype, a.act_sa, b * a.act_sb, S::imp(c, e.imp),
+                                                               a_imp, a_crew};
+            if (a.q_crew != nullptr) {
+                for (int i = 0; i < A; i++) sink.set_act(i, 0u);
+            } else if constexpr (!RNG::kNumpy) { // the crew's draws: made for EVERY agent (a word's digits depend on the draws before them)
+                ActionStream pas;
+                pas.init();
+                sample_actions_env<S>(c, sink, e, rng, pas, step_tick);
+            }
+        }
         constexpr bool kDuelSpec = !S::kGeneric && S::kA == 2 && S::kJ == 0 && S::kVar == SUSNET_VARIANT_ITG && S::kStaticRoles && S::kFixedOrder;
         bool stepped = false;
         if constexpr (kDuelSpec) {

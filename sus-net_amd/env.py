@@ -562,6 +562,29 @@ class BatchedFourRoomEnv:
                 self.poll_errors()
         return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics()
 
+    def policy_step(self, q_imposter: torch.Tensor, q_crew: Optional[torch.Tensor] = None, actions_out: Optional[torch.Tensor] = None):
+        """``policy_actions`` + ``step`` in ONE launch (``susnet_policy_step``): the stepping lane takes the teams' greedy actions from
+        the Q rows itself.  Returns ``(state, rewards, done, truncated, info, actions)``; ``actions`` = ``actions_out`` (default: the
+        env's int64 ``[B, A]`` buffer) holding the actions taken."""
+        assert q_imposter.dtype == torch.float32 and tuple(q_imposter.shape) == (self.batch, self.n_imposter_actions) and q_imposter.is_contiguous()
+        if q_crew is not None:
+            assert q_crew.dtype == torch.float32 and tuple(q_crew.shape) == (self.batch, self.n_crew_actions) and q_crew.is_contiguous()
+        if actions_out is None:
+            if getattr(self, "_policy_actions_buf", None) is None:
+                self._policy_actions_buf = torch.zeros(self.batch, self.n_agents, dtype=torch.int64, device=self.device)
+            actions_out = self._policy_actions_buf
+        dtype, layout, buf = self._describe_actions(actions_out)
+        io = self._step_io
+        io.actions, io.actions_dtype, io.actions_layout = buf.data_ptr(), dtype, layout
+        with self._on_device():
+            L.check(self.lib.susnet_policy_step(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None, C.byref(io),
+                                                self._stream()))
+            if self.export_state:
+                self._export(full=False)
+            if self.check_errors:
+                self.poll_errors()
+        return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics(), buf
+
     def step4(self, agent_actions):
         """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""
         state, rew, done, trunc, info = self.step(agent_actions)

@@ -197,31 +197,52 @@ class PolicyRollout:
         self._actions = torch.zeros(B, env.n_agents, dtype=torch.int64, device=env.device)
 
     @torch.no_grad()
-    def act(self) -> torch.Tensor:
-        """One tick's actions: the network forward(s) through stock PyTorch-ROCm, then ONE kernel (``susnet_policy_actions``) that
-        reads the episode's roles from the env's state, takes each team's argmax and -- without a crew network -- the crew's
-        draws from the action stream.  (The eager form of the same thing -- role export, argmax, sample_actions, dtype copy,
-        where -- was five launches and a tenth of the tick's GPU time.)"""
+    def q_rows(self):
+        """The teams' Q rows on the current observation: ``(q_imposter [B, n_imposter_actions], q_crew or None)``."""
         env = self.env
         feats = env.obs  # [B, F] float32, refreshed by reset()/step()
         q_imp = env.qnet_forward(self.fused_imposter) if self.fused_imposter is not None else self.imposter_model(self._spatial, feats)
         q_crew = None
         if self.crew_model is not None:
             q_crew = env.qnet_forward(self.fused_crew) if self.fused_crew is not None else self.crew_model(self._spatial, feats)
+        return q_imp.contiguous(), (q_crew.contiguous() if q_crew is not None else None)
+
+    @torch.no_grad()
+    def tick(self):
+        """One tick of the acting loop (visualize.py:547-582): Q rows, greedy actions, env.step.  Returns ``(actions, rewards, done,
+        truncated)``.  Two launches where the env serves it (the network kernel, then ``susnet_policy_step``: argmax, the crew's draws
+        and the step in one kernel); otherwise ``act()`` + ``env.step``."""
+        env = self.env
+        q_imp, q_crew = self.q_rows()
+        fits = max(env.n_imposter_actions, env.n_crew_actions) <= 16 and (q_crew is not None or env.rng_kind == "philox")
+        if fits:
+            _, rew, done, trunc, _, a = env.policy_step(q_imp, q_crew, actions_out=self._actions)
+            return a, rew, done, trunc
+        a = self.act()
+        _, rew, done, trunc, _ = env.step(a)
+        return a, rew, done, trunc
+
+    @torch.no_grad()
+    def act(self) -> torch.Tensor:
+        """One tick's actions: the network forward(s) through stock PyTorch-ROCm, then ONE kernel (``susnet_policy_actions``) that
+        reads the episode's roles from the env's state, takes each team's argmax and -- without a crew network -- the crew's
+        draws from the action stream.  (The eager form of the same thing -- role export, argmax, sample_actions, dtype copy,
+        where -- was five launches and a tenth of the tick's GPU time.)"""
+        env = self.env
+        q_imp, q_crew = self.q_rows()
         if env.rng_kind != "philox" and q_crew is None:  # numpy tapes: the crew's draws come from the env's own words
             if not env.export_state:
                 env.refresh_roles()
             torch.where(env.imposter_mask, q_imp.argmax(dim=1).unsqueeze(1), env.sample_actions().to(torch.int64), out=self._actions)
             return self._actions
-        return env.policy_actions(q_imp.contiguous(), q_crew.contiguous() if q_crew is not None else None, out=self._actions)
+        return env.policy_actions(q_imp, q_crew, out=self._actions)
 
     @torch.no_grad()
     def run(self, n_steps: int, record: bool = False) -> Dict[str, torch.Tensor]:
         env = self.env
         out: Dict[str, List[torch.Tensor]] = {"actions": [], "rewards": [], "done": [], "truncated": []}
         for _ in range(n_steps):
-            a = self.act()
-            _, rew, done, trunc, _ = env.step(a)
+            a, rew, done, trunc = self.tick()
             if record:
                 out["actions"].append(a.clone())
                 out["rewards"].append(rew.clone())
@@ -256,8 +277,7 @@ class PolicyRollout:
         def tick(k):
             if record:
                 out["obs_before"][k].copy_(env.obs)
-            a = self.act()
-            _, rew, done, trunc, _ = env.step(a)
+            a, rew, done, trunc = self.tick()
             if record:
                 out["actions"][k].copy_(a)
                 out["rewards"][k].copy_(rew)

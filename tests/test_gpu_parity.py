@@ -1138,6 +1138,33 @@ def test_policy_actions_kernel(pkg, oracle_mod, name):
         ob.reset(mask=np_(env._done | env._trunc))
 
 
+@pytest.mark.parametrize("crew_net", [False, True])
+@pytest.mark.parametrize("name", ["base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v1_nowalls", "itg_1v5_j3"])
+def test_policy_step_equals_policy_actions_then_step(pkg, oracle_mod, name, crew_net):
+    """susnet_policy_step (argmax per team, the crew's draws and the step in ONE launch) against the two launches it replaces on a twin
+    handle with the same seed: actions (every dtype the twin writes), reward bit patterns, done / truncated and the exported state, tick
+    after tick through episode ends and in-step resets; compiled-in and generic configurations."""
+    B, T = 2000, 40
+    e1, ob = make_pair(pkg, oracle_mod, name, B, 17, auto_reset=True, check_errors=True)
+    e2, _ = make_pair(pkg, oracle_mod, name, B, 17, auto_reset=True, check_errors=True)
+    e1.reset()
+    e2.reset()
+    gen = torch.Generator(device=e1.device)
+    gen.manual_seed(3)
+    for tick in range(T):
+        q_imp = torch.randn(B, e1.n_imposter_actions, device=e1.device, generator=gen)
+        q_crew = torch.randn(B, e1.n_crew_actions, device=e1.device, generator=gen) if crew_net else None
+        q_imp[::5, 1] = q_imp[::5].max(dim=1).values  # ties: the first maximum wins in both paths
+        a1 = e1.policy_actions(q_imp, q_crew).clone()
+        _, r1, d1, t1, _ = e1.step(a1)
+        out = torch.zeros(B, e2.n_agents, dtype=(torch.uint8, torch.int32, torch.int64)[tick % 3], device=e2.device)
+        _, r2, d2, t2, _, a2 = e2.policy_step(q_imp, q_crew, actions_out=out)
+        assert torch.equal(a2.to(torch.int64), a1), (name, tick)
+        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2) and torch.equal(t1, t2), (name, tick)
+        assert torch.equal(e1.agent_positions, e2.agent_positions) and torch.equal(e1.alive_agents, e2.alive_agents), (name, tick)
+    assert int(e1.tick) == int(e2.tick) == T
+
+
 @pytest.mark.parametrize("name,comps,hidden,slopes,B", [
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [256, 128, 64, 16], (0.1, 0.3, 0.5, 0.7), 5037),  # BASELINE config 5's network
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [200, 100, 50, 10], (0.25, 0.25, 0.0, 1.0), 5037),  # widths that need padding
