@@ -385,7 +385,12 @@ def main():
             pad = [net.dims[0], 256, 128, 64, 32, 32]
             issued = 2.0 * B * sum(a * b for a, b in zip(pad[1:-1], pad[2:]))       # layers 2..5 at their padded widths: what the matrix core executes
             model_flops = 2.0 * B * sum(a * b for a, b in zip(net.dims[:-1], net.dims[1:]))  # the reference MLP's own multiply-adds, layer 1 included
+            traffic, traffic_source = None, None
+            cpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_qnet_counters.json")
+            if B == 65536 and os.path.exists(cpath):  # WRITE_SIZE + 2 x FETCH_SIZE of the same kernel on the same batch (tools/profile_cfg5.sh)
+                traffic, traffic_source = json.load(open(cpath)).get("traffic_bytes_per_launch"), "profiles/r03_qnet_counters.json"
             qnet = {"kernel": "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward)", "bound": "mfma", "avg_launch_us": us, "unit": "TFLOP/s",
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "peak": MFMA_F32_PEAK_TFLOPS, "achieved": issued / us / 1e6, "frac": issued / us / 1e6 / MFMA_F32_PEAK_TFLOPS,
                     "model_flops_per_launch": model_flops, "model_tflops": model_flops / us / 1e6,
                     "note": "achieved = flops of the v_mfma_f32_32x32x2_f32 instructions issued (layers 2..5, padded widths) / launch time; layer 1 "
@@ -430,7 +435,7 @@ def main():
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
     if args.mode == "policy":  # the tick's dominant kernel is the Q-network: its roofline is the f32 matrix peak
-        line["roofline"] = dict(res["qnet"], traffic=None)
+        line["roofline"] = dict(res["qnet"])
         line["dtype"] = "f32"
         line["config"]["policy_forward"] = "susnet_qnet_forward: one HIP kernel from the state words to the Q rows (float32, f32-input MFMA)"
     del res

@@ -11,3 +11,10 @@ python3 $CMD > $OUT/bench_unprofiled.json 2> $OUT/unprofiled.err || exit 1
 python3 tools/qnet_bench.py > $OUT/qnet_bench.json 2> $OUT/qnet.err || exit 1
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 echo cfg5-profile-ok
+# the network kernel's own counters: MFMA instructions, matrix-busy cycles, VALU / LDS / VMEM instruction counts, memory traffic
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_mfma -- python3 tools/qnet_bench.py > $OUT/pmc_mfma.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_inst -- python3 tools/qnet_bench.py > $OUT/pmc_inst.log 2>&1 || exit 1
+for C in WRITE_SIZE FETCH_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 tools/qnet_bench.py > $OUT/pmc_$C.log 2>&1 || exit 1
+done
+echo cfg5-pmc-ok
