@@ -57,7 +57,7 @@ CONFIGS = {
     # BASELINE.json configs[4]: cfg3's env driven by the reference-architecture MLP (no checkpoints ship with the
     # reference: seeded random init), greedy imposter + uniformly random crew, everything on the device
     "cfg5": dict(workload="cfg5: cfg3 env (1v2, 14x14 walled, 4 jobs) driven by MLP[88,256,128,64,16,7] imposter policy "
-                          "(float32: susnet_qnet_forward, one HIP kernel on the f32-input MFMA) + random crew, batch 65536/GPU",
+                          "(float32 on the f32-input MFMA) + random crew, the whole tick one HIP kernel (susnet_qnet_policy_step), batch 65536/GPU",
                  cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536, policy=True),
 }
 POLICY_COMPONENTS = ["onehot_pos", "alive_crew", "closest_crew"]
@@ -389,10 +389,18 @@ def main():
             cpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_qnet_counters.json")
             if B == 65536 and os.path.exists(cpath):  # WRITE_SIZE + 2 x FETCH_SIZE of the same kernel on the same batch (tools/profile_cfg5.sh)
                 traffic, traffic_source = json.load(open(cpath)).get("traffic_bytes_per_launch"), "profiles/r03_qnet_counters.json"
-            qnet = {"kernel": "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward)", "bound": "mfma", "avg_launch_us": us, "unit": "TFLOP/s",
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "peak": MFMA_F32_PEAK_TFLOPS, "achieved": issued / us / 1e6, "frac": issued / us / 1e6 / MFMA_F32_PEAK_TFLOPS,
-                    "model_flops_per_launch": model_flops, "model_tflops": model_flops / us / 1e6,
+            alone = {"kernel": "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward), 50 launches outside the timed region", "avg_launch_us": us,
+                     "achieved": issued / us / 1e6, "frac": issued / us / 1e6 / MFMA_F32_PEAK_TFLOPS, "model_tflops": model_flops / us / 1e6,
+                     "traffic": traffic, "traffic_source": traffic_source}
+            one = bool(getattr(pr, "one_kernel_tick", False))
+            # the kernel of the TIMED region: with the one-kernel tick every launch there is k_qnet_step (network + argmax + crew draws + step:
+            # the matrix core idles while the wave steps its environments); else the network kernel as timed alone
+            tick_us = dev_ms * 1e3 / K if one else us
+            qnet = {"kernel": ("k_qnet_step<FlatRow<2,3,14>, Spec<3,4,..>> (susnet_qnet_policy_step: the whole tick, one launch per bench step)" if one
+                               else "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward)"),
+                    "bound": "mfma", "avg_launch_us": tick_us, "unit": "TFLOP/s", "traffic": None if one else traffic,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "achieved": issued / tick_us / 1e6, "frac": issued / tick_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                    "model_flops_per_launch": model_flops, "model_tflops": model_flops / tick_us / 1e6, "network_kernel_alone": alone,
                     "note": "achieved = flops of the v_mfma_f32_32x32x2_f32 instructions issued (layers 2..5, padded widths) / launch time; layer 1 "
                             "(35 % of the model's multiply-adds) is a gather of W1 columns and issues no MFMA, so model_tflops exceeds it"}
         return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, pair_us=pair_us, packed=packed, steps=K, warmup=W,
@@ -437,7 +445,7 @@ def main():
     if args.mode == "policy":  # the tick's dominant kernel is the Q-network: its roofline is the f32 matrix peak
         line["roofline"] = dict(res["qnet"])
         line["dtype"] = "f32"
-        line["config"]["policy_forward"] = "susnet_qnet_forward: one HIP kernel from the state words to the Q rows (float32, f32-input MFMA)"
+        line["config"]["policy_forward"] = "susnet_qnet_policy_step: the whole tick -- Q-network (float32, f32-input MFMA), argmax, crew draws, env step -- as one HIP kernel"
     del res
     secondary = rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy"
     if secondary:
@@ -498,7 +506,7 @@ def main():
                         entry["roofline"] = rp["qnet"]
                     del rp
                 entry["value"] = max(entry["eager"]["value"], entry["hip_graph_replay"]["value"])
-                entry["kernel"] = "k_qnet (susnet_qnet_forward: float32 Q-network, f32-input MFMA) + k_step<PhiloxRng, Spec<3,4,..>> (susnet_policy_step: argmax, crew draws and the step in one launch)"
+                entry["kernel"] = "k_qnet_step (susnet_qnet_policy_step: float32 Q-network on the f32-input MFMA, argmax, crew draws and the env step: the whole tick in one launch)"
                 entry["torch_modules_hip_graph_replay"]["note"] = ("the same tick with the network as torch modules (hipBLASLt f32 GEMMs + PReLU kernels on "
                                                                    "the [B][88] observation): round 2's path, kept as the comparison")
                 line["other_configs"].append(entry)

@@ -339,6 +339,13 @@ int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream);
  * 16 actions per team) and steps with them; io->actions is an OUTPUT here (the actions taken, same dtypes / layouts; NULL: not kept),
  * every other field of io as for susnet_step. */
 int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_step_io *io, void *stream);
+/* susnet_qnet_forward and susnet_policy_step (imposters by the network, random crew) as ONE kernel -- a whole tick of the acting loop
+ * in one launch: the wave that computed its 64 environments' Q rows takes their argmax in registers and steps them.  Arguments as for
+ * the two calls; q_out may be NULL (Q rows not kept).  Served: the two compiled-in games the network kernel knows the feature layout of
+ * (2-agent 9x9 ImposterTrainingGround; 1v2 14x14 FourRoomEnv with 4 jobs), PHILOX handles; otherwise SUSNET_E_INVALID and the caller
+ * uses the two calls. */
+int susnet_qnet_policy_step(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                            const float *packed, float *q_out, const susnet_step_io *io, void *stream);
 int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
 int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);
 int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *size_out, int32_t *size2_out);

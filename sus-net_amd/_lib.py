@@ -30,7 +30,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 # every symbol include/susnet.h declares
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
-    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_policy_actions", "susnet_qnet_packed_floats", "susnet_qnet_pack", "susnet_qnet_forward", "susnet_step", "susnet_policy_step",
+    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_policy_actions", "susnet_qnet_packed_floats", "susnet_qnet_pack", "susnet_qnet_forward", "susnet_step", "susnet_policy_step", "susnet_qnet_policy_step",
     "susnet_rollout", "susnet_record_layout", "susnet_set_launch_limit", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append", "susnet_scent",
 ]
@@ -160,6 +160,7 @@ def lib():
     L.susnet_step.argtypes = [C.c_void_p, P(StepIO), C.c_void_p]
     L.susnet_rollout.argtypes = [C.c_void_p, P(RolloutIO), C.c_void_p]
     L.susnet_policy_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(StepIO), C.c_void_p]
+    L.susnet_qnet_policy_step.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, P(StepIO), C.c_void_p]
     L.susnet_policy_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.susnet_qnet_packed_floats.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32]
     L.susnet_qnet_pack.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, P(C.c_void_p), P(C.c_void_p), C.c_void_p, C.c_void_p]

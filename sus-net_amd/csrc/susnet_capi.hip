@@ -919,9 +919,34 @@ extern "C" int susnet_qnet_forward(susnet_env *env, const int32_t *components, i
     return qnet_launch<QRow3>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
 }
 
-static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_imp, const float *q_crew, void *stream) {
+// susnet_qnet_policy_step: the network whose kernel also steps (nullptr: a plain / policy step through k_step)
+struct QnetFuse {
+    int feat;
+    const float *packed;
+    float *q_out;
+    int n_out;
+};
+template <class ROW, class S>
+static int qnet_step_launch(susnet_env *env, const QnetFuse &f, const StepArgs &a, const ObsArgs &o, size_t step_lds, hipStream_t st) {
+    using Q = QNet<ROW>;
+    // [table image of the step, shared by the four waves][network image][one region per wave: the rest of a k_step workgroup's LDS]
+    const size_t rest = step_lds - (size_t)kTableWords * 4;
+    const size_t sh = (size_t)kTableWords * 4 + (size_t)Q::kLdsBytes + 4 * rest;
+    if (sh > 160 * 1024) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: observation too large for the LDS left beside the network image");
+    static bool lds_set = false;
+    if (!lds_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet_step<ROW, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_set = true;
+    }
+    const unsigned blocks = (unsigned)((env->c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
+    hipLaunchKernelGGL((k_qnet_step<ROW, S>), dim3(blocks), dim3(Q::kThreads), sh, st, env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest);
+    HIP_TRY(hipGetLastError());
+    return SUSNET_OK;
+}
+
+static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_imp, const float *q_crew, void *stream, const QnetFuse *fuse = nullptr) {
     if (int rc = check_bound(env)) return rc;
-    if (!io || (!io->actions && !q_imp)) return fail(SUSNET_E_INVALID, "null actions");
+    if (!io || (!io->actions && !q_imp && !fuse)) return fail(SUSNET_E_INVALID, "null actions");
     StepArgs a;
     std::memset(&a, 0, sizeof(a));
     a.actions = io->actions;
@@ -958,6 +983,23 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
     size_t sh = lds_bytes(env, o, env->c.auto_reset != 0, spec);
     CHECK_LDS(sh);
     const dim3 g = grid_for(env), blk(kBlock);
+    if (fuse) { // the one-kernel policy tick: the compiled-in games whose feature layout the network kernel knows
+        if (tape) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: the crew draws from the production stream: PHILOX handles only");
+        if (o.flat_feat != 0) { // the compiled-in feature writer stages 64 bit masks, not the generic writer's byte image
+            ObsArgs small = o;
+            small.words1 = 64 * 4;
+            small.words2 = 0;
+            sh = lds_bytes(env, small, env->c.auto_reset != 0, spec);
+        }
+        sh = (sh + 15) & ~(size_t)15;
+        int rc;
+        if (spec == 3 && fuse->feat == FEAT_ONEHOT_ALIVE_CLOSEST) rc = qnet_step_launch<QRow3, SpecCfg3>(env, *fuse, a, o, sh, st);
+        else if (spec == 2 && fuse->feat == FEAT_ONEHOT) rc = qnet_step_launch<QRow1, SpecCfg2>(env, *fuse, a, o, sh, st);
+        else return fail(env, SUSNET_E_INVALID, "susnet_qnet_policy_step: served are the two compiled-in games (1v1 9x9 ITG, 1v2 14x14 with 4 jobs)");
+        if (rc) return rc;
+        env->ticks += 1;
+        return SUSNET_OK;
+    }
     switch (spec) {
     case 2: launch_step<SpecCfg2>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     case 3: launch_step<SpecCfg3>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
@@ -980,6 +1022,18 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
 extern "C" int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_step_io *io, void *stream) {
     if (!q_imposter) return fail(SUSNET_E_INVALID, "susnet_policy_step: null q_imposter");
     return step_impl(env, io, q_imposter, q_crew, stream);
+}
+
+extern "C" int susnet_qnet_policy_step(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                                       const float *packed, float *q_out, const susnet_step_io *io, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    const int64_t n = susnet_qnet_packed_floats(env, components, n_components, dims, n_dims);
+    if (n < 0) return (int)n;
+    if (!packed || (reinterpret_cast<uintptr_t>(packed) & 15u)) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: packed (16-byte aligned)");
+    if (dims[5] != env->layout.n_actions_imposter)
+        return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: the network's output width must be the imposters' action count");
+    const QnetFuse f = {qnet_feat(env, components, n_components), packed, q_out, dims[5]};
+    return step_impl(env, io, nullptr, nullptr, stream, &f);
 }
 
 extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out) {

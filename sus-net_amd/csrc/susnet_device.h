@@ -481,21 +481,27 @@ struct TableLoad {
         }
     }
 };
+// smem: the table image -- at LDS address 0 of the workgroup (lds_table_addr: the byte-parallel kernels read it through absolute
+// addresses); rest: the wave's own region behind it (k_step / the rollouts: smem + kTableWords; the one-kernel policy tick keeps ONE
+// table image for its four waves and gives each wave a region of its own further up)
 template <class S>
-__device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
+__device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, uint32_t *rest, int tid, typename StoreFor<S>::type &st) {
     Tables T;
     T.grid = smem;
     T.valid = reinterpret_cast<const uint8_t *>(smem + 16);
     T.comp = smem + 80;
     T.move = reinterpret_cast<const uint8_t *>(smem + 96);
     T.rew = reinterpret_cast<const float *>(smem + 480);
-    uint32_t *rest = smem + kTableWords;
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
     if (HasGroupWords<S>::value) rest += kGroupWords;
     T.perm = reinterpret_cast<uint8_t *>(rest);
     T.stage = rest;
     return T;
+}
+template <class S>
+__device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
+    return carve_lds<S>(c, smem, smem + kTableWords, tid, st);
 }
 __device__ __forceinline__ void wave_lds_publish() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

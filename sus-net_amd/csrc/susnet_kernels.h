@@ -141,15 +141,17 @@ __device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG 
     if (rng.ovf) atomicOr(s.err, SUSNET_ERRBIT_TAPE);
 }
 
+// One step of the wave's 64 environments b0 .. b0 + 63 (lane tid = environment b0 + tid): the body of k_step, also the tail of the
+// one-kernel policy tick (susnet_qnet.h k_qnet_step).  smem: the table image at LDS address 0 (every wave of the workgroup writes the
+// same words into it); rest: the wave's own LDS region (lds_bytes() of the host minus the table image).  pre_imp >= 0: the imposters'
+// greedy action, already chosen by the caller (the crew then draws from the action stream).
 template <class RNG, class S>
-__global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, ObsArgs o) {
-    extern __shared__ uint32_t smem[];
-    const int tid = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * kBlock, b = b0 + tid;
+__device__ __forceinline__ void step_wave(const Consts &c, const State &s, const StepArgs &a, const ObsArgs &o, uint32_t *smem, uint32_t *rest, int tid, int64_t b0,
+                                          int pre_imp) {
+    const int64_t b = b0 + tid;
     const bool active = b < c.B;
     typename StoreFor<S>::type st;
-    Tables T = carve_lds<S>(c, smem, tid, st);
-    warm_kernargs<sizeof(Consts) + sizeof(State) + sizeof(StepArgs) + sizeof(ObsArgs)>();
+    Tables T = carve_lds<S>(c, smem, rest, tid, st);
     // One step per launch is latency-bound: every load the step needs is issued here, back to back and without a branch
     // between them (state rows are padded to Bp, so lanes past B read their own padding; their action index is clamped),
     // and only then are the tables written to LDS -- one memory round trip instead of one per table, per agent, per field.
@@ -157,9 +159,12 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
     tl.issue(c, o.comp, tid);
     Env e = {};
     load_env<S>(c, s, st, b, e);
-    const bool policy = a.q_imp != nullptr; // (wave-uniform) susnet_policy_step: Q rows instead of actions
+    const bool policy = a.q_imp != nullptr || pre_imp >= 0; // (wave-uniform) susnet_policy_step: Q rows instead of actions
     float qi[kMaxPolicyActions], qc[kMaxPolicyActions];
-    if (policy) {
+    if (pre_imp >= 0) {
+#pragma unroll
+        for (int k = 0; k < kMaxPolicyActions; k++) qi[k] = qc[k] = 0.0f;
+    } else if (policy) {
         const int64_t bq = active ? b : 0;
 #pragma unroll
         for (int k = 0; k < kMaxPolicyActions; k++) {
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
                 if (k < a.n_qi && qi[k] > hi) { hi = qi[k]; a_imp = (uint32_t)k; }
                 if (a.q_crew != nullptr && k < a.n_qc && qc[k] > hc) { hc = qc[k]; a_crew = (uint32_t)k; }
             }
+            if (pre_imp >= 0) a_imp = (uint32_t)pre_imp;
             PolicyStepSink<typename StoreFor<S>::type> sink = {st, const_cast<void *>(a.actions), a.act_dtype, a.act_sa, b * a.act_sb, S::imp(c, e.imp),
                                                                a_imp, a_crew};
             if (a.q_crew != nullptr) {
@@ -317,6 +323,13 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
         }
     }
     write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
+}
+
+template <class RNG, class S>
+__global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, ObsArgs o) {
+    extern __shared__ uint32_t smem[];
+    warm_kernargs<sizeof(Consts) + sizeof(State) + sizeof(StepArgs) + sizeof(ObsArgs)>();
+    step_wave<RNG, S>(c, s, a, o, smem, smem + kTableWords, (int)threadIdx.x, (int64_t)blockIdx.x * kBlock, -1);
 }
 
 // Fused random rollout: n_ticks x {sample_actions; step; auto-reset} with the state held on chip.

@@ -135,9 +135,10 @@ __device__ __forceinline__ void dense(const WeightStream &ws, f32x4 (&w)[4][4], 
 // Q rows of the handle's CURRENT environments: q_out [B][n_out] float32.  256 threads = 4 waves (one per SIMD) share the LDS
 // image of layer 1; wave w of block g owns environments (4 g + w) * 64 ..; lane = (column m = lane % 32, half h = lane / 32) of each
 // of its two 32-environment tiles.
+// Returns the greedy action of the environment lane `lane` of the wave owns (b0 + lane): argmax of its Q row, first maximum.
 template <class ROW, bool UNIT>
-__device__ __forceinline__ void qnet_wave(const Consts &c, const uint32_t (&aw)[2][ROW::A], const float *pk, const float *w1, float *q_out, int n_out, int64_t b0,
-                                          int lane) {
+__device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&aw)[2][ROW::A], const float *pk, const float *w1, float *q_out, int n_out,
+                                              int64_t b0, int lane) {
     using Q = QNet<ROW>;
     constexpr int T = 2, R = Q::kGather;
     const int m = lane & 31, h = lane >> 5;
@@ -233,17 +234,32 @@ __device__ __forceinline__ void qnet_wave(const Consts &c, const uint32_t (&aw)[
     f32x16 a5[Q::NO / 32][T];
     dense<kB5, Q::H4 / 32, Q::NO / 32, T, kLast>(ws, w, w1 + Q::oB5, a4, a5); // dqn.py:328: no activation after the last Linear
 
+    uint32_t best[T];
 #pragma unroll
     for (int t = 0; t < T; t++) {
         const int64_t b = b0 + 32 * t + m;
-        if (b < c.B) {
+        if (q_out != nullptr && b < c.B) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int n = 8 * (i >> 2) + 4 * h + (i & 3);
                 if (n < n_out) q_out[b * n_out + n] = a5[0][t][i];
             }
         }
+        // argmax over the row: this lane's entries in ascending n (first maximum), then against the other half's (lane ^ 32)
+        float hv = -__builtin_inff();
+        uint32_t hn = 0xffffu;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+            const float v = a5[0][t][i];
+            if (n < n_out && (hn == 0xffffu || v > hv)) { hv = v; hn = (uint32_t)n; }
+        }
+        const float pv = __shfl_xor(hv, 32, 64);
+        const uint32_t pn = (uint32_t)__shfl_xor((int)hn, 32, 64);
+        const bool theirs = pn != 0xffffu && (hn == 0xffffu || pv > hv || (pv == hv && pn < hn));
+        best[t] = theirs ? pn : hn;
     }
+    return lane < 32 ? best[0] : best[1]; // lane L = (m = L % 32, half L / 32): tile L / 32 holds environment b0 + L
 }
 
 template <class ROW>
@@ -283,6 +299,52 @@ __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk
     for (int l = 0; l < 4; l++) unit = unit && pk[Q::oSlope + l] >= 0.0f && pk[Q::oSlope + l] <= 1.0f;
     if (unit) qnet_wave<ROW, true>(c, aw, pk, w1, q_out, n_out, b0, lane);
     else qnet_wave<ROW, false>(c, aw, pk, w1, q_out, n_out, b0, lane);
+}
+
+// The whole policy tick in ONE kernel (visualize.py:547-582 with a reference MLP as the imposters' network and a random crew): the
+// Q-network as above, the argmax taken where the Q row lives, then the wave steps its own 64 environments (k_step's body, susnet_kernels.h
+// step_wave: the crew's draws from the action stream, the step, the in-step reset, the fused observation) -- no Q rows, no actions and no
+// second launch in between.  Dynamic LDS: the network image, then one step region of step_lds_bytes per wave.  q_out may be NULL.
+template <class ROW, class S>
+__global__ __launch_bounds__(256) void k_qnet_step(Consts c, State s, const float *pk, float *q_out, int n_out, StepArgs a, ObsArgs o, int step_lds_bytes) {
+    using Q = QNet<ROW>;
+    // dynamic LDS: [the step's table image, at address 0: its readers use absolute addresses][the network image][4 wave regions]
+    extern __shared__ uint32_t dyn[];
+    float *w1 = reinterpret_cast<float *>(dyn + kTableWords);
+    static_assert((kTableWords * 4) % 16 == 0, "the network image is copied in 16-byte pieces");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * Q::kEnvsPerWave;
+    uint32_t aw[2][ROW::A];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int64_t b = b0 + 32 * t + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < ROW::A; i++) aw[t][i] = b < c.B ? (uint32_t)s.agent[(size_t)i * c.Bp + b] : 0u;
+    }
+    {
+        constexpr int kFill = (Q::kLdsFloats / 4 + Q::kThreads - 1) / Q::kThreads;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(pk);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(w1);
+        f32x4 tmp[kFill];
+#pragma unroll
+        for (int i = 0; i < kFill; i++) {
+            const int k = (int)threadIdx.x + Q::kThreads * i;
+            tmp[i] = src[k < Q::kLdsFloats / 4 ? k : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < kFill; i++) {
+            const int k = (int)threadIdx.x + Q::kThreads * i;
+            if (k < Q::kLdsFloats / 4) dst[k] = tmp[i];
+        }
+    }
+    __syncthreads();
+    if (b0 >= c.B) return; // (after the only barrier; the step below synchronises inside the wave only)
+    bool unit = true;
+#pragma unroll
+    for (int l = 0; l < 4; l++) unit = unit && pk[Q::oSlope + l] >= 0.0f && pk[Q::oSlope + l] <= 1.0f;
+    const uint32_t a_imp = unit ? qnet_wave<ROW, true>(c, aw, pk, w1, q_out, n_out, b0, lane) : qnet_wave<ROW, false>(c, aw, pk, w1, q_out, n_out, b0, lane);
+    uint32_t *rest = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
+    step_wave<PhiloxRng, S>(c, s, a, o, dyn, rest, lane, b0, (int)a_imp);
 }
 
 } // namespace susnet

@@ -585,6 +585,36 @@ class BatchedFourRoomEnv:
                 self.poll_errors()
         return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics(), buf
 
+    def supports_qnet_policy_step(self, net: "PackedQNet") -> bool:
+        """Whether ``qnet_policy_step`` serves this env (the compiled-in 1v1 9x9 ITG / 1v2 14x14 4-job games on the production stream)."""
+        if self.rng_kind != "philox" or net.dims[-1] != self.n_imposter_actions or getattr(self._layout, "test_overrides", 0) & 1:
+            return False
+        A, N, J = self.n_agents, self.n_rows, self.n_jobs
+        return (A == 2 and N == 9 and J == 0 and type(self).__name__.endswith("ImposterTrainingGround") and self.record_layout() is not None) or \
+               (A == 3 and N == 14 and J == 4 and self.record_layout() is not None and not type(self).__name__.endswith("Tagging"))
+
+    def qnet_policy_step(self, net: "PackedQNet", actions_out: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None):
+        """A whole tick of the acting loop in ONE kernel (``susnet_qnet_policy_step``): the imposters' network (``net``), its argmax, the
+        crew's random draws and the step.  Returns like ``policy_step``; raises ``RuntimeError`` where the library does not serve the
+        configuration (callers fall back to ``qnet_forward`` + ``policy_step``)."""
+        if actions_out is None:
+            if getattr(self, "_policy_actions_buf", None) is None:
+                self._policy_actions_buf = torch.zeros(self.batch, self.n_agents, dtype=torch.int64, device=self.device)
+            actions_out = self._policy_actions_buf
+        dtype, layout, buf = self._describe_actions(actions_out)
+        if q_out is not None:
+            assert q_out.dtype == torch.float32 and tuple(q_out.shape) == (self.batch, net.dims[-1]) and q_out.is_contiguous()
+        io = self._step_io
+        io.actions, io.actions_dtype, io.actions_layout = buf.data_ptr(), dtype, layout
+        with self._on_device():
+            L.check(self.lib.susnet_qnet_policy_step(self._h, net.components, len(net.components), net.cdims, len(net.dims), net.packed.data_ptr(),
+                                                     q_out.data_ptr() if q_out is not None else None, C.byref(io), self._stream()))
+            if self.export_state:
+                self._export(full=False)
+            if self.check_errors:
+                self.poll_errors()
+        return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics(), buf
+
     def step4(self, agent_actions):
         """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""
         state, rew, done, trunc, info = self.step(agent_actions)

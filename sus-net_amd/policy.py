@@ -192,6 +192,10 @@ class PolicyRollout:
         # anything else (SpatialDQN, other layer stacks / layouts) goes through the torch module on env.obs
         self.fused_imposter = pack_mlp(env, imposter_model, components) if fused else None
         self.fused_crew = pack_mlp(env, crew_model, components) if fused and crew_model is not None else None
+        # ... and with a random crew on one of the compiled-in games the whole tick -- network, argmax, the crew's draws, the step -- is
+        # ONE kernel (susnet_qnet_policy_step)
+        self.one_kernel_tick = (self.fused_imposter is not None and crew_model is None and env.rng_kind == "philox" and
+                                env.supports_qnet_policy_step(self.fused_imposter))
         B = env.batch
         self._spatial = torch.zeros(B, 1, 1, device=env.device)  # FlatFeaturizer's dummy spatial input
         self._actions = torch.zeros(B, env.n_agents, dtype=torch.int64, device=env.device)
@@ -210,9 +214,13 @@ class PolicyRollout:
     @torch.no_grad()
     def tick(self):
         """One tick of the acting loop (visualize.py:547-582): Q rows, greedy actions, env.step.  Returns ``(actions, rewards, done,
-        truncated)``.  Two launches where the env serves it (the network kernel, then ``susnet_policy_step``: argmax, the crew's draws
-        and the step in one kernel); otherwise ``act()`` + ``env.step``."""
+        truncated)``.  ONE launch where the env serves it (``susnet_qnet_policy_step``: a reference MLP for the imposters, a random crew, a
+        compiled-in game); else two (the network, then ``susnet_policy_step``: argmax, the crew's draws and the step in one kernel); else
+        ``act()`` + ``env.step``."""
         env = self.env
+        if self.one_kernel_tick:
+            _, rew, done, trunc, _, a = env.qnet_policy_step(self.fused_imposter, actions_out=self._actions)
+            return a, rew, done, trunc
         q_imp, q_crew = self.q_rows()
         fits = max(env.n_imposter_actions, env.n_crew_actions) <= 16 and (q_crew is not None or env.rng_kind == "philox")
         if fits:

@@ -1165,6 +1165,41 @@ def test_policy_step_equals_policy_actions_then_step(pkg, oracle_mod, name, crew
     assert int(e1.tick) == int(e2.tick) == T
 
 
+@pytest.mark.parametrize("name,comps", [("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"]), ("itg_1v1_nowalls", ["onehot_pos"])])
+def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps):
+    """susnet_qnet_policy_step (network, argmax, crew draws, step: ONE kernel) against susnet_qnet_forward + susnet_policy_step on a twin
+    handle with the same seed: actions, reward bit patterns, done / truncated, the fused float observation and the exported state, tick
+    after tick; B no multiple of the kernel's 256 environments per workgroup; the Q rows it can also emit."""
+    B, T = 3000 + 41, 60
+    obs = pkg.ObsConfig("flat", comps)
+    e1, _ = make_pair(pkg, oracle_mod, name, B, 23, auto_reset=True, check_errors=True, obs=obs)
+    e2, _ = make_pair(pkg, oracle_mod, name, B, 23, auto_reset=True, check_errors=True, obs=obs)
+    e1.reset()
+    e2.reset()
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(6)
+        model = pkg.MLP([e1.obs.shape[-1], 256, 128, 64, 16, e1.n_imposter_actions]).to(e1.device).eval()
+    two = pkg.PolicyRollout(e1, model, crew_model=None, components=comps)
+    one = pkg.PolicyRollout(e2, model, crew_model=None, components=comps)
+    assert one.one_kernel_tick and two.one_kernel_tick, "both games are served by the one-kernel tick"
+    two.one_kernel_tick = False  # the twin takes the two-launch path
+    ends = 0
+    for tick in range(T):
+        a1, r1, d1, t1 = two.tick()
+        a1 = a1.clone()
+        a2, r2, d2, t2 = one.tick()
+        assert torch.equal(a1, a2), (name, tick)
+        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2) and torch.equal(t1, t2), (name, tick)
+        assert torch.equal(e1.obs, e2.obs), (name, tick)
+        assert torch.equal(e1.agent_positions, e2.agent_positions) and torch.equal(e1.alive_agents, e2.alive_agents), (name, tick)
+        ends += int(d1.sum()) + int(t1.sum())
+    assert int(e1.tick) == int(e2.tick) == T  # (episode ends inside a policy step: test_policy_step_equals_policy_actions_then_step)
+    q = torch.empty(B, e2.n_imposter_actions, device=e2.device)
+    want = e2.qnet_forward(one.fused_imposter).clone()
+    e2.qnet_policy_step(one.fused_imposter, q_out=q)
+    assert torch.equal(q, want), "the Q rows the one-kernel tick emits are the network kernel's"
+
+
 @pytest.mark.parametrize("name,comps,hidden,slopes,B", [
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [256, 128, 64, 16], (0.1, 0.3, 0.5, 0.7), 5037),  # BASELINE config 5's network
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [200, 100, 50, 10], (0.25, 0.25, 0.0, 1.0), 5037),  # widths that need padding
