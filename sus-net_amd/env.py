@@ -586,12 +586,11 @@ class BatchedFourRoomEnv:
         return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics(), buf
 
     def supports_qnet_policy_step(self, net: "PackedQNet") -> bool:
-        """Whether ``qnet_policy_step`` serves this env (the compiled-in 1v1 9x9 ITG / 1v2 14x14 4-job games on the production stream)."""
-        if self.rng_kind != "philox" or net.dims[-1] != self.n_imposter_actions or getattr(self._layout, "test_overrides", 0) & 1:
+        """Whether ``qnet_policy_step`` serves this env: the compiled-in 1v1 9x9 ITG / 1v2 14x14 4-job games on the production stream
+        (a packed record layout exists exactly for the compiled-in games, and among them the agent count names the game)."""
+        if self.rng_kind != "philox" or net.dims[-1] != self.n_imposter_actions or self.record_layout() is None:
             return False
-        A, N, J = self.n_agents, self.n_rows, self.n_jobs
-        return (A == 2 and N == 9 and J == 0 and type(self).__name__.endswith("ImposterTrainingGround") and self.record_layout() is not None) or \
-               (A == 3 and N == 14 and J == 4 and self.record_layout() is not None and not type(self).__name__.endswith("Tagging"))
+        return (self.n_agents, self.n_rows) in ((2, 9), (3, 14))
 
     def qnet_policy_step(self, net: "PackedQNet", actions_out: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None):
         """A whole tick of the acting loop in ONE kernel (``susnet_qnet_policy_step``): the imposters' network (``net``), its argmax, the

@@ -1,9 +1,12 @@
 """Policy-in-the-loop rollout (BASELINE.json config 5).
 
-The Q-networks themselves are out of scope as kernels: they are the reference's architectures run through
-stock PyTorch-ROCm (`nn.Linear` -> hipBLASLt).  What this module adds is the loop around the HIP environment:
-fused flat observation -> model -> argmax -> `step`, greedy as in the reference's `run_game`
-(src/visualize.py:547-582), with every tensor staying on the device.
+The loop around the HIP environment -- fused flat observation -> model -> argmax -> `step`, greedy as in the reference's
+`run_game` (src/visualize.py:547-582) -- with every tensor staying on the device.  The networks are the reference's architectures
+as torch modules (so that its checkpoints load); a reference ``MLP`` on one of the compiled-in feature layouts does not RUN through
+torch, though: ``PolicyRollout`` hands its weights to the library once (``pack_mlp`` -> ``susnet_qnet_pack``) and a tick is then
+one kernel (``susnet_qnet_policy_step``: network on the f32-input MFMA, argmax, the crew's draws, the env step), or two
+(``susnet_qnet_forward`` + ``susnet_policy_step``) when the crew has a network too.  Everything else (``SpatialDQN``, other layer
+stacks) runs through stock PyTorch-ROCm and hands its Q rows to ``susnet_policy_step`` / ``susnet_policy_actions``.
 
 * ``MLP`` mirrors reference src/models/dqn.py:72-108 (`make_mlp` 322-329: Linear + PReLU, last activation
   dropped) INCLUDING the module names, so a reference checkpoint `{"state_dict", "config"}`
