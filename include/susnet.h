@@ -310,8 +310,15 @@ int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t dtype, int
  * torch.argmax / np.argmax.  q_crew = NULL: the crew draws uniformly random role-valid indices from the production action
  * stream -- exactly what susnet_sample_actions would return for them (PHILOX handles only).  One launch instead of the
  * role export + argmax + sample + dtype copy + where of the eager loop; actions_out as for susnet_sample_actions. */
-int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, void *actions_out, int32_t dtype,
-                          int32_t layout, void *stream);
+typedef struct susnet_policy_opts {
+    float epsilon;     /* epsilon-greedy, train.py:355-381: with this probability an agent takes its uniformly random role-valid draw (what
+                        * susnet_sample_actions returns for it) instead of the argmax; the decision is word tick * A + i of a third
+                        * stream of the handle's Philox key (PHILOX handles only); 0 = greedy */
+    int32_t mask_dead; /* != 0: dead agents get index 0 (train.py sets only the living agents' actions); 0: they act like everybody
+                        * else (run_game, visualize.py:547-560) -- the step ignores a dead agent's action either way */
+} susnet_policy_opts;
+int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts /* or NULL */,
+                          void *actions_out, int32_t dtype, int32_t layout, void *stream);
 
 /* The policy loop's Q-network -- the reference's MLP (src/models/dqn.py:72-108: make_mlp 322-329, Linear + nn.PReLU() with ONE
  * slope per layer, no activation after the last Linear) on the FlatFeaturizer observation of the handle's CURRENT environments
@@ -338,14 +345,15 @@ int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream);
  * the stepping lane takes the teams' greedy actions from the Q rows itself (q_imposter / q_crew as for susnet_policy_actions; at most
  * 16 actions per team) and steps with them; io->actions is an OUTPUT here (the actions taken, same dtypes / layouts; NULL: not kept),
  * every other field of io as for susnet_step. */
-int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_step_io *io, void *stream);
+int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts /* or NULL */,
+                       const susnet_step_io *io, void *stream);
 /* susnet_qnet_forward and susnet_policy_step (imposters by the network, random crew) as ONE kernel -- a whole tick of the acting loop
  * in one launch: the wave that computed its 64 environments' Q rows takes their argmax in registers and steps them.  Arguments as for
  * the two calls; q_out may be NULL (Q rows not kept).  Served: the two compiled-in games the network kernel knows the feature layout of
  * (2-agent 9x9 ImposterTrainingGround; 1v2 14x14 FourRoomEnv with 4 jobs), PHILOX handles; otherwise SUSNET_E_INVALID and the caller
  * uses the two calls. */
 int susnet_qnet_policy_step(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
-                            const float *packed, float *q_out, const susnet_step_io *io, void *stream);
+                            const float *packed, float *q_out, const susnet_policy_opts *opts /* or NULL */, const susnet_step_io *io, void *stream);
 int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
 int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);
 int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *size_out, int32_t *size2_out);

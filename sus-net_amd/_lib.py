@@ -90,6 +90,10 @@ class RingIO(C.Structure):
     ]
 
 
+class PolicyOpts(C.Structure):
+    _fields_ = [("epsilon", C.c_float), ("mask_dead", C.c_int32)]
+
+
 class RecordLayout(C.Structure):
     _fields_ = [("record_bytes", C.c_int32), ("off_rewards", C.c_int32), ("off_actions", C.c_int32), ("off_done", C.c_int32),
                 ("off_truncated", C.c_int32), ("off_obs", C.c_int32)]
@@ -159,9 +163,10 @@ def lib():
     L.susnet_sample_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.susnet_step.argtypes = [C.c_void_p, P(StepIO), C.c_void_p]
     L.susnet_rollout.argtypes = [C.c_void_p, P(RolloutIO), C.c_void_p]
-    L.susnet_policy_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(StepIO), C.c_void_p]
-    L.susnet_qnet_policy_step.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, P(StepIO), C.c_void_p]
-    L.susnet_policy_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.susnet_policy_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(PolicyOpts), P(StepIO), C.c_void_p]
+    L.susnet_qnet_policy_step.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, P(PolicyOpts), P(StepIO),
+                                          C.c_void_p]
+    L.susnet_policy_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(PolicyOpts), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.susnet_qnet_packed_floats.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32]
     L.susnet_qnet_pack.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, P(C.c_void_p), P(C.c_void_p), C.c_void_p, C.c_void_p]
     L.susnet_qnet_forward.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -117,8 +117,18 @@ struct PolicyActionSink {
     int32_t dtype;
     int64_t sa, k0;
     uint32_t roles, a_imp, a_crew; // a_crew = ~0u: keep the sampled index
+    float eps;                     // epsilon-greedy / dead mask: as PolicyStepSink (susnet_kernels.h)
+    uint32_t alive, mask_dead;
+    const PhiloxRng *rng;
+    ActionStream *xs;
+    uint64_t xbase;
     __device__ __forceinline__ void set_act(int i, uint32_t sampled) const {
-        const uint32_t a = ((roles >> i) & 1u) ? a_imp : (a_crew != ~0u ? a_crew : sampled);
+        uint32_t a = ((roles >> i) & 1u) ? a_imp : (a_crew != ~0u ? a_crew : sampled);
+        if (eps > 0.0f) {
+            const float u = (float)(xs->word(*rng, xbase + (uint64_t)i) >> 8) * 5.9604644775390625e-08f;
+            a = u <= eps ? sampled : a;
+        }
+        if (mask_dead && !((alive >> i) & 1u)) a = 0u;
         store_action(out, dtype, (int64_t)i * sa + k0, a);
     }
 };
@@ -132,34 +142,44 @@ __device__ __forceinline__ uint32_t argmax_row(const float *q, int n) {
     return best;
 }
 __global__ __launch_bounds__(kBlock) void k_policy_actions(Consts c, State s, const float *q_imp, const float *q_crew, int n_imp_actions,
-                                                           int n_crew_actions, void *out, int32_t dtype, int64_t sa, int64_t sb, uint64_t tick) {
+                                                           int n_crew_actions, void *out, int32_t dtype, int64_t sa, int64_t sb, uint64_t tick, float epsilon,
+                                                           int mask_dead) {
     using S = GenericSpec;
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; // (< Bp: rows are padded, every lane may load its roles)
     uint32_t roles = (1u << c.n_imp) - 1u; // fixed roles: the first n_imposters agents (base.py:286-290 without the shuffle)
-    if (c.shuffle_imp) {
+    uint32_t alive = ~0u;
+    if (c.shuffle_imp || mask_dead) {
         uint32_t w[SUSNET_MAX_AGENTS];
 #pragma unroll
         for (int i = 0; i < SUSNET_MAX_AGENTS; i++) w[i] = (uint32_t)s.agent[(size_t)(i < c.A ? i : c.A - 1) * c.Bp + b];
-        roles = 0;
+        uint32_t r2 = 0;
+        alive = 0;
 #pragma unroll
-        for (int i = 0; i < SUSNET_MAX_AGENTS; i++) roles |= (i < c.A ? (w[i] >> 9) & 1u : 0u) << i;
+        for (int i = 0; i < SUSNET_MAX_AGENTS; i++) {
+            r2 |= (i < c.A ? (w[i] >> 9) & 1u : 0u) << i;
+            alive |= (i < c.A ? (w[i] >> 8) & 1u : 0u) << i;
+        }
+        if (c.shuffle_imp) roles = r2;
     }
     uint64_t tick_word = tick;
     if (c.dev_tick) tick_word = s.tickw[b];
     if (b >= c.B) return;
+    PhiloxRng rng;
+    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0ull);
+    ActionStream as, xs;
+    as.init();
+    xs.init(kExploreStreamTag);
+    const uint64_t tk = uniform64(tick_word);
     PolicyActionSink sink = {out, dtype, sa, b * sb, roles, argmax_row(q_imp + b * n_imp_actions, n_imp_actions),
-                             q_crew ? argmax_row(q_crew + b * n_crew_actions, n_crew_actions) : ~0u};
-    if (q_crew) {
+                             q_crew ? argmax_row(q_crew + b * n_crew_actions, n_crew_actions) : ~0u, epsilon, alive, (uint32_t)mask_dead, &rng, &xs,
+                             tk * (uint64_t)c.A};
+    if (q_crew && !(epsilon > 0.0f)) {
         for (int i = 0; i < c.A; i++) sink.set_act(i, 0u);
         return;
     }
     Env e = {};
     e.imp = roles;
-    PhiloxRng rng;
-    rng.init(c.seed, c.env_id_base + (uint64_t)b, 0ull);
-    ActionStream as;
-    as.init();
-    sample_actions_env<S>(c, sink, e, rng, as, uniform64(tick_word));
+    sample_actions_env<S>(c, sink, e, rng, as, tk);
 }
 
 // Device-resident step counter (susnet_device_tick): one copy per environment, read and advanced by the lane that owns the
@@ -800,17 +820,33 @@ extern "C" int susnet_sample_actions(susnet_env *env, void *actions_out, int32_t
     return SUSNET_OK;
 }
 
-extern "C" int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, void *actions_out, int32_t dtype,
-                                     int32_t layout, void *stream) {
+// epsilon / mask_dead of a susnet_policy_opts (NULL = greedy, dead agents act like everybody else)
+static int policy_opts(const susnet_env *env, const susnet_policy_opts *opts, float &eps, int &mask_dead) {
+    eps = 0.0f;
+    mask_dead = 0;
+    if (!opts) return SUSNET_OK;
+    if (!(opts->epsilon >= 0.0f && opts->epsilon <= 1.0f)) return fail(SUSNET_E_INVALID, "susnet_policy_opts: epsilon must lie in [0, 1]");
+    if (opts->epsilon > 0.0f && env->cfg.rng_mode != SUSNET_RNG_PHILOX)
+        return fail(SUSNET_E_INVALID, "susnet_policy_opts: exploration draws come from the production stream: PHILOX handles only");
+    eps = opts->epsilon;
+    mask_dead = opts->mask_dead != 0;
+    return SUSNET_OK;
+}
+
+extern "C" int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts, void *actions_out,
+                                     int32_t dtype, int32_t layout, void *stream) {
     if (int rc = check_bound(env)) return rc;
     if (!q_imposter || !actions_out) return fail(SUSNET_E_INVALID, "susnet_policy_actions: null q_imposter / actions_out");
     if (dtype != SUSNET_U8 && dtype != SUSNET_I32 && dtype != SUSNET_I64) return fail(SUSNET_E_INVALID, "actions dtype must be U8/I32/I64");
     if (!q_crew && env->cfg.rng_mode != SUSNET_RNG_PHILOX)
         return fail(SUSNET_E_INVALID, "susnet_policy_actions: a random crew (q_crew = NULL) draws from the production stream: PHILOX handles only");
+    float eps;
+    int mask_dead;
+    if (int rc = policy_opts(env, opts, eps, mask_dead)) return rc;
     int64_t sa, sb;
     if (int rc = strides_for(env, layout, sa, sb)) return rc;
     hipLaunchKernelGGL(k_policy_actions, grid_for(env), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->c, env->s, q_imposter, q_crew,
-                       (int)env->layout.n_actions_imposter, (int)env->layout.n_actions_crew, actions_out, dtype, sa, sb, env->ticks);
+                       (int)env->layout.n_actions_imposter, (int)env->layout.n_actions_crew, actions_out, dtype, sa, sb, env->ticks, eps, mask_dead);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }
@@ -944,12 +980,20 @@ static int qnet_step_launch(susnet_env *env, const QnetFuse &f, const StepArgs &
     return SUSNET_OK;
 }
 
-static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_imp, const float *q_crew, void *stream, const QnetFuse *fuse = nullptr) {
+static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_imp, const float *q_crew, void *stream, const QnetFuse *fuse = nullptr,
+                     const susnet_policy_opts *opts = nullptr) {
     if (int rc = check_bound(env)) return rc;
     if (!io || (!io->actions && !q_imp && !fuse)) return fail(SUSNET_E_INVALID, "null actions");
     StepArgs a;
     std::memset(&a, 0, sizeof(a));
     a.actions = io->actions;
+    {
+        float eps;
+        int mask_dead;
+        if (int rc = policy_opts(env, opts, eps, mask_dead)) return rc;
+        a.epsilon = eps;
+        a.mask_dead = mask_dead;
+    }
     if (q_imp) {
         a.q_imp = q_imp;
         a.q_crew = q_crew;
@@ -1019,13 +1063,14 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
     return SUSNET_OK;
 }
 extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream) { return step_impl(env, io, nullptr, nullptr, stream); }
-extern "C" int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_step_io *io, void *stream) {
+extern "C" int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts, const susnet_step_io *io,
+                                  void *stream) {
     if (!q_imposter) return fail(SUSNET_E_INVALID, "susnet_policy_step: null q_imposter");
-    return step_impl(env, io, q_imposter, q_crew, stream);
+    return step_impl(env, io, q_imposter, q_crew, stream, nullptr, opts);
 }
 
 extern "C" int susnet_qnet_policy_step(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
-                                       const float *packed, float *q_out, const susnet_step_io *io, void *stream) {
+                                       const float *packed, float *q_out, const susnet_policy_opts *opts, const susnet_step_io *io, void *stream) {
     if (int rc = check_bound(env)) return rc;
     const int64_t n = susnet_qnet_packed_floats(env, components, n_components, dims, n_dims);
     if (n < 0) return (int)n;
@@ -1033,7 +1078,7 @@ extern "C" int susnet_qnet_policy_step(susnet_env *env, const int32_t *component
     if (dims[5] != env->layout.n_actions_imposter)
         return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: the network's output width must be the imposters' action count");
     const QnetFuse f = {qnet_feat(env, components, n_components), packed, q_out, dims[5]};
-    return step_impl(env, io, nullptr, nullptr, stream, &f);
+    return step_impl(env, io, nullptr, nullptr, stream, &f, opts);
 }
 
 extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out) {

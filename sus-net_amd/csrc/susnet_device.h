@@ -279,13 +279,17 @@ struct PhiloxRng {
 // far: the same for every env stepped in lockstep, so blocks are generated under wave-uniform control flow
 // (see sample_actions_env for the word assignment; 1v1: one Philox block per FOUR ticks).
 constexpr uint32_t kActionStreamTag = 0x80000000u;
+// a third stream of the same key: the acting loop's exploration draws (train.py:359,371: one uniform number per agent and step),
+// word tick * A + i; restated by the tests from the oracle's Philox function
+constexpr uint32_t kExploreStreamTag = 0x40000000u;
 struct ActionStream {
     uint64_t blk;          // block currently held (uniform across the wave)
     uint32_t w0, w1, w2, w3;
     uint32_t rem;          // what the last draw left of its word (the next draw of the same word continues from it)
-    __device__ __forceinline__ void init() { blk = ~0ull; w0 = w1 = w2 = w3 = 0; rem = 0; }
+    uint32_t tag;          // which stream of the key: kActionStreamTag (init) or kExploreStreamTag
+    __device__ __forceinline__ void init(uint32_t stream_tag = kActionStreamTag) { blk = ~0ull; w0 = w1 = w2 = w3 = 0; rem = 0; tag = stream_tag; }
     __device__ __forceinline__ void gen(const PhiloxRng &r, uint64_t b) {
-        uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32) | kActionStreamTag, c2 = r.e0, c3 = r.e1;
+        uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32) | tag, c2 = r.e0, c3 = r.e1;
         uint32_t a = r.k0, d = r.k1;
 #pragma unroll
         for (int q = 0; q < 10; q++) {

@@ -27,6 +27,8 @@ struct StepArgs {
     // NULL = the crew's draws from the action stream), made by the stepping lane itself and written to `actions` (NULL: not kept)
     const float *q_imp, *q_crew;
     int32_t n_qi, n_qc;
+    float epsilon;     // > 0: every agent explores (takes its uniformly random role-valid draw instead) with this probability
+    int32_t mask_dead; // != 0: dead agents are given index 0 (train.py:351-381 sets only the living agents' actions)
 };
 constexpr int kMaxPolicyActions = 16; // Q row lengths susnet_policy_step serves
 
@@ -39,8 +41,19 @@ struct PolicyStepSink {
     int32_t dtype;
     int64_t sa, k0;
     uint32_t roles, a_imp, a_crew; // a_crew = ~0u: keep the sampled index
+    // epsilon-greedy (train.py:355-381): explore[i] = the exploration stream's word for (tick, agent i) as a uniform number <= epsilon
+    float eps;
+    uint32_t alive, mask_dead;
+    const PhiloxRng *rng;
+    ActionStream *xs;
+    uint64_t xbase; // tick * A
     __device__ __forceinline__ void set_act(int i, uint32_t sampled) const {
-        const uint32_t a = ((roles >> i) & 1u) ? a_imp : (a_crew != ~0u ? a_crew : sampled);
+        uint32_t a = ((roles >> i) & 1u) ? a_imp : (a_crew != ~0u ? a_crew : sampled);
+        if (eps > 0.0f) {
+            const float u = (float)(xs->word(*rng, xbase + (uint64_t)i) >> 8) * 5.9604644775390625e-08f; // [0, 1): 24 bits
+            a = u <= eps ? sampled : a;
+        }
+        if (mask_dead && !((alive >> i) & 1u)) a = 0u;
         st.set_act(i, a);
         if (out) {
             if (dtype == SUSNET_U8) reinterpret_cast<uint8_t *>(out)[(int64_t)i * sa + k0] = (uint8_t)a;
@@ -195,14 +208,23 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
                 if (a.q_crew != nullptr && k < a.n_qc && qc[k] > hc) { hc = qc[k]; a_crew = (uint32_t)k; }
             }
             if (pre_imp >= 0) a_imp = (uint32_t)pre_imp;
-            PolicyStepSink<typename StoreFor<S>::type> sink = {st, const_cast<void *>(a.actions), a.act_dtype, a.act_sa, b * a.act_sb, S::imp(c, e.imp),
-                                                               a_imp, a_crew};
-            if (a.q_crew != nullptr) {
-                for (int i = 0; i < A; i++) sink.set_act(i, 0u);
-            } else if constexpr (!RNG::kNumpy) { // the crew's draws: made for EVERY agent (a word's digits depend on the draws before them)
-                ActionStream pas;
+            if constexpr (!RNG::kNumpy) {
+                ActionStream pas, xs;
                 pas.init();
-                sample_actions_env<S>(c, sink, e, rng, pas, step_tick);
+                xs.init(kExploreStreamTag);
+                PolicyStepSink<typename StoreFor<S>::type> sink = {st, const_cast<void *>(a.actions), a.act_dtype, a.act_sa, b * a.act_sb, S::imp(c, e.imp),
+                                                                   a_imp, a_crew, a.epsilon, e.alive, (uint32_t)a.mask_dead, &rng, &xs, step_tick * (uint64_t)A};
+                // the stream's draws are needed by a random crew and by exploration; they are made for EVERY agent (a word's digits
+                // depend on the draws before them)
+                if (a.q_crew != nullptr && !(a.epsilon > 0.0f)) {
+                    for (int i = 0; i < A; i++) sink.set_act(i, 0u);
+                } else {
+                    sample_actions_env<S>(c, sink, e, rng, pas, step_tick);
+                }
+            } else { // numpy tapes: both teams by their networks, no exploration (the host refuses anything else)
+                PolicyStepSink<typename StoreFor<S>::type> sink = {st, const_cast<void *>(a.actions), a.act_dtype, a.act_sa, b * a.act_sb, S::imp(c, e.imp),
+                                                                   a_imp, a_crew, 0.0f, e.alive, (uint32_t)a.mask_dead, nullptr, nullptr, 0ull};
+                for (int i = 0; i < A; i++) sink.set_act(i, 0u);
             }
         }
         constexpr bool kDuelSpec = !S::kGeneric && S::kA == 2 && S::kJ == 0 && S::kVar == SUSNET_VARIANT_ITG && S::kStaticRoles && S::kFixedOrder;

@@ -470,11 +470,20 @@ class BatchedFourRoomEnv:
             L.check(self.lib.susnet_sample_actions(self._h, buf.data_ptr(), dtype, layout, self._stream()))
         return buf
 
-    def policy_actions(self, q_imposter: torch.Tensor, q_crew: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    @staticmethod
+    def _policy_opts(epsilon: float, mask_dead: bool):
+        """susnet_policy_opts pointer (None = greedy, dead agents act like everybody else)."""
+        if not epsilon and not mask_dead:
+            return None
+        return C.byref(L.PolicyOpts(float(epsilon), 1 if mask_dead else 0))
+
+    def policy_actions(self, q_imposter: torch.Tensor, q_crew: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                       epsilon: float = 0.0, mask_dead: bool = False) -> torch.Tensor:
         """Greedy actions of one tick (visualize.py:547-562): every imposter takes ``argmax(q_imposter[b])``, every crew member
         ``argmax(q_crew[b])`` -- or, with ``q_crew=None``, its uniformly random draw from the action stream (what
-        ``sample_actions()`` returns for it).  One launch (``susnet_policy_actions``); returns ``out`` (default: an int64
-        ``[B, A]`` buffer the env keeps)."""
+        ``sample_actions()`` returns for it).  ``epsilon`` > 0: epsilon-greedy (train.py:355-381) -- with that probability an agent takes
+        its random draw instead, decided by a third Philox stream of the handle; ``mask_dead``: dead agents get index 0 (train.py).
+        One launch (``susnet_policy_actions``); returns ``out`` (default: an int64 ``[B, A]`` buffer the env keeps)."""
         assert q_imposter.dtype == torch.float32 and tuple(q_imposter.shape) == (self.batch, self.n_imposter_actions) and q_imposter.is_contiguous()
         if q_crew is not None:
             assert q_crew.dtype == torch.float32 and tuple(q_crew.shape) == (self.batch, self.n_crew_actions) and q_crew.is_contiguous()
@@ -485,7 +494,7 @@ class BatchedFourRoomEnv:
         dtype, layout, buf = self._describe_actions(out)
         with self._on_device():
             L.check(self.lib.susnet_policy_actions(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None,
-                                                   buf.data_ptr(), dtype, layout, self._stream()))
+                                                   self._policy_opts(epsilon, mask_dead), buf.data_ptr(), dtype, layout, self._stream()))
         return buf
 
     def qnet_pack(self, components: Sequence[str], weights, biases, slopes) -> Optional["PackedQNet"]:
@@ -562,7 +571,8 @@ class BatchedFourRoomEnv:
                 self.poll_errors()
         return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics()
 
-    def policy_step(self, q_imposter: torch.Tensor, q_crew: Optional[torch.Tensor] = None, actions_out: Optional[torch.Tensor] = None):
+    def policy_step(self, q_imposter: torch.Tensor, q_crew: Optional[torch.Tensor] = None, actions_out: Optional[torch.Tensor] = None,
+                    epsilon: float = 0.0, mask_dead: bool = False):
         """``policy_actions`` + ``step`` in ONE launch (``susnet_policy_step``): the stepping lane takes the teams' greedy actions from
         the Q rows itself.  Returns ``(state, rewards, done, truncated, info, actions)``; ``actions`` = ``actions_out`` (default: the
         env's int64 ``[B, A]`` buffer) holding the actions taken."""
@@ -577,8 +587,8 @@ class BatchedFourRoomEnv:
         io = self._step_io
         io.actions, io.actions_dtype, io.actions_layout = buf.data_ptr(), dtype, layout
         with self._on_device():
-            L.check(self.lib.susnet_policy_step(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None, C.byref(io),
-                                                self._stream()))
+            L.check(self.lib.susnet_policy_step(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None,
+                                                self._policy_opts(epsilon, mask_dead), C.byref(io), self._stream()))
             if self.export_state:
                 self._export(full=False)
             if self.check_errors:
@@ -592,7 +602,8 @@ class BatchedFourRoomEnv:
             return False
         return (self.n_agents, self.n_rows) in ((2, 9), (3, 14))
 
-    def qnet_policy_step(self, net: "PackedQNet", actions_out: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None):
+    def qnet_policy_step(self, net: "PackedQNet", actions_out: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None,
+                         epsilon: float = 0.0, mask_dead: bool = False):
         """A whole tick of the acting loop in ONE kernel (``susnet_qnet_policy_step``): the imposters' network (``net``), its argmax, the
         crew's random draws and the step.  Returns like ``policy_step``; raises ``RuntimeError`` where the library does not serve the
         configuration (callers fall back to ``qnet_forward`` + ``policy_step``)."""
@@ -607,7 +618,8 @@ class BatchedFourRoomEnv:
         io.actions, io.actions_dtype, io.actions_layout = buf.data_ptr(), dtype, layout
         with self._on_device():
             L.check(self.lib.susnet_qnet_policy_step(self._h, net.components, len(net.components), net.cdims, len(net.dims), net.packed.data_ptr(),
-                                                     q_out.data_ptr() if q_out is not None else None, C.byref(io), self._stream()))
+                                                     q_out.data_ptr() if q_out is not None else None, self._policy_opts(epsilon, mask_dead), C.byref(io),
+                                                     self._stream()))
             if self.export_state:
                 self._export(full=False)
             if self.check_errors:

@@ -187,10 +187,13 @@ class PolicyRollout:
     """
 
     def __init__(self, env, imposter_model: nn.Module, crew_model: Optional[nn.Module] = None,
-                 components: Sequence[str] = ("onehot_pos",), fused: bool = True):
+                 components: Sequence[str] = ("onehot_pos",), fused: bool = True, epsilon: float = 0.0, mask_dead: bool = False):
         assert env.obs_config.mode == "flat" and list(env.obs_config.components) == list(components), (
             "construct the env with obs=ObsConfig('flat', components) so that step() fuses the observation")
         self.env, self.imposter_model, self.crew_model = env, imposter_model, crew_model
+        # epsilon-greedy acting as in the trainer (train.py:355-381; `epsilon` may be changed between ticks: the scheduler's value) and its
+        # habit of giving dead agents index 0; both are applied by the kernels that choose the actions (PHILOX handles)
+        self.epsilon, self.mask_dead = float(epsilon), bool(mask_dead)
         # reference MLPs on a compiled-in feature layout run as ONE kernel from the state words to the Q row (susnet_qnet_forward);
         # anything else (SpatialDQN, other layer stacks / layouts) goes through the torch module on env.obs
         self.fused_imposter = pack_mlp(env, imposter_model, components) if fused else None
@@ -222,12 +225,12 @@ class PolicyRollout:
         ``act()`` + ``env.step``."""
         env = self.env
         if self.one_kernel_tick:
-            _, rew, done, trunc, _, a = env.qnet_policy_step(self.fused_imposter, actions_out=self._actions)
+            _, rew, done, trunc, _, a = env.qnet_policy_step(self.fused_imposter, actions_out=self._actions, epsilon=self.epsilon, mask_dead=self.mask_dead)
             return a, rew, done, trunc
         q_imp, q_crew = self.q_rows()
         fits = max(env.n_imposter_actions, env.n_crew_actions) <= 16 and (q_crew is not None or env.rng_kind == "philox")
         if fits:
-            _, rew, done, trunc, _, a = env.policy_step(q_imp, q_crew, actions_out=self._actions)
+            _, rew, done, trunc, _, a = env.policy_step(q_imp, q_crew, actions_out=self._actions, epsilon=self.epsilon, mask_dead=self.mask_dead)
             return a, rew, done, trunc
         a = self.act()
         _, rew, done, trunc, _ = env.step(a)
@@ -241,12 +244,13 @@ class PolicyRollout:
         where -- was five launches and a tenth of the tick's GPU time.)"""
         env = self.env
         q_imp, q_crew = self.q_rows()
-        if env.rng_kind != "philox" and q_crew is None:  # numpy tapes: the crew's draws come from the env's own words
+        if env.rng_kind != "philox" and q_crew is None:  # numpy tapes: the crew's draws come from the env's own words (greedy only)
+            assert not self.epsilon and not self.mask_dead, "epsilon-greedy / mask_dead act through the production stream: rng='philox'"
             if not env.export_state:
                 env.refresh_roles()
             torch.where(env.imposter_mask, q_imp.argmax(dim=1).unsqueeze(1), env.sample_actions().to(torch.int64), out=self._actions)
             return self._actions
-        return env.policy_actions(q_imp, q_crew, out=self._actions)
+        return env.policy_actions(q_imp, q_crew, out=self._actions, epsilon=self.epsilon, mask_dead=self.mask_dead)
 
     @torch.no_grad()
     def run(self, n_steps: int, record: bool = False) -> Dict[str, torch.Tensor]:

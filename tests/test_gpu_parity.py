@@ -1139,6 +1139,55 @@ def test_policy_actions_kernel(pkg, oracle_mod, name):
 
 
 @pytest.mark.parametrize("crew_net", [False, True])
+@pytest.mark.parametrize("name", ["base_1v2_j4_14", "tagging_1v4_j5", "itg_1v1_nowalls"])
+def test_epsilon_greedy_and_dead_mask(pkg, oracle_mod, name, crew_net):
+    """The trainer's acting rule (train.py:351-381) inside the kernels that choose the actions: with probability epsilon an agent takes
+    its uniformly random role-valid draw (the action stream's, what sample_actions() returns for it) instead of its team's argmax, dead
+    agents get index 0.  The explore decisions are word tick * A + i of the exploration stream (Philox key of the handle, counter word 1
+    tagged 0x40000000), restated here from the oracle's Philox function; susnet_policy_actions, susnet_policy_step (twin handle) and
+    the share of explored actions are checked tick by tick."""
+    B, T, seed, eps = 1500, 30, 29, 0.3
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=True)
+    twin, _ = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=True)
+    env.reset()
+    twin.reset()
+    ob.reset()
+    A = env.n_agents
+    gen = torch.Generator(device=env.device)
+    gen.manual_seed(8)
+    explored = total = 0
+    for tick in range(T):
+        q_imp = torch.randn(B, env.n_imposter_actions, device=env.device, generator=gen)
+        q_crew = torch.randn(B, env.n_crew_actions, device=env.device, generator=gen) if crew_net else None
+        st = ob.export()
+        imp, alive = st["imp"].astype(bool), st["alive"].astype(bool)
+        sampled = ob.sample_actions().astype(np.int64)
+        greedy = np.where(imp, np_(q_imp.argmax(1))[:, None], np_(q_crew.argmax(1))[:, None] if crew_net else sampled)
+        explore = np.zeros((B, A), dtype=bool)
+        for b in range(B):
+            for i in range(A):
+                idx = tick * A + i
+                w = oracle_mod.philox4x32_10([(idx >> 2) & 0xFFFFFFFF, ((idx >> 2) >> 32) | 0x40000000, b, 0], [seed & 0xFFFFFFFF, seed >> 32])[idx & 3]
+                explore[b, i] = np.float32(w >> 8) * np.float32(2.0 ** -24) <= np.float32(eps)
+        want = np.where(explore, sampled, greedy)
+        want_masked = np.where(alive, want, 0)
+        assert int(env.tick) == tick
+        np.testing.assert_array_equal(np_(env.policy_actions(q_imp, q_crew, epsilon=eps)), want, err_msg=f"{name} tick {tick}")
+        a = env.policy_actions(q_imp, q_crew, epsilon=eps, mask_dead=True).clone()
+        np.testing.assert_array_equal(np_(a), want_masked, err_msg=f"{name} tick {tick} (dead mask)")
+        np.testing.assert_array_equal(np_(env.policy_actions(q_imp, q_crew, mask_dead=True)), np.where(alive, greedy, 0))
+        _, r1, d1, t1, _ = env.step(a)
+        _, r2, d2, t2, _, a2 = twin.policy_step(q_imp, q_crew, epsilon=eps, mask_dead=True)
+        assert torch.equal(a2, a) and torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2) and torch.equal(t1, t2), (name, tick)
+        orew, odone, otrunc, rc = ob.step(np_(a))
+        assert rc == 0 and np.array_equal(np_(d1), odone.astype(bool))
+        ob.reset(mask=(odone | otrunc).astype(bool))
+        explored += int(explore.sum())
+        total += explore.size
+    assert abs(explored / total - eps) < 0.02, "the exploration stream is uniform"
+
+
+@pytest.mark.parametrize("crew_net", [False, True])
 @pytest.mark.parametrize("name", ["base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v1_nowalls", "itg_1v5_j3"])
 def test_policy_step_equals_policy_actions_then_step(pkg, oracle_mod, name, crew_net):
     """susnet_policy_step (argmax per team, the crew's draws and the step in ONE launch) against the two launches it replaces on a twin
@@ -1165,8 +1214,9 @@ def test_policy_step_equals_policy_actions_then_step(pkg, oracle_mod, name, crew
     assert int(e1.tick) == int(e2.tick) == T
 
 
+@pytest.mark.parametrize("eps", [0.0, 0.25])
 @pytest.mark.parametrize("name,comps", [("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"]), ("itg_1v1_nowalls", ["onehot_pos"])])
-def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps):
+def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps, eps):
     """susnet_qnet_policy_step (network, argmax, crew draws, step: ONE kernel) against susnet_qnet_forward + susnet_policy_step on a twin
     handle with the same seed: actions, reward bit patterns, done / truncated, the fused float observation and the exported state, tick
     after tick; B no multiple of the kernel's 256 environments per workgroup; the Q rows it can also emit."""
@@ -1179,8 +1229,8 @@ def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(6)
         model = pkg.MLP([e1.obs.shape[-1], 256, 128, 64, 16, e1.n_imposter_actions]).to(e1.device).eval()
-    two = pkg.PolicyRollout(e1, model, crew_model=None, components=comps)
-    one = pkg.PolicyRollout(e2, model, crew_model=None, components=comps)
+    two = pkg.PolicyRollout(e1, model, crew_model=None, components=comps, epsilon=eps, mask_dead=eps > 0)  # (0.25: the trainer's acting rule)
+    one = pkg.PolicyRollout(e2, model, crew_model=None, components=comps, epsilon=eps, mask_dead=eps > 0)
     assert one.one_kernel_tick and two.one_kernel_tick, "both games are served by the one-kernel tick"
     two.one_kernel_tick = False  # the twin takes the two-launch path
     ends = 0
