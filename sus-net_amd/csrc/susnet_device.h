@@ -286,7 +286,7 @@ struct ActionStream {
     uint64_t blk;          // block currently held (uniform across the wave)
     uint32_t w0, w1, w2, w3;
     uint32_t rem;          // what the last draw left of its word (the next draw of the same word continues from it)
-    uint32_t tag;          // which stream of the key: kActionStreamTag (init) or kExploreStreamTag
+    uint32_t tag = kActionStreamTag; // which stream of the key (also for objects that only ever gen(): GroupWords::refill); init(kExploreStreamTag) selects the other one
     __device__ __forceinline__ void init(uint32_t stream_tag = kActionStreamTag) { blk = ~0ull; w0 = w1 = w2 = w3 = 0; rem = 0; tag = stream_tag; }
     __device__ __forceinline__ void gen(const PhiloxRng &r, uint64_t b) {
         uint32_t c0 = (uint32_t)b, c1 = (uint32_t)(b >> 32) | tag, c2 = r.e0, c3 = r.e1;
