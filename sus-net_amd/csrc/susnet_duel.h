@@ -25,8 +25,11 @@ namespace susnet {
 
 struct Duel {
     uint32_t pq;    // biased coordinates, see above
-    uint32_t al;    // bit 0 imposter alive, bit 1 crew member alive
+    uint32_t lv;    // who is alive, AS THE MASK of their coordinate bytes: 0x0000ffff imposter (agent 0) | 0xffff0000 crew member
+                    // (a dead agent's move is masked with it in one instruction; flags, indices and stored bytes are bit picks of it)
 };
+// alive flags as flatten_state stores them next to the cells: byte 0 = imposter alive, byte 1 = crew member alive
+__device__ __forceinline__ uint32_t duel_alive_bytes(const Duel &d) { return __builtin_amdgcn_perm(0u, d.lv, 0x0c0c0200u) & 0x0101u; }
 
 // wave-uniform constants of a launch (scalar registers)
 struct DuelConsts {
@@ -47,29 +50,24 @@ template <class Store>
 __device__ __forceinline__ void to_duel(const Store &st, const Env &e, Duel &d) {
     const uint32_t c0 = st.xy(0), c1 = st.xy(1);
     d.pq = ((c0 & 15u) | ((c0 >> 4) << 8) | ((c1 & 15u) << 16) | ((c1 >> 4) << 24)) + k01;
-    d.al = e.alive & 3u;
+    d.lv = ((0u - (e.alive & 1u)) & 0x0000ffffu) | ((0u - ((e.alive >> 1) & 1u)) & 0xffff0000u);
 }
 template <class Store>
 __device__ __forceinline__ void from_duel(const Duel &d, Store &st, Env &e) {
     const uint32_t p = d.pq - k01;
     st.set_xy(0, (p & 15u) | (((p >> 8) & 15u) << 4));
     st.set_xy(1, ((p >> 16) & 15u) | (((p >> 24) & 15u) << 4));
-    e.alive = d.al;
+    e.alive = (d.lv & 1u) | ((d.lv >> 31) << 1);
 }
 
-// One step with role-relative actions a0 in [0, 6) (5 = KILL, pred_prey.py:12-19) and a1 in [0, 5).
-// Out: rewards as float32 bit patterns, done, truncated.  e: t, flags, info counters; cur: the env's event-stream cursor
-// (production protocol: a landed kill takes one word -- its value is never needed with a single candidate).
-template <bool NUMPY>
-__device__ __forceinline__ void duel_step(const DuelConsts &k, Duel &d, Env &e, uint64_t &cur, uint32_t a0, uint32_t a1, float &r0, float &r1,
-                                          uint32_t &done, uint32_t &trunc) {
-    e.m_steps += 1; // base.py:366
+// The step proper, with role-relative actions a0 in [0, 6) (5 = KILL, pred_prey.py:12-19) and a1 in [0, 5): cells, who is alive, the
+// landed kill, the rewards (float32), done.  Everything an episode merely COUNTS (steps, t, kills, flags, the kill's word of the
+// event stream) is duel_step's, below.
+__device__ __forceinline__ void duel_core(const DuelConsts &k, Duel &d, uint32_t a0, uint32_t a1, float &r0, float &r1, uint32_t &done, uint32_t &hit) {
     // KILL first (agent 0 acts first, base.py:377-382 with a fixed order): both alive, same cell (base.py:490-515)
     const uint32_t same = ((d.pq >> 16) == (d.pq & 0xffffu)) ? 1u : 0u;
-    const uint32_t hit = (a0 == 5u ? 1u : 0u) & same & (d.al == 3u ? 1u : 0u);
-    d.al &= ~(hit << 1);                 // base.py:511
-    e.m_kv += hit;                       // IMP_KILLED_CREW, base.py:508
-    if (!NUMPY) cur += (uint64_t)hit;    // (numpy draws nothing for a single candidate, base.py:497)
+    hit = (a0 == 5u ? 1u : 0u) & same & (d.lv == 0xffffffffu ? 1u : 0u);
+    d.lv &= hit ? 0x0000ffffu : 0xffffffffu; // base.py:511
     // moves (base.py:484-487): table of (dx, dy) per action -- STAY, UP (y + 1), DOWN, LEFT (x - 1), RIGHT, KILL (no move)
     const uint32_t selx = a0 | (a1 << 16) | 0x0c000c00u;       // byte 0 <- table[a0], byte 2 <- table[a1]
     // (v_perm: selector values 0..3 pick bytes of the SECOND operand, 4..7 of the first)
@@ -78,23 +76,38 @@ __device__ __forceinline__ void duel_step(const DuelConsts &k, Duel &d, Env &e, 
     const uint32_t dy = __builtin_amdgcn_perm(0x00000000u, 0x007f0100u, selx); // dy by action: 0 +1 -1 0 | 0 0
     uint32_t delta = dx | (dy << 8);
     // dead agents do not act (base.py:477); a crew member killed this tick never gets its turn
-    const uint32_t live = ((0u - (d.al & 1u)) & 0x0000ffffu) | ((0u - (d.al >> 1)) & 0xffff0000u);
-    delta &= live;
+    delta &= d.lv;
     const uint32_t q = (d.pq + delta) ^ ((delta << 1) & k80); // bytes in [0, n + 1]
     // undo a step off the grid: byte == 0 or byte == n + 1 (_is_valid_position, base.py:548-551: bounds only, no walls here)
     const uint32_t bad80 = ((q + k.hi_probe) | ~((q | k80) - k01)) & k80;
     const uint32_t badff = (bad80 - (bad80 >> 7)) | bad80;
     d.pq = (d.pq & badff) | (q & ~badff);
     // win (pred_prey.py:78-99 with no jobs): the imposter wins when no crew member is alive
-    const uint32_t dead0 = (d.al & 1u) ^ 1u, dead1 = (d.al >> 1) ^ 1u;
-    done = dead1;
-    e.flags |= dead1 << 2;               // FLAG_IMP_WON (metrics.update, pred_prey.py:96)
-    // rewards: byte tables over {kill landed, imposter dead, crew dead}
-    const uint32_t idx = hit | (dead0 << 1) | (dead1 << 2);
-    const int32_t b0 = (int32_t)(int8_t)__builtin_amdgcn_perm(k.lut0_hi, k.lut0_lo, idx | 0x0c0c0c00u);
-    const int32_t b1 = (int32_t)(int8_t)__builtin_amdgcn_perm(k.lut1_hi, k.lut1_lo, idx | 0x0c0c0c00u);
+    const uint32_t n = ~d.lv; // bit 1: imposter dead, bits 18 / 31: crew member dead
+    done = n >> 31;
+    // rewards: byte tables over {kill landed, imposter dead, crew dead} = selector bits 0, 1, 2 (only byte 0 of the picked word is
+    // read below, so whatever else the selector's upper bytes pick does not matter)
+    const uint32_t t = n & 0x00040002u;
+    const uint32_t idx = hit | t | (t >> 16);
+    const int32_t b0 = (int32_t)(int8_t)__builtin_amdgcn_perm(k.lut0_hi, k.lut0_lo, idx);
+    const int32_t b1 = (int32_t)(int8_t)__builtin_amdgcn_perm(k.lut1_hi, k.lut1_lo, idx);
     r0 = (float)b0;
     r1 = (float)b1;
+}
+
+// One step.  Out: rewards, done, truncated.  e: t, flags, info counters; cur: the env's event-stream cursor (production protocol: a
+// landed kill takes one word -- its value is never needed with a single candidate; numpy draws nothing there, base.py:497).
+// hit_out: the caller advances the cursor itself (k_rollout_duel: inside its episode-end branch).
+template <bool NUMPY>
+__device__ __forceinline__ void duel_step(const DuelConsts &k, Duel &d, Env &e, uint64_t &cur, uint32_t a0, uint32_t a1, float &r0, float &r1,
+                                          uint32_t &done, uint32_t &trunc, uint32_t *hit_out = nullptr) {
+    uint32_t hit;
+    duel_core(k, d, a0, a1, r0, r1, done, hit);
+    e.m_steps += 1;                      // base.py:366
+    e.m_kv += hit;                       // IMP_KILLED_CREW, base.py:508
+    if (hit_out) *hit_out = hit;
+    else if (!NUMPY) cur += (uint64_t)hit;
+    e.flags |= done << 2;                // FLAG_IMP_WON (metrics.update, pred_prey.py:96)
     // base.py:392-395: t saturates at max_time_steps - 1
     trunc = e.t == k.max_t_m1 ? 1u : 0u;
     e.t += trunc ^ 1u;

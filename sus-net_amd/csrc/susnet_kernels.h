@@ -1070,7 +1070,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     as.init();
     Duel d;
     to_duel(st, e, d);
-    const DuelConsts k = make_duel_consts(c);
+    DuelConsts k = make_duel_consts(c);
+    // the low halves of the two reward tables are v_perm's second source every tick and an instruction takes one scalar operand: as
+    // scalars they are copied to a vector register tick after tick (the compiler re-materialises rather than keep them); pinned here
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(k.lut0_lo), "=v"(k.lut1_lo) : "s"(k.lut0_lo), "s"(k.lut1_lo));
     uint64_t tick_base = a.tick_base;
     if (c.dev_tick) tick_base = uniform64(s.tickw[bl]); // (every env holds the same count)
     LifeAcc life;
@@ -1126,8 +1129,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
         }
         if (kTraj) da.st16(0u, a0 | (a1 << 8));
         float r0, r1;
-        uint32_t done, trunc;
-        duel_step<RNG::kNumpy>(k, d, e, rng.cur, a0, a1, r0, r1, done, trunc);
+        uint32_t done, trunc, hit;
+        duel_step<RNG::kNumpy>(k, d, e, rng.cur, a0, a1, r0, r1, done, trunc, &hit);
         if (kTraj) {
             dr.st64(0u, __float_as_uint(r0), __float_as_uint(r1));
             dd.st8(0u, done);
@@ -1135,11 +1138,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
         }
         if (kFeed(OUT) && a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)1u; // the imposter is agent 0 (pred_prey.py:52-66, shuffle off)
         if (__builtin_expect((done | trunc) != 0u, 0)) {
+            if (!RNG::kNumpy) rng.cur += (uint64_t)hit; // the landed kill's word of the event stream: a hit ends the episode (the crew has
+                                                        // one member), so it is counted here instead of by a 64-bit add on every tick
             life.add_episode(e, trunc != 0u);
             if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
                 PtrDst tp{a.term_obs + ((int64_t)tick * c.B + b) * 6};
                 tp.st32(0u, d.pq - k01);
-                tp.st16(4u, (d.al & 1u) | ((d.al & 2u) << 7));
+                tp.st16(4u, duel_alive_bytes(d));
             }
             reset_env<S>(c, T, st, tid, e, rng);
             to_duel(st, e, d);
@@ -1151,15 +1156,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
         }
         if (OUT == OUT_TRAJ_RAW8) { // flatten_state: x0 y0 x1 y1 alive0 alive1
             dobs.st32(0u, d.pq - k01);
-            dobs.st16(4u, (d.al & 1u) | ((d.al & 2u) << 7));
+            dobs.st16(4u, duel_alive_bytes(d));
         }
         if (kRec) {
             drec.st128(0u, __float_as_uint(r0), __float_as_uint(r1), a0 | (a1 << 8) | (done << 16) | (trunc << 24), d.pq - k01);
-            drec.st32(16u, (d.al & 1u) | ((d.al & 2u) << 7));
+            drec.st32(16u, duel_alive_bytes(d));
         }
         if constexpr (kFlat) { // onehot_pos of the state after the step (and after an in-launch reset)
             const uint32_t pos = d.pq - k01;
-            const uint32_t fx[2] = {pos & 0xffu, (pos >> 16) & 0xffu}, fy[2] = {(pos >> 8) & 0xffu, pos >> 24}, fal[2] = {d.al & 1u, d.al >> 1};
+            const uint32_t fx[2] = {pos & 0xffu, (pos >> 16) & 0xffu}, fy[2] = {(pos >> 8) & 0xffu, pos >> 24}, fal[2] = {d.lv & 1u, d.lv >> 31};
             FlatRowT frow;
             frow.build(fx, fy, fal);
             flat_store_wave(frow, T.stage, tid, nrows, dflat.r, dflat.vo + (uint32_t)tick * (slab_o * 4u));
