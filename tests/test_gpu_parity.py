@@ -1250,6 +1250,48 @@ def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps
     assert torch.equal(q, want), "the Q rows the one-kernel tick emits are the network kernel's"
 
 
+def test_one_kernel_policy_tick_long_horizon_and_full_size(pkg, oracle_mod):
+    """The one-kernel tick (susnet_qnet_policy_step) over many episode ends: 400 ticks of epsilon-greedy acting on 384 envs, the
+    recorded actions replayed on the oracle -- rewards bit for bit, done / truncated, the fused float observation after every in-step
+    reset.  And at the benchmark's size (65 536 envs) against the two-launch tick on a twin handle, 12 ticks, bit for bit."""
+    comps = ["onehot_pos", "alive_crew", "closest_crew"]
+    name, B, T, seed = "base_1v2_j4_14", 384, 400, 31
+    env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=True, obs=pkg.ObsConfig("flat", comps))
+    env.reset()
+    ob.reset()
+    model = pkg.policy.reference_imposter_mlp(env, comps, seed=9)
+    runner = pkg.PolicyRollout(env, model, crew_model=None, components=comps, epsilon=0.3)
+    assert runner.one_kernel_tick
+    ends = 0
+    for tick in range(T):
+        a, rew, done, trunc = runner.tick()
+        orew, odone, otrunc, rc = ob.step(np_(a))
+        assert rc == 0, f"tick {tick}: the oracle refuses an action the kernel chose"
+        assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"rewards tick {tick}"
+        np.testing.assert_array_equal(np_(done), odone.astype(bool), err_msg=f"done tick {tick}")
+        np.testing.assert_array_equal(np_(trunc), otrunc.astype(bool), err_msg=f"truncated tick {tick}")
+        ob.reset(mask=(odone | otrunc).astype(bool))
+        if tick % 20 == 0 or tick == T - 1:
+            np.testing.assert_array_equal(np_(env.obs), ob.obs_flat(comps), err_msg=f"fused flat obs tick {tick}")
+        ends += int(odone.sum()) + int(otrunc.sum())
+    assert ends > 50, "episodes ended inside the one-kernel tick"
+    # full size, against the two-launch tick
+    Bf = 65536
+    e1, _ = make_pair(pkg, oracle_mod, name, Bf, seed, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
+    e2, _ = make_pair(pkg, oracle_mod, name, Bf, seed, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
+    e1.reset()
+    e2.reset()
+    two = pkg.PolicyRollout(e1, model, crew_model=None, components=comps, epsilon=0.1, mask_dead=True)
+    one = pkg.PolicyRollout(e2, model, crew_model=None, components=comps, epsilon=0.1, mask_dead=True)
+    two.one_kernel_tick = False
+    for tick in range(12):
+        a1, r1, d1, t1 = two.tick()
+        a1 = a1.clone()
+        a2, r2, d2, t2 = one.tick()
+        assert torch.equal(a1, a2) and torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2) and torch.equal(t1, t2), tick
+        assert torch.equal(e1.obs, e2.obs), tick
+
+
 @pytest.mark.parametrize("name,comps,hidden,slopes,B", [
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [256, 128, 64, 16], (0.1, 0.3, 0.5, 0.7), 5037),  # BASELINE config 5's network
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [200, 100, 50, 10], (0.25, 0.25, 0.0, 1.0), 5037),  # widths that need padding
