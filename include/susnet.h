@@ -124,7 +124,7 @@ extern "C" {
 #define SUSNET_L_IMP_VOTED_OUT 7
 #define SUSNET_L_CREW_VOTED_OUT 8
 #define SUSNET_L_EPISODE_STEPS 9
-#define SUSNET_L_ENV_STEPS 10
+#define SUSNET_L_ENV_STEPS 10 /* every step the env took, finished episode or not (k_step: +1, a fused rollout: +n_ticks) */
 #define SUSNET_L_RESERVED 11
 
 typedef struct susnet_env susnet_env; /* opaque host-side handle */
@@ -199,7 +199,8 @@ typedef struct susnet_step_io {
 
 /* Fused random rollout: T lockstep ticks in one launch; per tick every env samples uniform role-valid
  * actions (sample_actions), steps, and auto-resets on done|truncated.  Every trajectory pointer is
- * optional (NULL = not stored).  Philox stream only. */
+ * optional (NULL = not stored).  PHILOX handles: any subset of outputs.  TAPE handles (numpy parity): the full trajectory
+ * with the raw uint8 observation, as separate tensors or as packed records. */
 typedef struct susnet_rollout_io {
     int32_t n_ticks;
     uint8_t *actions;   /* out [T][B][A] u8  (env-major: what reference callers index as actions[b]) */

@@ -935,11 +935,10 @@ extern "C" int susnet_qnet_pack(const susnet_env *env, const int32_t *components
 template <class ROW>
 static int qnet_launch(susnet_env *env, const float *packed, float *q_out, int n_out, hipStream_t st) {
     using Q = QNet<ROW>;
-    static bool lds_set = false; // 90 KB of LDS: above the 64 KB a kernel gets without asking
-    if (!lds_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet<ROW>), hipFuncAttributeMaxDynamicSharedMemorySize, Q::kLdsBytes));
-        lds_set = true;
-    }
+    // ~106 KB of dynamic LDS: above the 64 KB a kernel gets without asking.  The attribute belongs to the CURRENT device's function
+    // object, so it is set before every launch (a host-side table write: cheap; a process-wide "done" flag would leave a second
+    // device without it and race between host threads)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet<ROW>), hipFuncAttributeMaxDynamicSharedMemorySize, Q::kLdsBytes));
     const unsigned blocks = (unsigned)((env->c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
     hipLaunchKernelGGL(k_qnet<ROW>, dim3(blocks), dim3(Q::kThreads), Q::kLdsBytes, st, env->c, env->s, packed, q_out, n_out);
     HIP_TRY(hipGetLastError());
@@ -969,11 +968,7 @@ static int qnet_step_launch(susnet_env *env, const QnetFuse &f, const StepArgs &
     const size_t rest = step_lds - (size_t)kTableWords * 4;
     const size_t sh = (size_t)kTableWords * 4 + (size_t)Q::kLdsBytes + 4 * rest;
     if (sh > 160 * 1024) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: observation too large for the LDS left beside the network image");
-    static bool lds_set = false;
-    if (!lds_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet_step<ROW, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_set = true;
-    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet_step<ROW, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); // (per device: see qnet_launch)
     const unsigned blocks = (unsigned)((env->c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
     hipLaunchKernelGGL((k_qnet_step<ROW, S>), dim3(blocks), dim3(Q::kThreads), sh, st, env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest);
     HIP_TRY(hipGetLastError());
@@ -1004,10 +999,16 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
         if (!q_crew && env->cfg.rng_mode != SUSNET_RNG_PHILOX)
             return fail(SUSNET_E_INVALID, "susnet_policy_step: a random crew (q_crew = NULL) draws from the production stream: PHILOX handles only");
     }
-    a.act_dtype = io->actions_dtype;
-    if (a.act_dtype != SUSNET_U8 && a.act_dtype != SUSNET_I32 && a.act_dtype != SUSNET_I64)
-        return fail(SUSNET_E_INVALID, "actions dtype must be U8/I32/I64");
-    if (int rc = strides_for(env, io->actions_layout, a.act_sa, a.act_sb)) return rc;
+    if (io->actions) {
+        a.act_dtype = io->actions_dtype;
+        if (a.act_dtype != SUSNET_U8 && a.act_dtype != SUSNET_I32 && a.act_dtype != SUSNET_I64)
+            return fail(SUSNET_E_INVALID, "actions dtype must be U8/I32/I64");
+        if (int rc = strides_for(env, io->actions_layout, a.act_sa, a.act_sb)) return rc;
+    } else { // the policy forms with actions == NULL ("not kept"): a zero-initialised susnet_step_io is valid
+        a.act_dtype = SUSNET_U8;
+        a.act_sa = env->c.B;
+        a.act_sb = 1;
+    }
     a.rewards.ptr = io->rewards;
     if (io->rewards) {
         if (io->rewards_dtype != SUSNET_F32 && io->rewards_dtype != SUSNET_F64) return fail(SUSNET_E_INVALID, "rewards dtype must be F32/F64");

@@ -1265,9 +1265,11 @@ struct LifeAcc {
         v[SUSNET_L_CREW_VOTED_OUT] += e.m_kv >> 24;
         v[SUSNET_L_EPISODE_STEPS] += e.m_steps;
     }
-    __device__ __forceinline__ void flush(const Consts &c, const State &s, int64_t b) const {
+    // n_steps: the ticks this launch advanced the environment by (SUSNET_L_ENV_STEPS counts every step taken, finished episode or not)
+    __device__ __forceinline__ void flush(const Consts &c, const State &s, int64_t b, uint32_t n_steps) const {
 #pragma unroll
         for (int k = 0; k < 10; k++) s.life[(size_t)k * c.Bp + b] += v[k];
+        s.life[(size_t)SUSNET_L_ENV_STEPS * c.Bp + b] += n_steps;
     }
 };
 

@@ -310,6 +310,7 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
             bits = step_env<S, true, 0>(c, T, st, e, rng, a.rewards, b, done, trunc, nullptr, ord);
         }
         if (bits) atomicOr(s.err, bits);
+        else atomicAdd(&s.life[(size_t)SUSNET_L_ENV_STEPS * c.Bp + b], 1u); // (fire and forget: nothing waits for it)
         if (c.dev_tick) s.tickw[b] = step_tick + 1ull;
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
     if (active) {
         store_env<S>(c, s, st, b, e, true);
         finish_rng(s, b, rng);
-        life.flush(c, s, b);
+        life.flush(c, s, b, (uint32_t)(a.n_ticks > 0 ? a.n_ticks : 0));
         if (c.dev_tick) s.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     }
 }
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         from_swar<S>(c, w, st, e);
         store_env<S>(c, se, st, b, e, true);
         finish_rng(se, b, rng);
-        life.flush(c, se, b);
+        life.flush(c, se, b, (uint32_t)(a.n_ticks > 0 ? a.n_ticks : 0));
         if (c.dev_tick) se.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     }
 }
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
         const State se = kernarg_reload<State>(kStateArgOffset); // (not `s`: see kernarg_reload)
         store_env<S>(c, se, st, b, e, true);
         finish_rng(se, b, rng);
-        life.flush(c, se, b);
+        life.flush(c, se, b, (uint32_t)(a.n_ticks > 0 ? a.n_ticks : 0));
         if (c.dev_tick) se.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     }
 }
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     from_duel(d, st, e);
     store_env<S>(c, se, st, b, e, true);
     finish_rng(se, b, rng);
-    life.flush(c, se, b);
+    life.flush(c, se, b, (uint32_t)(a.n_ticks > 0 ? a.n_ticks : 0));
     if (c.dev_tick) se.tickw[b] = tick_base + (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
 }
 

@@ -466,7 +466,7 @@ class BatchedFourRoomEnv:
             if out is None:
                 L.check(self.lib.susnet_sample_actions(self._h, self._actions.data_ptr(), L.U8, L.LAYOUT_AB, self._stream()))
                 return self._actions_view  # [A][B] in memory, returned as a [B, A] view
-            dtype, layout, buf = self._describe_actions(out)
+            dtype, layout, buf = self._describe_actions(out, output=True)
             L.check(self.lib.susnet_sample_actions(self._h, buf.data_ptr(), dtype, layout, self._stream()))
         return buf
 
@@ -491,16 +491,17 @@ class BatchedFourRoomEnv:
             if getattr(self, "_policy_actions_buf", None) is None:
                 self._policy_actions_buf = torch.zeros(self.batch, self.n_agents, dtype=torch.int64, device=self.device)
             out = self._policy_actions_buf
-        dtype, layout, buf = self._describe_actions(out)
+        dtype, layout, buf = self._describe_actions(out, output=True)
         with self._on_device():
             L.check(self.lib.susnet_policy_actions(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None,
                                                    self._policy_opts(epsilon, mask_dead), buf.data_ptr(), dtype, layout, self._stream()))
         return buf
 
-    def qnet_pack(self, components: Sequence[str], weights, biases, slopes) -> Optional["PackedQNet"]:
+    def qnet_pack(self, components: Sequence[str], weights, biases, slopes, into: Optional["PackedQNet"] = None) -> Optional["PackedQNet"]:
         """Pack a reference ``MLP`` (dqn.py:72-108: ``weights[l]`` ``[out, in]`` float32, ``biases[l]``, one PReLU slope per hidden
         layer) for ``qnet_forward``.  Returns ``None`` when the library does not serve this handle / feature layout / layer stack
-        (callers then run the torch module and hand its Q rows to ``policy_actions``)."""
+        (callers then run the torch module and hand its Q rows to ``policy_actions``).  ``into``: re-pack changed weights of the same layer
+        stack into an existing image, in place (the trainer's optimizer step / target sync, train.py:402-416)."""
         comps = (C.c_int32 * len(components))(*[L.FLAT_COMPONENTS[k] for k in components])
         w = [np.ascontiguousarray(np.asarray(x, dtype=np.float32)) for x in weights]
         b = [np.ascontiguousarray(np.asarray(x, dtype=np.float32)) for x in biases]
@@ -513,9 +514,14 @@ class BatchedFourRoomEnv:
         n = self.lib.susnet_qnet_packed_floats(self._h, comps, len(components), cdims, len(dims))
         if n < 0:
             return None
-        host = np.empty(int(n), dtype=np.float32)
         wp = (C.c_void_p * len(w))(*[x.ctypes.data for x in w])
         bp = (C.c_void_p * len(b))(*[x.ctypes.data for x in b])
+        if into is not None:  # new weights into an existing image: same device buffer, so captured graphs that read it stay valid
+            assert list(into.dims) == dims and int(n) == into.host.size, "qnet_pack(into=...): another layer stack"
+            L.check(self.lib.susnet_qnet_pack(self._h, comps, len(components), cdims, len(dims), wp, bp, sl.ctypes.data, into.host.ctypes.data))
+            into.packed.copy_(torch.from_numpy(into.host), non_blocking=False)
+            return into
+        host = np.empty(int(n), dtype=np.float32)
         L.check(self.lib.susnet_qnet_pack(self._h, comps, len(components), cdims, len(dims), wp, bp, sl.ctypes.data, host.ctypes.data))
         return PackedQNet(comps, cdims, dims, torch.from_numpy(host).to(self.device), host)
 
@@ -532,10 +538,17 @@ class BatchedFourRoomEnv:
                                                  net.packed.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
-    def _describe_actions(self, a: torch.Tensor):
+    def _describe_actions(self, a: torch.Tensor, output: bool = False):
+        """(dtype, layout, tensor) of an action tensor as the C ABI takes it.  An INPUT of another dtype / stride pattern is converted;
+        an ``output=True`` buffer must be usable as it is (a converted copy would receive the kernel's writes instead of the caller's
+        tensor)."""
         if a is self._actions_view:
             return L.U8, L.LAYOUT_AB, a
         A, B = self.n_agents, self.batch
+        if output:
+            assert a.dtype in _TORCH_TO_SUS and a.device == self.device, f"action output buffers are uint8 / int32 / int64 on {self.device}"
+            assert (tuple(a.shape) == (B, A) and (a.is_contiguous() or a.t().is_contiguous())) or (tuple(a.shape) == (A, B) and a.is_contiguous() and A != B), \
+                f"action output buffers are [B, A] (either memory order) or contiguous [A, B], got shape {tuple(a.shape)} stride {a.stride()}"
         if a.dtype not in _TORCH_TO_SUS:
             a = a.to(torch.int64)
         if tuple(a.shape) == (B, A) and a.is_contiguous():
@@ -583,7 +596,7 @@ class BatchedFourRoomEnv:
             if getattr(self, "_policy_actions_buf", None) is None:
                 self._policy_actions_buf = torch.zeros(self.batch, self.n_agents, dtype=torch.int64, device=self.device)
             actions_out = self._policy_actions_buf
-        dtype, layout, buf = self._describe_actions(actions_out)
+        dtype, layout, buf = self._describe_actions(actions_out, output=True)
         io = self._step_io
         io.actions, io.actions_dtype, io.actions_layout = buf.data_ptr(), dtype, layout
         with self._on_device():
@@ -611,7 +624,7 @@ class BatchedFourRoomEnv:
             if getattr(self, "_policy_actions_buf", None) is None:
                 self._policy_actions_buf = torch.zeros(self.batch, self.n_agents, dtype=torch.int64, device=self.device)
             actions_out = self._policy_actions_buf
-        dtype, layout, buf = self._describe_actions(actions_out)
+        dtype, layout, buf = self._describe_actions(actions_out, output=True)
         if q_out is not None:
             assert q_out.dtype == torch.float32 and tuple(q_out.shape) == (self.batch, net.dims[-1]) and q_out.is_contiguous()
         io = self._step_io

@@ -163,9 +163,9 @@ def reference_imposter_mlp(env, components: Sequence[str], seed: int = 0) -> MLP
     return model.to(env.device).eval()
 
 
-def pack_mlp(env, model, components: Sequence[str]):
+def pack_mlp(env, model, components: Sequence[str], into=None):
     """``env.qnet_pack`` of a reference ``MLP`` (Linear / nn.PReLU() alternating, dqn.py:322-329), or None if ``model`` is something
-    else or the library does not serve its shape on this env."""
+    else or the library does not serve its shape on this env.  ``into``: an image of the same stack to overwrite in place."""
     if not isinstance(model, MLP):
         return None
     layers = list(model.model)
@@ -174,7 +174,12 @@ def pack_mlp(env, model, components: Sequence[str]):
             not all(isinstance(m, nn.PReLU) and m.weight.numel() == 1 for m in acts) or len(acts) != len(linears) - 1:
         return None
     cpu = lambda t: t.detach().to("cpu", torch.float32).numpy()
-    return env.qnet_pack(components, [cpu(m.weight) for m in linears], [cpu(m.bias) for m in linears], [float(m.weight.detach()) for m in acts])
+    return env.qnet_pack(components, [cpu(m.weight) for m in linears], [cpu(m.bias) for m in linears], [float(m.weight.detach()) for m in acts], into=into)
+
+
+def _weights_version(model) -> int:
+    """Changes whenever a parameter of ``model`` is written in place (optimizer.step, load_state_dict, target sync) or replaced."""
+    return 0 if model is None else sum(p._version + id(p) for p in model.parameters())
 
 
 class PolicyRollout:
@@ -196,8 +201,10 @@ class PolicyRollout:
         self.epsilon, self.mask_dead = float(epsilon), bool(mask_dead)
         # reference MLPs on a compiled-in feature layout run as ONE kernel from the state words to the Q row (susnet_qnet_forward);
         # anything else (SpatialDQN, other layer stacks / layouts) goes through the torch module on env.obs
+        self.components = list(components)
         self.fused_imposter = pack_mlp(env, imposter_model, components) if fused else None
         self.fused_crew = pack_mlp(env, crew_model, components) if fused and crew_model is not None else None
+        self._packed_version = (_weights_version(imposter_model), _weights_version(crew_model))
         # ... and with a random crew on one of the compiled-in games the whole tick -- network, argmax, the crew's draws, the step -- is
         # ONE kernel (susnet_qnet_policy_step)
         self.one_kernel_tick = (self.fused_imposter is not None and crew_model is None and env.rng_kind == "philox" and
@@ -206,10 +213,27 @@ class PolicyRollout:
         self._spatial = torch.zeros(B, 1, 1, device=env.device)  # FlatFeaturizer's dummy spatial input
         self._actions = torch.zeros(B, env.n_agents, dtype=torch.int64, device=env.device)
 
+    def refresh_weights(self, force: bool = True) -> bool:
+        """Re-pack the models' CURRENT weights into the device images the fused kernels read (in place: a captured graph keeps
+        reading the same buffers).  The acting loop of the trainer changes the weights between ticks (optimizer.step, target sync:
+        train.py:402-416); ``tick()`` / ``act()`` / ``q_rows()`` call this with ``force=False`` -- a version check of the parameters --
+        so eager loops follow the modules by themselves, but a REPLAYED graph runs no host code: call ``refresh_weights()`` before
+        ``graph.replay()`` after changing weights.  Returns whether anything was re-packed."""
+        ver = (_weights_version(self.imposter_model), _weights_version(self.crew_model))
+        if not force and ver == self._packed_version:
+            return False
+        if self.fused_imposter is not None:
+            pack_mlp(self.env, self.imposter_model, self.components, into=self.fused_imposter)
+        if self.fused_crew is not None:
+            pack_mlp(self.env, self.crew_model, self.components, into=self.fused_crew)
+        self._packed_version = ver
+        return self.fused_imposter is not None or self.fused_crew is not None
+
     @torch.no_grad()
     def q_rows(self):
         """The teams' Q rows on the current observation: ``(q_imposter [B, n_imposter_actions], q_crew or None)``."""
         env = self.env
+        self.refresh_weights(force=False)
         feats = env.obs  # [B, F] float32, refreshed by reset()/step()
         q_imp = env.qnet_forward(self.fused_imposter) if self.fused_imposter is not None else self.imposter_model(self._spatial, feats)
         q_crew = None
@@ -225,6 +249,7 @@ class PolicyRollout:
         ``act()`` + ``env.step``."""
         env = self.env
         if self.one_kernel_tick:
+            self.refresh_weights(force=False)
             _, rew, done, trunc, _, a = env.qnet_policy_step(self.fused_imposter, actions_out=self._actions, epsilon=self.epsilon, mask_dead=self.mask_dead)
             return a, rew, done, trunc
         q_imp, q_crew = self.q_rows()
