@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SUSNET_ABI_VERSION 4
+#define SUSNET_ABI_VERSION 5
 
 #define SUSNET_MAX_AGENTS 16
 #define SUSNET_MAX_JOBS 16
@@ -275,8 +275,10 @@ typedef struct susnet_state_view {
     int32_t *tag_reset_timer; /* [B]                         tagging.py:31 */
     int32_t *t;               /* [B]                         base.py:315 */
     int64_t *metrics;         /* [B][13] info counters       metrics.py:35-64 */
-    uint64_t *rng_cursor;     /* [B] words consumed so far */
+    uint64_t *rng_cursor;     /* [B] words consumed so far (PHILOX: the event stream = the kill draws; TAPE: every draw) */
     uint32_t *lifetime;       /* [SUSNET_N_LIFETIME][B] per-env sums over finished episodes */
+    uint32_t *episode_index;  /* [B] resets drawn so far = the index of the env's next reset in the RESET stream (PHILOX handles:
+                                 a reset's draws are a function of (seed, global env id, this index) alone) */
 } susnet_state_view;
 
 int susnet_abi_version(void);

@@ -40,7 +40,7 @@ class SoRng(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("mt", C.c_uint32 * 624), ("mti", C.c_int32), ("tape", C.POINTER(C.c_uint32)),
         ("tape_len", C.c_int64), ("seed", C.c_uint64), ("env_id", C.c_uint64), ("cursor", C.c_uint64),
-        ("tick", C.c_uint64), ("overflow", C.c_int32),
+        ("tick", C.c_uint64), ("overflow", C.c_int32), ("episode", C.c_uint32), ("reset_pos", C.c_uint32), ("in_reset", C.c_int32),
     ]
 
 
@@ -292,6 +292,16 @@ class OracleBatch:
         return np.array([self.envs[b].rng.cursor for b in range(self.B)], dtype=np.int64)
 
     @property
+    def episode(self):
+        """Resets drawn so far per env (index of the production RESET stream; Philox kind)."""
+        return np.array([self.envs[b].rng.episode for b in range(self.B)], dtype=np.int64)
+
+    def set_episode(self, episode):
+        ep = np.broadcast_to(np.asarray(episode, dtype=np.int64), (self.B,))
+        for b in range(self.B):
+            self.envs[b].rng.episode = int(ep[b])
+
+    @property
     def tape_overflow(self):
         return np.array([self.envs[b].rng.overflow for b in range(self.B)], dtype=np.int64)
 
@@ -304,6 +314,7 @@ class OracleBatch:
                    metrics=np.zeros((B, N_METRICS), np.int64), cursor=np.zeros(B, np.uint64))
         self.L.so_batch_export(self.envs, B, *[out[k].ctypes.data for k in
                                ("pos", "alive", "imp", "jobpos", "jobdone", "used", "counts", "timer", "t", "metrics", "cursor")])
+        out["episode"] = self.episode.astype(np.uint32)
         return out
 
     def imp_idxs(self, b=0):

@@ -84,11 +84,20 @@ void so_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
     for (int i = 0; i < 4; i++) out[i] = c[i];
 }
 
-/* Two streams share the key and the env id: the per-env EVENT stream (reset / step-internal draws; tag 0) and the
+/* Streams that share the key and the env id: the per-env EVENT stream (step-internal draws: the kill draws; tag 0), the
  * ACTION stream (tag bit 31 of counter word 1), whose word index is tick * A + agent with `tick` the number of
  * steps taken -- identical for all envs stepped in lockstep, so a wave generates action blocks under uniform
- * control flow and every generated word is used. */
+ * control flow and every generated word is used -- and the RESET stream (tag bit 29): word j of the env's n-th reset
+ * (n = resets drawn since seeding) is word j & 3 of the block with counter (n, tag | j >> 2, env).  A reset's draws are
+ * thereby a function of (seed, env, n) alone -- not of how many words the episodes before it consumed -- which is
+ * what lets the fused rollouts draw an environment's NEXT episode ahead of time, all lanes of a wave at once. */
 #define SO_ACTION_STREAM_TAG 0x80000000u
+#define SO_RESET_STREAM_TAG 0x20000000u
+static uint32_t philox_reset_word(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t j) {
+    uint32_t c[4] = {episode, SO_RESET_STREAM_TAG | (j >> 2), (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return c[j & 3];
+}
 static uint32_t philox_word_tagged(uint64_t seed, uint64_t env_id, uint64_t cursor, uint32_t tag) {
     uint64_t block = cursor >> 2;
     uint32_t c[4] = {(uint32_t)block, (uint32_t)(block >> 32) | tag, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
@@ -116,6 +125,7 @@ uint32_t so_next_u32(so_env *e) {
         }
         break;
     case SO_RNG_PHILOX:
+        if (r->in_reset) return philox_reset_word(r->seed, r->env_id, r->episode, r->reset_pos++); /* (the event cursor stays) */
         w = philox_word(r->seed, r->env_id, r->cursor);
         break;
     default:
@@ -148,7 +158,11 @@ void so_set_philox(so_env *e, uint64_t seed, uint64_t env_id, uint64_t cursor) {
     e->rng.cursor = cursor;
     e->rng.overflow = 0;
     e->rng.tick = 0;
+    e->rng.episode = 0;
+    e->rng.reset_pos = 0;
+    e->rng.in_reset = 0;
 }
+void so_set_episode(so_env *e, uint32_t episode) { e->rng.episode = episode; }
 
 void so_set_tick(so_env *e, uint64_t tick) { e->rng.tick = tick; }
 
@@ -176,10 +190,10 @@ static int np_randint(so_env *e, int n) { return (int)rk_interval(e, (uint32_t)(
  * MT19937 / TAPE : numpy-legacy semantics (reference behaviour).
  * PHILOX         : the PRODUCT's production protocol, restated here only so that the HIP kernels can be
  *                  checked bit for bit in that mode too (it is not reference behaviour; it draws from the
- *                  same distributions): the cursor is aligned to a 4-word Philox block at the start of
- *                  reset / sample_actions / step, every bounded draw consumes exactly one word (also for
- *                  n == 1) and maps it with a multiply-shift, and "without replacement" is sequential
- *                  rejection of duplicates instead of a full permutation. */
+ *                  same distributions): the event cursor is aligned to a 4-word Philox block at the start of
+ *                  a step, every bounded draw consumes exactly one word (also for n == 1) and maps it with a
+ *                  multiply-shift, "without replacement" is sequential rejection of duplicates instead of a
+ *                  full permutation, and a reset draws from the RESET stream (above), word 0 onwards. */
 static int draw_bounded(so_env *e, int n) {
     if (e->rng.kind == SO_RNG_PHILOX) return (int)(((uint64_t)so_next_u32(e) * (uint64_t)(uint32_t)n) >> 32);
     return np_randint(e, n);
@@ -308,8 +322,11 @@ void so_reset(so_env *e) {
     const int A = e->A, J = e->J;
     memset(e->metrics, 0, sizeof(e->metrics)); /* base.py:270 */
 
-    draw_align(e);
     const int philox = e->rng.kind == SO_RNG_PHILOX;
+    if (philox) { /* production protocol: this reset's own words of the RESET stream */
+        e->rng.in_reset = 1;
+        e->rng.reset_pos = 0;
+    }
     /* base.py:273-278 */
     if (e->cfg.shuffle_imposter_index && philox) {
         for (int i = 0; i < A; i++) e->imp_mask[i] = 0;
@@ -358,6 +375,10 @@ void so_reset(so_env *e) {
             e->jobpos[j][0] = e->valid[perm[j]][0];
             e->jobpos[j][1] = e->valid[perm[j]][1];
         }
+    }
+    if (philox) {
+        e->rng.in_reset = 0;
+        e->rng.episode += 1u;
     }
     for (int i = 0; i < A; i++) e->alive[i] = 1;     /* base.py:301 */
     for (int j = 0; j < J; j++) e->jobdone[j] = 0;   /* base.py:302 */
@@ -678,6 +699,10 @@ void so_batch_obs_raw(const so_env *envs, int64_t B, uint8_t *out /*[B][F]*/) {
         so_obs_raw(&envs[b], tmp);
         for (int k = 0; k < F; k++) out[b * F + k] = (uint8_t)tmp[k];
     }
+}
+
+void so_batch_export_episode(const so_env *envs, int64_t B, uint32_t *episode) {
+    for (int64_t b = 0; b < B; b++) episode[b] = envs[b].rng.episode;
 }
 
 /* dense export of the batched state (test convenience; avoids per-env Python loops) */

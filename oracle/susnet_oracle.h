@@ -80,6 +80,9 @@ typedef struct so_rng {
     uint64_t cursor;  /* words consumed so far (all kinds) */
     uint64_t tick;    /* steps taken: index of the production ACTION stream */
     int32_t overflow; /* tape exhausted */
+    uint32_t episode; /* resets drawn so far: index of the production RESET stream (Philox kind only) */
+    uint32_t reset_pos; /* word position inside the reset being drawn (Philox kind only) */
+    int32_t in_reset;
 } so_rng;
 
 typedef struct so_env {
@@ -137,6 +140,8 @@ void so_batch_obs_raw(const so_env *envs, int64_t B, uint8_t *out);
 void so_batch_export(const so_env *envs, int64_t B, int32_t *pos, uint8_t *alive, uint8_t *imp, int32_t *jobpos,
                      uint8_t *jobdone, uint8_t *used, int32_t *counts, int32_t *timer, int32_t *t, int64_t *metrics,
                      uint64_t *cursor);
+void so_batch_export_episode(const so_env *envs, int64_t B, uint32_t *episode); /* resets drawn so far (production RESET stream) */
+void so_set_episode(so_env *e, uint32_t episode);
 /* populate()-shaped random rollout (replay_memory.py:96-143 minus the buffer): per env
  * reset; repeat {sample_actions; step; reset on done|trunc}; returns env-steps taken (B*steps). */
 int64_t so_batch_random_rollout(so_env *envs, int64_t B, int64_t steps, int threads, int64_t *episodes_out,

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libsusnet_hip.so"
 LIB_PATH = os.environ.get("SUSNET_LIB_PATH", os.path.join(PKG_DIR, LIB_NAME))  # override: A/B experiments only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_AGENTS, MAX_JOBS, MAX_GRID, N_METRICS, N_LIFETIME = 16, 16, 16, 13, 12
 
 VARIANT_BASE, VARIANT_ITG, VARIANT_TAGGING = 0, 1, 2
@@ -104,7 +104,7 @@ class StateView(C.Structure):
         ("agent_positions", C.c_void_p), ("alive_agents", C.c_void_p), ("imposter_mask", C.c_void_p),
         ("job_positions", C.c_void_p), ("completed_jobs", C.c_void_p), ("used_tag_actions", C.c_void_p),
         ("tag_counts", C.c_void_p), ("tag_reset_timer", C.c_void_p), ("t", C.c_void_p), ("metrics", C.c_void_p),
-        ("rng_cursor", C.c_void_p), ("lifetime", C.c_void_p),
+        ("rng_cursor", C.c_void_p), ("lifetime", C.c_void_p), ("episode_index", C.c_void_p),
     ]
 
 

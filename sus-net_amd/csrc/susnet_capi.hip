@@ -343,6 +343,7 @@ __global__ __launch_bounds__(kBlock) void k_export(Consts c, State s, susnet_sta
     if (v.tag_reset_timer) v.tag_reset_timer[b] = s.timer[b];
     if (v.t) v.t[b] = s.t[b];
     if (v.rng_cursor) v.rng_cursor[b] = s.rng[b];
+    if (v.episode_index) v.episode_index[b] = s.ep[b];
     if (v.metrics) {
         int64_t *m = v.metrics + b * SUSNET_N_METRICS;
         const uint32_t kv = s.m_kv[b], fl = s.flags[b];
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_import(Consts c, State s, susnet_sta
     if (v.tag_reset_timer) s.timer[b] = (uint16_t)v.tag_reset_timer[b];
     if (v.t) s.t[b] = (uint16_t)v.t[b];
     if (v.rng_cursor) s.rng[b] = v.rng_cursor[b];
+    if (v.episode_index) s.ep[b] = v.episode_index[b];
     if (v.metrics) {
         const int64_t *m = v.metrics + b * SUSNET_N_METRICS;
         s.m_kv[b] = ((uint32_t)m[0] & 0xffffu) | (((uint32_t)m[1] & 0xffu) << 16) | (((uint32_t)m[2] & 0xffu) << 24);
@@ -401,7 +403,10 @@ __global__ __launch_bounds__(kBlock) void k_import(Consts c, State s, susnet_sta
 
 __global__ void k_fill_cursor(Consts c, State s, uint64_t cursor) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < c.B) s.rng[b] = cursor;
+    if (b < c.B) {
+        s.rng[b] = cursor;
+        s.ep[b] = 0u; // the RESET stream restarts with the seed
+    }
 }
 
 // lifetime row sums: grid = (chunks, rows); 64-lane shuffles, one LDS hop across the block's 4 waves, then ONE
@@ -433,7 +438,7 @@ struct susnet_env {
     int spec = 0; // pick_spec(): which compiled-in kernel family serves the handle (0 = generic)
     susnet_layout layout;
     uint64_t off_err, off_agent, off_job, off_jobdone, off_t, off_timer, off_flags, off_rng, off_msteps, off_mfix, off_msab,
-        off_mkv, off_life, off_tickw;
+        off_mkv, off_life, off_tickw, off_ep;
 };
 
 static thread_local std::string g_err;
@@ -613,6 +618,7 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     e->off_mkv = take(4 * Bp);
     e->off_life = take(4 * Bp * SUSNET_N_LIFETIME);
     e->off_tickw = take(8 * Bp);
+    e->off_ep = take(4 * Bp);
     susnet_layout &L = e->layout;
     L.state_bytes = off;
     L.state_align = 256;
@@ -660,6 +666,7 @@ extern "C" int susnet_bind_state(susnet_env *env, void *blob, uint64_t bytes, vo
     s.m_kv = reinterpret_cast<uint32_t *>(p + env->off_mkv);
     s.life = reinterpret_cast<uint32_t *>(p + env->off_life);
     s.tickw = reinterpret_cast<uint64_t *>(p + env->off_tickw);
+    s.ep = reinterpret_cast<uint32_t *>(p + env->off_ep);
     s.tape = tape;
     s.tape_len = tape_len;
     HIP_TRY(hipMemsetAsync(blob, 0, env->layout.state_bytes, static_cast<hipStream_t>(stream)));
@@ -756,9 +763,11 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
 
 // spec: what pick_spec() returned for the launch (0 = the generic kernels, the LDS-column store; 3 / 4 / 6 = the byte-parallel
 // configurations, whose rollouts stage the action stream in LDS: HasGroupWords in susnet_device.h)
-static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset, int spec = 0) {
+// rollout: the launch is a fused rollout (the byte-parallel ones also keep the cell -> job map there: susnet_swar.h JobMap)
+static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset, int spec = 0, bool rollout = false) {
     const Consts &c = env->c;
-    size_t core = (size_t)lds_core_words(c.A, c.J, spec == 0, spec == 3 || spec == 4 || spec == 6) * 4;
+    const bool swar = spec == 3 || spec == 4 || spec == 6;
+    size_t core = (size_t)lds_core_words(c.A, c.J, spec == 0, swar, (swar && rollout) ? c.N : 0) * 4;
     size_t perm = (may_reset && env->cfg.rng_mode == SUSNET_RNG_TAPE) ? (size_t)c.n_valid * kBlock : 0;
     size_t stage = (size_t)(o.words1 + o.words2) * 4;
     return core + (perm > stage ? perm : stage);
@@ -1140,7 +1149,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         if ((uintptr_t)a.record % 16) return fail(SUSNET_E_INVALID, "record buffer must be 16-byte aligned");
         a.record_bytes = lay.record_bytes;
     }
-    size_t sh = lds_bytes(env, o, true, spec);
+    size_t sh = lds_bytes(env, o, true, spec, true);
     CHECK_LDS(sh);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 g((unsigned)((env->c.B + env->c.epw - 1) / env->c.epw)), blk(kBlock);

@@ -125,6 +125,7 @@ struct State {
     uint16_t *timer;    // [Bp] tag_reset_timer
     uint8_t *flags;     // [Bp]
     uint64_t *rng;      // [Bp] words consumed
+    uint32_t *ep;       // [Bp] resets drawn so far: the index of the env's next reset in the RESET stream (production protocol)
     uint32_t *m_steps;  // [Bp] TOTAL_TIME_STEPS
     uint32_t *m_fix;    // [Bp] COMPLETED_JOBS
     uint32_t *m_sab;    // [Bp] SABOTAGED_JOBS
@@ -320,6 +321,54 @@ struct ActionStream {
     }
 };
 
+// RESET stream of the production protocol (counter word 1 tagged with bit 29; restated in oracle/susnet_oracle.c
+// philox_reset_word): word j of the env's n-th reset is word j & 3 of the block with counter (n, tag | j >> 2, env).  A reset's
+// draws are a function of (seed, env, n) alone -- not of how many words earlier episodes consumed -- so a fused rollout can draw an
+// environment's NEXT episode ahead of time, all lanes of a wave at once (susnet_kernels.h NextEpisode), instead of sending the whole
+// wave through the reset path whenever one lane's episode ends.
+constexpr uint32_t kResetStreamTag = 0x20000000u;
+struct ResetStream {
+    static constexpr bool kNumpy = false;
+    uint32_t k0, k1, e0, e1, n;
+    uint32_t pos, held; // word position inside this reset; block whose words are held (~0u: none)
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ void init(const PhiloxRng &r, uint32_t episode) {
+        k0 = r.k0; k1 = r.k1; e0 = r.e0; e1 = r.e1; n = episode;
+        pos = 0; held = ~0u;
+        w0 = w1 = w2 = w3 = 0;
+    }
+    __device__ __forceinline__ void gen(uint32_t blk) {
+        uint32_t c0 = n, c1 = kResetStreamTag | blk, c2 = e0, c3 = e1;
+        uint32_t a = k0, d = k1;
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, a), n2 = xor3((uint32_t)(p0 >> 32), c3, d);
+            c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+            a += 0x9E3779B9u; d += 0xBB67AE85u;
+        }
+        w0 = c0; w1 = c1; w2 = c2; w3 = c3;
+        held = blk;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t b = pos >> 2;
+        if (__builtin_expect(b != held, 0)) gen(b);
+        const uint32_t q = pos & 3u;
+        pos++;
+        const uint32_t lo = (q & 1u) ? w1 : w0, hi = (q & 1u) ? w3 : w2;
+        return (q & 2u) ? hi : lo;
+    }
+    __device__ __forceinline__ uint32_t bounded(uint32_t m) { return __umulhi(next(), m); }
+    // draw number k (compile-time) of the reset: no block check, no select
+    __device__ __forceinline__ uint32_t bounded_at(uint32_t m, int k) {
+        if ((k & 3) == 0) gen((uint32_t)(k >> 2));
+        pos = (uint32_t)k + 1u;
+        const uint32_t w = (k & 3) == 0 ? w0 : (k & 3) == 1 ? w1 : (k & 3) == 2 ? w2 : w3;
+        return __umulhi(w, m);
+    }
+    __device__ __forceinline__ void align() {}
+};
+
 // Caller-supplied raw words consumed with numpy-legacy semantics (masked rejection, nothing drawn for a
 // one-element range): fed numpy's MT19937 output the decisions equal the reference's.
 struct TapeRng {
@@ -385,8 +434,11 @@ __device__ __forceinline__ float lds_reward_lookup(uint32_t byte_index) { return
 // The byte-parallel rollouts (susnet_swar.h GroupWords) stage the action-stream words of one GROUP of ticks behind the tables:
 // at most 12 words x 64 environments (cfg4: 3 words per tick, 4 ticks; with two lanes per environment 24 words x 32)
 constexpr uint32_t kGroupWords = 768;
-__host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic, bool group_words = false) {
-    return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u) + (group_words ? kGroupWords : 0u);
+// ... and, in the fused rollouts of those kernels, the per-environment cell -> job map behind the group words (susnet_swar.h JobMap:
+// one 64-byte row per cell value x | y << 4 of an N x N grid)
+__host__ __device__ inline uint32_t lds_jobmap_words(int N) { return ((uint32_t)(((N - 1) << 4) | (N - 1)) + 1u) * 16u; }
+__host__ __device__ inline uint32_t lds_core_words(int A, int J, bool generic, bool group_words = false, int jobmap_N = 0) {
+    return kTableWords + (generic ? (uint32_t)(2 * A + J) * kBlock : 0u) + (group_words ? kGroupWords : 0u) + (jobmap_N > 0 ? lds_jobmap_words(jobmap_N) : 0u);
 }
 
 // first LDS word of the group-words area (carve_lds: behind the tables; compiled-in configurations have no store columns)
@@ -488,7 +540,8 @@ struct TableLoad {
 // smem: the table image -- at LDS address 0 of the workgroup (lds_table_addr: the byte-parallel kernels read it through absolute
 // addresses); rest: the wave's own region behind it (k_step / the rollouts: smem + kTableWords; the one-kernel policy tick keeps ONE
 // table image for its four waves and gives each wave a region of its own further up)
-template <class S>
+// JOBMAP: the kernel keeps the cell -> job map behind the group words (fused rollouts of the byte-parallel configurations)
+template <class S, bool JOBMAP = false>
 __device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, uint32_t *rest, int tid, typename StoreFor<S>::type &st) {
     Tables T;
     T.grid = smem;
@@ -499,22 +552,23 @@ __device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, uin
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
     if (HasGroupWords<S>::value) rest += kGroupWords;
+    if (JOBMAP) rest += lds_jobmap_words(c.N);
     T.perm = reinterpret_cast<uint8_t *>(rest);
     T.stage = rest;
     return T;
 }
-template <class S>
+template <class S, bool JOBMAP = false>
 __device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
-    return carve_lds<S>(c, smem, smem + kTableWords, tid, st);
+    return carve_lds<S, JOBMAP>(c, smem, smem + kTableWords, tid, st);
 }
 __device__ __forceinline__ void wave_lds_publish() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <class S, bool STEP_TABLES = true>
+template <class S, bool STEP_TABLES = true, bool JOBMAP = false>
 __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int tid, typename StoreFor<S>::type &st) {
-    Tables T = carve_lds<S>(c, smem, tid, st);
+    Tables T = carve_lds<S, JOBMAP>(c, smem, tid, st);
     TableLoad<STEP_TABLES> tl;
     tl.issue(c, nullptr, tid);
     tl.commit(smem, tid, false);
@@ -526,6 +580,7 @@ __device__ __forceinline__ Tables setup_lds(const Consts &c, uint32_t *smem, int
 struct Env {
     uint32_t alive, imp, used, jd; // bitmasks over agents / jobs
     uint32_t t, timer, flags;
+    uint32_t ep;                   // resets drawn so far (index of the next one in the RESET stream)
     uint32_t m_steps, m_fix, m_sab, m_kv;
 };
 
@@ -547,6 +602,7 @@ __device__ __forceinline__ void load_env(const Consts &c, const State &s, Store 
     e.t = s.t[b];
     e.timer = s.timer[b];
     e.flags = s.flags[b];
+    e.ep = s.ep[b];
     e.m_steps = s.m_steps[b];
     e.m_fix = s.m_fix[b];
     e.m_sab = s.m_sab[b];
@@ -569,6 +625,7 @@ __device__ __forceinline__ void store_env(const Consts &c, const State &s, const
     s.t[b] = (uint16_t)e.t;
     s.timer[b] = (uint16_t)e.timer;
     s.flags[b] = (uint8_t)e.flags;
+    s.ep[b] = e.ep;
     s.m_steps[b] = e.m_steps;
     s.m_fix[b] = e.m_fix;
     s.m_sab[b] = e.m_sab;
@@ -636,7 +693,7 @@ __device__ __forceinline__ int role_action(const Consts &c, uint32_t is_imp, uin
 // loop from the first job draw only in a lane that sees a duplicate cell; colliding picks -> false, nothing the caller keeps has
 // been touched but the cursor (the caller rewinds and takes the draw-by-draw path).
 template <class S, int NPICK, class Store>
-__device__ __forceinline__ bool place_static(const Consts &c, const Tables &T, Store &st, Env &e, PhiloxRng &rng) {
+__device__ __forceinline__ bool place_static(const Consts &c, const Tables &T, Store &st, Env &e, ResetStream &rng) {
     constexpr int AA = S::kA, JJ = S::kJ;
     if (NPICK > 0) {
         uint32_t imp = 0;
@@ -653,7 +710,7 @@ __device__ __forceinline__ bool place_static(const Consts &c, const Tables &T, S
     uint32_t ai[AA], ji[JJ > 0 ? JJ : 1], ac[AA], jc[JJ > 0 ? JJ : 1];
 #pragma unroll
     for (int i = 0; i < AA; i++) ai[i] = rng.bounded_at((uint32_t)c.n_valid, NPICK + i);
-    const uint64_t cur0 = rng.cur;
+    const uint32_t pos0 = rng.pos;
 #pragma unroll
     for (int j = 0; j < JJ; j++) ji[j] = rng.bounded_at((uint32_t)c.n_valid, NPICK + AA + j);
 #pragma unroll
@@ -671,7 +728,8 @@ __device__ __forceinline__ bool place_static(const Consts &c, const Tables &T, S
 #pragma unroll
         for (int j = 0; j < JJ; j++) st.set_job(j, jc[j]);
     } else {
-        rng.cur = cur0;
+        rng.pos = pos0; // (the draw-by-draw walk re-generates its blocks by position)
+        rng.held = ~0u;
 #pragma unroll
         for (int j = 0; j < JJ; j++) {
             uint32_t xy;
@@ -688,12 +746,11 @@ __device__ __forceinline__ bool place_static(const Consts &c, const Tables &T, S
     return true;
 }
 
+// rng: the reset's word source -- ResetStream (production protocol: this reset's own words, position 0 onwards) or TapeRng
 template <class S, class RNG, class Store>
-__device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Store &st, int tid, Env &e, RNG &rng) {
+__device__ __forceinline__ void reset_draws(const Consts &c, const Tables &T, Store &st, int tid, Env &e, RNG &rng) {
     const int A = S::A(c), J = S::J(c);
-    rng.align();
     if constexpr (!RNG::kNumpy && !S::kGeneric && S::kJ >= 0 && S::kNI >= 1) {
-        const uint64_t run0 = rng.cur;
         bool placed;
         if (S::shuffle_imp(c)) {
             placed = place_static<S, S::kNI>(c, T, st, e, rng);
@@ -709,7 +766,8 @@ __device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Stor
             e.t = 0;                  // base.py:315
             return;
         }
-        rng.cur = run0; // two imposter picks collided: draw by draw, below
+        rng.pos = 0; // two imposter picks collided: draw by draw, below
+        rng.held = ~0u;
     }
     if (S::shuffle_imp(c)) {
         if (RNG::kNumpy) {
@@ -766,6 +824,20 @@ __device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Stor
     e.used = 0;               // tagging.py:64-66 (counts cleared with xy above)
     e.timer = 0;
     e.t = 0;                  // base.py:315
+}
+
+// reset (base.py:251-324).  Production protocol: the draws of the env's reset number e.ep of the RESET stream; the event cursor
+// (rng.cur: the kill draws) is not touched.  Numpy tapes: the env's own words, in numpy's order.
+template <class S, class RNG, class Store>
+__device__ __forceinline__ void reset_env(const Consts &c, const Tables &T, Store &st, int tid, Env &e, RNG &rng) {
+    if constexpr (RNG::kNumpy) {
+        reset_draws<S>(c, T, st, tid, e, rng);
+    } else {
+        ResetStream rs;
+        rs.init(rng, e.ep);
+        reset_draws<S>(c, T, st, tid, e, rs);
+        e.ep += 1u;
+    }
 }
 
 __device__ __forceinline__ void zero_metrics(Env &e) {

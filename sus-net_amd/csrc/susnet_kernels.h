@@ -635,13 +635,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     const bool active = tid < c.epw && b < c.B;
     const int nrows = (int)((c.B - b0) < c.epw ? (c.B - b0) : c.epw);
     typename StoreFor<S>::type st;
-    Tables T = setup_lds<S>(c, smem, tid, st);
+    Tables T = setup_lds<S, true, true>(c, smem, tid, st);
     if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
     if (!RNG::kNumpy && RankLut<S>::kOk) build_rank_lut<S>(smem, tid);
+    JobMap::clear_all(kJobMapWord, c.N, tid); // the cell -> job map (susnet_swar.h): zeroed once, then kept by the lanes that own the columns
     wave_lds_fence();
+    JobMap jm;
+    jm.init(kJobMapWord, tid);
     Env e = {};
     RNG rng = make_rng<RNG>(c, s, active ? b : 0);
-    if (active) load_env<S>(c, s, st, b, e);
+    if (active) {
+        load_env<S>(c, s, st, b, e);
+        jm.set_jobs(st, S::J(c));
+    }
     constexpr bool kFlat = OUT == OUT_TRAJ_FLAT; // (cooperative feature stores: every lane stays)
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ || kFlat;
     if (((kTraj && !kFlat) || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
@@ -756,10 +762,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             else if (OUT == OUT_ANY && pa != nullptr) store_packed_bytes<A>(PtrDst{pa}, act);
             float rr[A];
             bool done, trunc;
+            // (the win rules run unconditionally at the launch's first tick only: the state may come from outside; see step_swar)
 #ifdef SUSNET_STAMPS
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2, stage_b);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2, stage_b, jm, tick == 0);
 #else
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, nullptr, stage_b);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, nullptr, stage_b, jm, tick == 0);
 #endif
             KSTAMP(1);
             if (kTraj) {
@@ -780,7 +787,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                     raw_row_swar<S>(w, trow, (uint32_t)c.tag_interval);
                     store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
                 }
+                jm.clear_jobs(st, S::J(c)); // the finished episode's job cells leave the map, the new ones enter
                 reset_env<S>(c, T, st, tid, e, rng);
+                jm.set_jobs(st, S::J(c));
                 to_swar<S>(c, st, e, w);
                 // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
                 // continue what the action draws (role-dependent ranges) left of their last word
@@ -879,13 +888,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     const int64_t b0 = (int64_t)wave_id * 32, b = b0 + (tid & 31);
     const bool active = b < c.B;
     typename StoreFor<S>::type st;
-    Tables T = setup_lds<S>(c, smem, tid, st);
+    Tables T = setup_lds<S, true, true>(c, smem, tid, st);
     if (RankLut<S>::kOk) build_rank_lut<S>(smem, tid);
+    JobMap::clear_all(kJobMapWord, c.N, tid); // the cell -> job map (susnet_swar.h): one column per environment, shared by its two lanes
     wave_lds_fence();
+    JobMap jm;
+    jm.init(kJobMapWord, tid & 31);
     Env e = {};
     RNG rng = make_rng<RNG>(c, s, active ? b : 0);
     if (!active) return; // both lanes of a pair leave together: every exchange below is between two active lanes
     load_env<S>(c, s, st, b, e);
+    jm.set_jobs(st, S::J(c)); // (both lanes of the pair write the same bytes)
     W w;
     to_swar2<S>(c, st, e, h, w);
     uint64_t tick_base = a.tick_base;
@@ -977,8 +990,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
         }
         float rr[4];
         bool done, trunc;
-        if constexpr (RNG::kNumpy) step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc);
-        else step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, stage_b);
+        if constexpr (RNG::kNumpy) step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0);
+        else step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0, stage_b);
         // (the rewards come out of LDS lookups issued at the very end of the step: they are stored LAST, behind everything else
         // the tick writes, so that nothing waits for them)
         if (kTraj) {
@@ -999,7 +1012,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
                 raw_row_swar<S>(f, trow);
                 if (h == 0u) store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
             }
+            jm.clear_jobs(st, S::J(c)); // the finished episode's job cells leave the map, the new ones enter
             reset_env<S>(c, T, st, tid, e, rng);
+            jm.set_jobs(st, S::J(c));
             to_swar2<S>(c, st, e, h, w);
             // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
             // continue what the action draws (role-dependent ranges) left of their last word

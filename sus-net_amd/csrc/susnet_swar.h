@@ -44,6 +44,50 @@ __device__ __forceinline__ uint32_t zero80(uint32_t x) {
 // bytes of a where the 0xff mask m is set, else bytes of b
 __device__ __forceinline__ uint32_t sel_bytes(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
+// ---- the per-environment cell -> job map of the fused rollouts -------------------------------------------------------------------
+// _get_job_at_pos (base.py:544-546) asks "which job, if any, lies on this cell".  Job cells are constant within an episode, so the
+// fused rollouts keep the answer in LDS, [cell][environment column] bytes: 0 = no job, 0x80 | j = job j.  Written at launch and by the
+// in-launch reset (the old cells cleared, the new ones set: the only writers), read once per agent and tick -- one ds_read_u8
+// instead of one byte-compare chain per job and word (that chain was a quarter of cfg3's vector instructions), and the job count
+// drops out of the step altogether.  The one-step kernels keep the chain (NoJobMap): a launch per step would have to zero the map
+// first, and they are latency-bound anyway.
+constexpr uint32_t kJobMapColumns = 64; // bytes per row: one per lane (kernels with two lanes per environment use the first 32)
+static_assert(kJobMapColumns == kBlock, "lds_jobmap_words (susnet_device.h) reserves 64-byte rows");
+// first LDS word of the map: behind the tables and the group words (carve_lds<S, true>)
+constexpr uint32_t kJobMapWord = kTableWords + kGroupWords;
+struct NoJobMap {
+    static constexpr bool kOn = false;
+};
+struct JobMap {
+    static constexpr bool kOn = true;
+    typedef __attribute__((address_space(3))) uint8_t *lds_u8_wptr;
+    uint32_t col; // LDS byte address of my environment's column in row 0
+    __device__ __forceinline__ void init(uint32_t first_word, int column) { col = lds_table_addr(first_word) + (uint32_t)column; }
+    __device__ __forceinline__ uint32_t at(uint32_t cell) const { return *(lds_u8_ptr)(uintptr_t)(col + cell * kJobMapColumns); }
+    __device__ __forceinline__ void put(uint32_t cell, uint32_t v) const { *(lds_u8_wptr)(uintptr_t)(col + cell * kJobMapColumns) = (uint8_t)v; }
+    // all 64 lanes: zero the whole map (once per launch)
+    static __device__ __forceinline__ void clear_all(uint32_t first_word, int N, int tid) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) u32x4 *lds_u4_wptr;
+        const uint32_t n16 = lds_jobmap_words(N) / 4u; // (rows * 64 bytes: a multiple of 16)
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (uint32_t k = (uint32_t)tid; k < n16; k += kBlock) *(lds_u4_wptr)(uintptr_t)(lds_table_addr(first_word) + 16u * k) = zero;
+    }
+    // the job cells of the store: set (0x80 | j) / cleared; n_jobs may be a run-time count
+    template <class Store>
+    __device__ __forceinline__ void set_jobs(const Store &st, int n_jobs) const {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < n_jobs) put(st.job(j), 0x80u | (uint32_t)j);
+    }
+    template <class Store>
+    __device__ __forceinline__ void clear_jobs(const Store &st, int n_jobs) const {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < n_jobs) put(st.job(j), 0u);
+    }
+};
+
 // ---- the action stream of a fused rollout, one GROUP of ticks at a time -------------------------------------------------------
 // A tick owns W consecutive words of the action stream (susnet_device.h AwLayout), a Philox block has four: a group of G ticks
 // (4; 8 with two lanes per environment) covers whole blocks.  At the first tick of a group the wave generates the group's blocks
@@ -360,10 +404,15 @@ struct NoMid {
 };
 // mid(): called between the kill section and the job section -- the fused rollouts put the next tick's sampling there (its
 // multiplies and table reads fill the waits of this tick's own lookups)
-template <class S, class RNG, class MID = NoMid>
+// jm: the fused rollouts' cell -> job map (JobMap), or NoJobMap = match the job cells by compare chain (one-step kernels).
+// check_win = false: the caller guarantees that the state it hands over is not a won one (every tick of a fused rollout but its
+// first: the previous tick's check covered it, or a reset replaced it) -- the win rules then run only behind a ballot on "something
+// they read changed this step" (a kill landed, a job flipped, a vote ejected somebody), or always where a game is won without
+// any of that (FourRoomEnv with no jobs, base.py:430).
+template <class S, class RNG, class MID = NoMid, class JM = NoJobMap>
 __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar<S> &w, Env &e, RNG &rng, const uint32_t (&act)[Swar<S>::NW],
                                           const uint32_t (&R)[Swar<S>::NW], float (&rr)[Swar<S>::A], bool &done, bool &trunc,
-                                          unsigned long long *sg = nullptr, MID &&mid = MID()) {
+                                          unsigned long long *sg = nullptr, MID &&mid = MID(), const JM &jm = JM(), bool check_win = true) {
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycles of the step's sections, one wave
     unsigned long long sprev = __builtin_readcyclecounter();
 #define WSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); if (sg) sg[k] += tn - sprev; sprev = tn; } while (0)
@@ -420,6 +469,20 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 #pragma unroll
         for (int i = 0; i < A; i++) dest[i / 4] |= d[i] << (8 * (i & 3));
     }
+    // ... and, with the cell -> job map, the job under every agent (0x80 | j, or 0): job actors do not move, so the cell an agent
+    // stands on NOW is the one its FIX / SABOTAGE would act on; issued here, used after the kill section
+    uint32_t jobat[NW];
+#pragma unroll
+    for (int q = 0; q < NW; q++) jobat[q] = 0;
+    if constexpr (JM::kOn) {
+        if (W::kBase) {
+            uint32_t mj[A];
+#pragma unroll
+            for (int i = 0; i < A; i++) mj[i] = jm.at((w.xy[i / 4] >> (8 * (i & 3))) & 0xffu);
+#pragma unroll
+            for (int i = 0; i < A; i++) jobat[i / 4] |= mj[i] << (8 * (i & 3));
+        }
+    }
     // positions if every living mover moved (kills below may cancel a victim's move)
     uint32_t newt[NW];
 #pragma unroll
@@ -463,6 +526,9 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                     cand[q] = attempt ? (zero80(pos ^ cbb) & crew80) : 0u;
                     nc += (uint32_t)__popc(cand[q]);
                 }
+                // Nearly every tick some lane ATTEMPTS a kill, but a crew member on the killer's cell is rare (a fraction of a
+                // percent per environment): everything below the candidate search sits behind a second ballot.
+                if (__builtin_amdgcn_ballot_w64(nc != 0u) == 0ull) continue;
                 // base.py:497: uniform among the candidates (ascending agent index).  With one candidate -- nearly always --
                 // the victim is the lowest set flag; several candidates (rare) are handled behind a wave-uniform branch.
                 uint32_t v80[NW];
@@ -512,7 +578,82 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     uint32_t fc80[NW], sc80[NW];
 #pragma unroll
     for (int q = 0; q < NW; q++) fc80[q] = sc80[q] = 0;
-    if (W::kBase && J > 0) {
+    if constexpr (JM::kOn) {
+        // With the cell -> job map (fused rollouts): jobat = 0x80 | j under every agent that stands on a job.  An actor standing on
+        // a job is rare (a percent or two per environment), so all that follows the flag test sits behind a ballot; the job count
+        // appears nowhere.
+        if (W::kBase) {
+            constexpr int JW = W::JW;
+            uint32_t hj80[NW], anyj = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                hj80[q] = jobat[q] & (fix80[q] | sab80[q]) & ~pend80[q]; // (flag bits only) a living job actor, not killed before its turn, on a job
+                anyj |= hj80[q];
+            }
+            if (__builtin_amdgcn_ballot_w64(anyj != 0u) != 0ull) {
+                const uint32_t jhi = JW > 1 ? JW - 1 : 0;
+                uint32_t sel[NW], oh[NW], succ[NW];
+                uint32_t abits = 0, nactors = 0;
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    sel[q] = jobat[q] & 0x07070707u; // the job's index: a v_perm selector into the status bytes / a one-hot table
+                    const uint32_t dj80 = __builtin_amdgcn_perm(JW > 1 ? w.jd[jhi] : 0u, w.jd[0], sel[q]) << 7; // completed? (0x80 / 0)
+                    succ[q] = hj80[q] & ~(w.im80[q] ^ dj80); // crew (flag 0) on an open job, imposter (0x80) on a completed one
+                    oh[q] = __builtin_amdgcn_perm(0x80402010u, 0x08040201u, sel[q]); // 1 << j per agent byte
+                    const uint32_t t = hj80[q] - (hj80[q] >> 7);
+                    const uint32_t mine = oh[q] & (t | hj80[q]); // (0x80 flag -> 0xff mask) the actors' one-hots
+                    abits = __builtin_amdgcn_sad_u8(mine, 0u, abits); // sum over the bytes: jobs with an actor -- a bit set per job ...
+                    nactors += (uint32_t)__popc(hj80[q]);
+                }
+                // ... unless two actors share a job: the sum of n powers of two has n bits set exactly when they are distinct
+                const bool crowd = (uint32_t)__popc(abits) != nactors;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(crowd) != 0ull, 0)) {
+                    // two agents work on the SAME job in one env of this wave: the actors in turn order (base.py:377-382).  Jobs are
+                    // independent of each other (distinct cells, base.py:295-299), so the turns are the outer, ROLLED loop: rare code
+                    // (written as integer arithmetic on 0 / 1 values, not as booleans: a boolean per job and word lives in a scalar
+                    // register pair, and this rare block alone spilled two dozen of them)
+                    uint32_t jbits = 0; // job status as a bit mask
+#pragma unroll
+                    for (int j = 0; j < 4 * JW; j++) jbits |= ((w.jd[j / 4] >> (8 * (j & 3))) & 1u) << j;
+#pragma clang loop unroll(disable)
+                    for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
+                        const uint32_t tb = (turn | 0x80u) * k01;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) {
+                            const uint32_t me = zero80(R[q] ^ tb) & hj80[q]; // the agent whose turn it is, if it works on a job (one byte at most)
+                            const uint32_t myjob = __builtin_amdgcn_sad_u8(sel[q] & ff_from80(me), 0u, 0u);
+                            const uint32_t actor = __builtin_amdgcn_sad_u8(me >> 7, 0u, 0u), imp = __builtin_amdgcn_sad_u8((me & w.im80[q]) >> 7, 0u, 0u);
+                            const uint32_t status = (jbits >> myjob) & 1u;
+                            const uint32_t ok = actor & ~(imp ^ status); // crew (0) on an open job (0), imposter (1) on a completed one (1)
+                            jbits ^= ok << myjob;
+                            const uint32_t f = ok & ~imp, sb = ok & imp;
+                            e.m_fix += f;
+                            e.m_sab += sb;
+                            fc80[q] |= me & (0u - f);
+                            sc80[q] |= me & (0u - sb);
+                        }
+                    }
+                    w.jd[0] = ((jbits & 15u) * 0x00204081u) & k01; // bits -> 0x01 per job byte (see below)
+                    if (JW > 1) w.jd[jhi] = ((jbits >> 4) * 0x00204081u) & k01;
+                } else {
+                    uint32_t tbits = 0;
+#pragma unroll
+                    for (int q = 0; q < NW; q++) {
+                        const uint32_t t = succ[q] - (succ[q] >> 7);
+                        tbits = __builtin_amdgcn_sad_u8(oh[q] & (t | succ[q]), 0u, tbits); // jobs that flip
+                        fc80[q] = succ[q] & ~w.im80[q];
+                        sc80[q] = succ[q] & w.im80[q];
+                        e.m_fix += (uint32_t)__popc(fc80[q]);
+                        e.m_sab += (uint32_t)__popc(sc80[q]);
+                    }
+                    // bits -> 0x01 per job byte: b * (1 + 2^7 + 2^14 + 2^21) puts bit k of a 4-bit b at bit 8k (the four shifted copies
+                    // occupy disjoint bit ranges: no carries)
+                    w.jd[0] ^= ((tbits & 15u) * 0x00204081u) & k01;
+                    if (JW > 1) w.jd[jhi] ^= ((tbits >> 4) * 0x00204081u) & k01;
+                }
+            }
+        }
+    } else if (W::kBase && J > 0) {
         constexpr int JW = W::JW;
         uint32_t ja80[NW], on[J][NW], acted[NW], tog[JW];
 #pragma unroll
@@ -585,6 +726,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     WSTAMP(2);
     // ---- tag actions (tagging.py:103-110) and the vote (tagging.py:180-207) ------------------------------------------------------
     float team = 0.0f; // team reward: vote outcome, then the win reward (tagging.py:196, 209-213)
+    bool voted_out = false; // the vote ejected somebody this step
     if (W::kTag) {
         const uint32_t hi = NW > 1 ? NW - 1 : 0;
         uint32_t tgt[NW], vt80[NW];
@@ -621,8 +763,18 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             w.cnt[0] = (uint32_t)cn;
             if (NW > 1) w.cnt[hi] = (uint32_t)(cn >> 32);
         }
+        // tagging.py:180: tag_counts *= alive_agents.  A count only ever grows on a LIVING target (tagging.py:105), so the product
+        // changes something exactly when this step killed somebody (a vote's ejection is followed by the reset of all counts) --
+        // or when the state came from outside (check_win: the first tick of a launch)
+        {
+            uint32_t killed = 0;
 #pragma unroll
-        for (int q = 0; q < NW; q++) w.cnt[q] &= ff_from80((w.al[q] << 7) & k80); // tagging.py:180: tag_counts *= alive_agents
+            for (int q = 0; q < NW; q++) killed |= kc80[q];
+            if (__builtin_amdgcn_ballot_w64(check_win || killed != 0u) != 0ull) {
+#pragma unroll
+                for (int q = 0; q < NW; q++) w.cnt[q] &= ff_from80((w.al[q] << 7) & k80);
+            }
+        }
         w.timer += 1u;                                                               // tagging.py:182
         const bool due = w.timer >= (uint32_t)c.tag_interval;
         if (__builtin_amdgcn_ballot_w64(due) != 0ull) { // tagging.py:184-207
@@ -638,6 +790,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 #pragma unroll
             for (int q = 0; q < NW; q++) alive_sum += (uint32_t)__popc(w.al[q] & kLive[q] & k01);
             const bool out = due && highest >= ((alive_sum + 1u) >> 1);
+            voted_out = out;
             const uint64_t hot = (uint64_t)(out ? 1u : 0u) << (8u * best);
             const uint64_t im = (uint64_t)w.im80[0] | ((uint64_t)(NW > 1 ? w.im80[hi] : 0u) << 32);
             const bool vimp = ((im >> (8u * best + 7u)) & 1ull) != 0ull;
@@ -657,8 +810,16 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 
     WSTAMP(3);
     // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
-    uint32_t wsel; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
-    {
+    uint32_t wsel = 0u; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
+    done = false;
+    bool win_inputs_changed = check_win || (W::kBase && J == 0); // (J == 0: FourRoomEnv's "all jobs done" holds at every step, base.py:430)
+    if (!win_inputs_changed) { // alive flags / job status moved this step?
+        uint32_t ev = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) ev |= kc80[q] | fc80[q] | sc80[q];
+        win_inputs_changed = ev != 0u || voted_out;
+    }
+    if (__builtin_amdgcn_ballot_w64(win_inputs_changed) != 0ull) {
         int alive_imp = 0, alive_all = 0;
 #pragma unroll
         for (int q = 0; q < NW; q++) {

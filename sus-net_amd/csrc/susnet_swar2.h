@@ -110,9 +110,11 @@ __device__ __forceinline__ void gather_swar2(const Swar2<S> &w, Swar<S> &f) {
 }
 
 // One step; act / R: MY word of the action bytes and of the turn ranks.  rr: the rewards of my four agents.
+// jm: the environment's column of the cell -> job map (susnet_swar.h JobMap; both lanes of a pair read the same column);
+// check_win: see step_swar.
 template <class S, class RNG, class MID = NoMid>
 __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e, RNG &rng, uint32_t act, uint32_t R, float (&rr)[4], bool &done,
-                                           bool &trunc, MID &&mid = MID()) {
+                                           bool &trunc, const JobMap &jm, bool check_win, MID &&mid = MID()) {
     using W = Swar2<S>;
     constexpr int A = W::A, J = W::J, NI = W::NI;
     const uint32_t h = w.h;
@@ -146,9 +148,18 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
         dest = d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24);
     }
     const uint32_t newt = sel_bytes(ff_from80(mv80), dest, w.xy); // positions if every living mover moved
+    // the job under each of my agents (0x80 | j, or 0): job actors do not move; issued here, used after the kill section
+    uint32_t jobat = 0;
+    if (W::kBase) {
+        uint32_t mj[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) mj[i] = jm.at((w.xy >> (8 * i)) & 0xffu);
+        jobat = mj[0] | (mj[1] << 8) | (mj[2] << 16) | (mj[3] << 24);
+    }
 
     // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
     uint32_t kc80 = 0, pend80 = 0;
+    bool changed = check_win; // something the win rules read moved this step (the same in both lanes of a pair)
     {
         const Pair pk = both_halves(kill80), pr = both_halves(R), px = both_halves(w.xy);
         uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot: kill flag (0x80 / 0), rank | 0x80, cell
@@ -173,6 +184,8 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
                 const uint32_t cand = attempt ? (zero80(pos ^ cbb) & crew80) : 0u;
                 const Pair pc = both_halves(cand);
                 const uint32_t nc = (uint32_t)__popc(pc.lo) + (uint32_t)__popc(pc.hi);
+                // (a crew member on the killer's cell is rare: the rest sits behind a second ballot)
+                if (__builtin_amdgcn_ballot_w64(nc != 0u) == 0ull) continue;
                 // base.py:497: uniform among the candidates (ascending agent index); with one candidate the lowest set flag
                 uint32_t v0 = pc.lo & (0u - pc.lo), v1 = pc.lo != 0u ? 0u : (pc.hi & (0u - pc.hi));
                 const uint64_t word_pos = rng.cur; // production protocol: one word per landed kill
@@ -193,6 +206,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
                 }
                 const uint32_t v80 = h ? v1 : v0;
                 const bool hit = nc != 0u;
+                changed |= hit;
                 e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
                 w.al &= ~(v80 >> 7);     // base.py:511
                 const uint32_t hot = second_first ? w.ihot[s1] : w.ihot[s0];
@@ -204,73 +218,76 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     w.xy = sel_bytes(ff_from80(pend80), w.xy, newt); // a victim that had not acted yet stays where it was
     mid(); // (the fused rollout samples the next tick here: see step_swar)
 
-    // ---- FIX (base.py:518-524) / SABOTAGE (527-533), in agent space (see susnet_swar.h) ----------------------------------------
+    // ---- FIX (base.py:518-524) / SABOTAGE (527-533) through the cell -> job map (see susnet_swar.h) ------------------------------
     uint32_t fc80 = 0, sc80 = 0;
-    if (W::kBase && J > 0) {
-        const uint32_t ja80 = (fix80 | sab80) & ~pend80;
-        uint32_t on[J], acted = 0, tog = 0, cntb = 0;
+    if (W::kBase) {
+        static_assert(J <= 4, "one word of job status bytes");
+        const uint32_t hj80 = jobat & (fix80 | sab80) & ~pend80; // (flag bits only) a living job actor, not killed before its turn, on a job
+        if (__builtin_amdgcn_ballot_w64(hj80 != 0u) != 0ull) {
+            const uint32_t sel = jobat & 0x03030303u;                                  // the job's index
+            const uint32_t dj80 = __builtin_amdgcn_perm(0u, w.jd, sel) << 7;          // completed? (0x80 / 0)
+            const uint32_t succ = hj80 & ~(w.im80 ^ dj80);                             // crew on an open job, imposter on a completed one
+            const uint32_t oh = __builtin_amdgcn_perm(0u, 0x08040201u, sel);          // 1 << j per agent byte
+            // per lane: sum of the actors' one-hots | sum of the succeeding actors' << 8 | number of actors << 16; the pair's sums
+            // follow from ONE exchange (every field stays below its 8 bits: at most 8 actors on jobs 0 .. 3)
+            const uint32_t ta = hj80 - (hj80 >> 7), ts = succ - (succ >> 7);
+            const uint32_t mine = __builtin_amdgcn_sad_u8(oh & (ta | hj80), 0u, 0u) | (__builtin_amdgcn_sad_u8(oh & (ts | succ), 0u, 0u) << 8) |
+                                  ((uint32_t)__popc(hj80) << 16);
+            const Pair pm = both_halves(mine);
+            const uint32_t both = pm.lo + pm.hi;
+            const uint32_t abits = both & 0xffu, sbits = (both >> 8) & 0xffu, nactors = both >> 16;
+            // two actors share a job <=> the sum of their one-hots has fewer bits set than there are actors
+            const bool crowd = (uint32_t)__popc(abits) != nactors;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(crowd) != 0ull, 0)) {
+                // two agents work on the SAME job in one env of this wave: the actors in turn order over BOTH words (base.py:377-382);
+                // jobs are independent of each other, so the turns are the outer, ROLLED loop (rare code, kept small)
+                const Pair pr = both_halves(R), pi = both_halves(w.im80), ph = both_halves(hj80), ps = both_halves(sel);
+                const uint32_t R2[2] = {pr.lo, pr.hi}, im2[2] = {pi.lo, pi.hi}, hj2[2] = {ph.lo, ph.hi}, sel2[2] = {ps.lo, ps.hi};
+                uint32_t f2[2] = {0, 0}, s2[2] = {0, 0};
+                // (integer arithmetic on 0 / 1 values, not booleans: see step_swar)
+                uint32_t jbits = 0; // job status as a bit mask
 #pragma unroll
-        for (int j = 0; j < J; j++) {
-            const uint32_t dj80 = (0u - ((w.jd >> (8 * j)) & 1u)) & k80;
-            on[j] = zero80(w.xy ^ w.jb[j]) & ja80;
-            cntb |= (uint32_t)__popc(on[j]) << (8 * j);
-            const uint32_t succ = on[j] & ~(w.im80 ^ dj80);
-            acted |= succ;
-            tog |= (uint32_t)__popc(succ) << (8 * j);
-        }
-        // the environment's toggles (0x01 per job: at most one of the two lanes holds the actor) and, per job, the actors of both words
-        const Pair pt = both_halves(tog), pn = both_halves(cntb);
-        const uint32_t tog_env = pt.lo | pt.hi;
-        const uint32_t crowd = ((pn.lo + pn.hi) + 0x7e7e7e7eu) & k80; // some job with two or more actors
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(crowd != 0u) != 0ull, 0)) {
-            // two agents work on the SAME job in one env of this wave: the actors in turn order over BOTH words (base.py:377-382);
-            // jobs are independent of each other, so the turns are the outer, ROLLED loop (rare code, kept small)
-            const Pair pr = both_halves(R), pm = both_halves(w.im80);
-            const uint32_t R2[2] = {pr.lo, pr.hi}, im2[2] = {pm.lo, pm.hi};
-            uint32_t f2[2] = {0, 0}, s2[2] = {0, 0}, on2[J][2], dj[J];
-#pragma unroll
-            for (int j = 0; j < J; j++) {
-                const Pair po = both_halves(on[j]);
-                on2[j][0] = po.lo;
-                on2[j][1] = po.hi;
-                dj[j] = (w.jd >> (8 * j)) & 1u;
-            }
+                for (int j = 0; j < 4; j++) jbits |= ((w.jd >> (8 * j)) & 1u) << j;
 #pragma clang loop unroll(disable)
-            for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
-                const uint32_t tb = (turn | 0x80u) * k01;
+                for (uint32_t turn = 0; turn < (uint32_t)A; turn++) {
+                    const uint32_t tb = (turn | 0x80u) * k01;
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const uint32_t mine = zero80(R2[q] ^ tb); // the agent whose turn it is
-#pragma unroll
-                    for (int j = 0; j < J; j++) {
-                        const uint32_t me = mine & on2[j][q];
-                        const bool is_sab = (me & im2[q]) != 0u, is_fix = (me & ~im2[q]) != 0u;
-                        const bool f = is_fix && dj[j] == 0u, sb = is_sab && dj[j] != 0u;
-                        dj[j] = f ? 1u : (sb ? 0u : dj[j]);
-                        e.m_fix += f ? 1u : 0u;
-                        e.m_sab += sb ? 1u : 0u;
-                        f2[q] |= f ? me : 0u;
-                        s2[q] |= sb ? me : 0u;
+                    for (int q = 0; q < 2; q++) {
+                        const uint32_t me = zero80(R2[q] ^ tb) & hj2[q]; // the agent whose turn it is, if it works on a job (one byte at most)
+                        const uint32_t myjob = __builtin_amdgcn_sad_u8(sel2[q] & ff_from80(me), 0u, 0u);
+                        const uint32_t actor = __builtin_amdgcn_sad_u8(me >> 7, 0u, 0u), imp = __builtin_amdgcn_sad_u8((me & im2[q]) >> 7, 0u, 0u);
+                        const uint32_t status = (jbits >> myjob) & 1u;
+                        const uint32_t ok = actor & ~(imp ^ status); // crew (0) on an open job (0), imposter (1) on a completed one (1)
+                        jbits ^= ok << myjob;
+                        const uint32_t f = ok & ~imp, sb = ok & imp;
+                        e.m_fix += f;
+                        e.m_sab += sb;
+                        f2[q] |= me & (0u - f);
+                        s2[q] |= me & (0u - sb);
                     }
                 }
+                w.jd = (jbits * 0x00204081u) & k01; // bits -> 0x01 per job byte
+                fc80 = h ? f2[1] : f2[0];
+                sc80 = h ? s2[1] : s2[0];
+                changed |= (f2[0] | f2[1] | s2[0] | s2[1]) != 0u;
+            } else {
+                // bits -> 0x01 per job byte (see step_swar); without a crowd every job has at most one actor, so the sums are ORs
+                const uint32_t tog_env = (sbits * 0x00204081u) & k01;
+                e.m_fix += (uint32_t)__popc(tog_env & ~w.jd);
+                e.m_sab += (uint32_t)__popc(tog_env & w.jd);
+                w.jd ^= tog_env;
+                fc80 = succ & ~w.im80;
+                sc80 = succ & w.im80;
+                changed |= tog_env != 0u;
             }
-            w.jd = 0;
-#pragma unroll
-            for (int j = 0; j < J; j++) w.jd |= dj[j] << (8 * j);
-            fc80 = h ? f2[1] : f2[0];
-            sc80 = h ? s2[1] : s2[0];
-        } else {
-            e.m_fix += (uint32_t)__popc(tog_env & ~w.jd);
-            e.m_sab += (uint32_t)__popc(tog_env & w.jd);
-            w.jd ^= tog_env;
-            fc80 = acted & ~w.im80;
-            sc80 = acted & w.im80;
         }
     }
 
     // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
-    uint32_t wsel;
-    {
+    uint32_t wsel = 0u;
+    done = false;
+    if (W::kBase && J == 0) changed = true; // FourRoomEnv's "all jobs done" holds at every step when there are none (base.py:430)
+    if (__builtin_amdgcn_ballot_w64(changed) != 0ull) { // (only when a kill landed / a job flipped this step: see step_swar)
         const uint32_t mine = (uint32_t)__popc(w.al & k01) | ((uint32_t)__popc((w.al << 7) & w.im80 & k80) << 8);
         const Pair pa = both_halves(mine);
         const uint32_t sum = pa.lo + pa.hi;

@@ -788,7 +788,7 @@ class BatchedFourRoomEnv:
 
     def set_state(self, *, agent_positions=None, alive_agents=None, imposter_mask=None, job_positions=None,
                   completed_jobs=None, used_tag_actions=None, tag_counts=None, tag_reset_timer=None, t=None,
-                  metrics=None, rng_cursor=None):
+                  metrics=None, rng_cursor=None, episode_index=None):
         """Direct state assignment (what reference callers do with ``env.agent_positions[...] = ...``)."""
         keep = []
 
@@ -820,6 +820,8 @@ class BatchedFourRoomEnv:
             view.metrics = dev(metrics, torch.int64)
         if rng_cursor is not None:
             view.rng_cursor = dev(rng_cursor, torch.int64)
+        if episode_index is not None:
+            view.episode_index = dev(episode_index, torch.int32)
         with torch.cuda.device(self.device):
             L.check(self.lib.susnet_import_state(self._h, C.byref(view), self._stream()))
             if self.export_state:
@@ -880,6 +882,17 @@ class BatchedFourRoomEnv:
             L.check(self.lib.susnet_export_state(self._h, C.byref(view), self._stream()))
             torch.cuda.current_stream(self.device).synchronize()
         return cur
+
+    def episode_index(self) -> torch.Tensor:
+        """int64[B]: resets drawn so far per env = the index of its next reset in the RESET stream (production protocol: a reset's
+        draws are a function of (seed, global env id, this index) alone)."""
+        ep = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
+        view = L.StateView()
+        view.episode_index = ep.data_ptr()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.susnet_export_state(self._h, C.byref(view), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+        return ep.to(torch.int64) & 0xFFFFFFFF
 
     def lifetime_totals(self) -> torch.Tensor:
         """int64[12] sums over this device's envs of the per-env episode accumulators (device tensor):

@@ -338,6 +338,7 @@ def compare_full_state(env, ob, tag):
         np.testing.assert_array_equal(np_(env.completed_jobs), e["jobdone"].astype(bool), err_msg=tag + " jobdone")
     np.testing.assert_array_equal(np_(env.t), e["t"], err_msg=tag + " t")
     np.testing.assert_array_equal(np_(env.rng_cursor()).astype(np.uint64), e["cursor"], err_msg=tag + " cursor")
+    np.testing.assert_array_equal(np_(env.episode_index()).astype(np.uint32), e["episode"], err_msg=tag + " episode index (RESET stream)")
     if env.VARIANT == 2:
         np.testing.assert_array_equal(np_(env.used_tag_actions), e["used"].astype(bool), err_msg=tag + " used")
         np.testing.assert_array_equal(np_(env.tag_counts), e["counts"], err_msg=tag + " counts")
