@@ -255,6 +255,15 @@ int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, void *stream);
 typedef struct susnet_record_layout_t {
     int32_t record_bytes;
     int32_t off_rewards, off_actions, off_done, off_truncated, off_obs;
+    /* planar = 0: the record array is [T][B][record_bytes].
+     * planar = 1 (the multi-agent kernels): the same record, cut into pieces of 16 bytes -- the last one(s) 8 and / or 4 bytes when
+     * record_bytes is not a multiple of 16 -- and stored piece by piece, [T][piece][B][piece width]: every store instruction of a
+     * wave then writes 1 KiB of consecutive bytes (40 partially written cache lines at a 40-byte record stride otherwise).  Byte o
+     * of env b's record of tick t lives at
+     *     t * B * record_bytes + B * P(o) + b * W(o) + (o - P(o)),
+     * P(o) = the start of o's piece, W(o) its width: with full = record_bytes / 16 * 16, P(o) = o / 16 * 16, W = 16 for o < full;
+     * then an 8-byte piece when record_bytes - full >= 8, then a 4-byte piece when record_bytes - full is 4 or 12. */
+    int32_t planar;
 } susnet_record_layout_t;
 int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out);
 

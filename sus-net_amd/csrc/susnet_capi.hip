@@ -1111,6 +1111,7 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
         out->off_obs = 5 * A;
         out->off_done = 5 * A + F;
         out->off_truncated = 5 * A + F + 1;
+        out->planar = 1; // stored as planes of 16-byte pieces (susnet_kernels.h store_record_planar)
     }
     return SUSNET_OK;
 }

@@ -415,7 +415,10 @@ struct Tables {
 
 // grid + valid + obs components + move table + rewards, then the turn-rank tables of the byte-parallel rollouts (susnet_swar.h
 // RankLut: 120 x 2 words for the first five agents, 336 x 2 words for agents 5 .. 7; filled by the kernel that uses them)
-constexpr uint32_t kRankLut1Word = 16 + 64 + 16 + 384 + 64, kRankLut2Word = kRankLut1Word + 240;
+// LDS words: grid 16 | spawn cells 64 | obs components 16 | move table 7 x 64 (rows 0 .. 5 from Consts::move_tab, row 6 = row 5 again:
+// the identity, so that FourRoomEnv's imposter list -- index 6 = KILL -- indexes the table as it is) | rewards 64
+constexpr uint32_t kMoveRows = 7;
+constexpr uint32_t kRankLut1Word = 16 + 64 + 16 + kMoveRows * 64 + 64, kRankLut2Word = kRankLut1Word + 240;
 constexpr uint32_t kTableWords = kRankLut2Word + 672;
 
 // LDS byte address of word `word` of the kernel's dynamic LDS (every kernel here uses dynamic LDS only, so the static
@@ -427,7 +430,7 @@ typedef const __attribute__((address_space(3))) float *lds_f32_ptr;
 // the table base folds into the ds_read's offset field; going through __builtin_amdgcn_groupstaticsize() left one
 // `v_add_u32 v, 0, v` per lookup in the code, the symbol being resolved only at link time.)
 __device__ __forceinline__ constexpr uint32_t lds_table_addr(uint32_t word) { return 4u * word; }
-constexpr uint32_t kMoveTableWord = 96, kRewardTableWord = 480; // (setup_lds)
+constexpr uint32_t kMoveTableWord = 96, kRewardTableWord = kMoveTableWord + kMoveRows * 64; // (setup_lds)
 __device__ __forceinline__ uint32_t lds_move_lookup(uint32_t row_cell) { return *(lds_u8_ptr)(uintptr_t)(lds_table_addr(kMoveTableWord) + row_cell); }
 __device__ __forceinline__ float lds_reward_lookup(uint32_t byte_index) { return *(lds_f32_ptr)(uintptr_t)(lds_table_addr(kRewardTableWord) + byte_index); }
 
@@ -532,8 +535,9 @@ struct TableLoad {
         if (with_comp) smem[80 + (tid & 15)] = cp;
         if (STEP_TABLES) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) smem[96 + k * kBlock + tid] = mv[k];
-            smem[480 + (tid < 48 ? tid : 47)] = rw;
+            for (int k = 0; k < 6; k++) smem[kMoveTableWord + k * kBlock + tid] = mv[k];
+            smem[kMoveTableWord + 6 * kBlock + tid] = mv[5]; // row 6: the identity once more (see kMoveRows)
+            smem[kRewardTableWord + (tid < 48 ? tid : 47)] = rw;
         }
     }
 };
@@ -547,8 +551,8 @@ __device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, uin
     T.grid = smem;
     T.valid = reinterpret_cast<const uint8_t *>(smem + 16);
     T.comp = smem + 80;
-    T.move = reinterpret_cast<const uint8_t *>(smem + 96);
-    T.rew = reinterpret_cast<const float *>(smem + 480);
+    T.move = reinterpret_cast<const uint8_t *>(smem + kMoveTableWord);
+    T.rew = reinterpret_cast<const float *>(smem + kRewardTableWord);
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
     if (HasGroupWords<S>::value) rest += kGroupWords;

@@ -620,6 +620,57 @@ __device__ __forceinline__ void store_packed_bytes(const D &d, const uint32_t *w
     if (N & 1) d.st8((uint32_t)(N - 1), (w[kW] >> (8 * ((N & 3) - 1))) & 0xffu);
 }
 
+// ---- the next episode, drawn ahead ------------------------------------------------------------------------------------------------
+// An in-launch reset used to send the WHOLE wave through the reset path -- Philox blocks, placement draws with their rejection rules,
+// the episode constants of the byte-parallel form -- whenever ONE of its environments finished: every tenth tick for cfg3, every third
+// for the tagging game, a quarter of the rollouts' cycles with one or two lanes doing useful work.  On the production stream a reset's
+// draws are a function of (seed, env, episode index) alone (susnet_device.h ResetStream), so a lane can hold its NEXT episode's
+// initial state ready: a finishing lane just takes it (a dozen register moves), and the expensive pass runs only when a finishing
+// lane has none -- and then draws for EVERY lane of the wave that has none, at full lane efficiency (about one pass per ten resets).
+// Numpy tapes (parity mode) keep the inline reset: their draws depend on the words consumed so far.
+template <class S, class Store>
+__device__ __forceinline__ void draw_episode(const Consts &c, const Tables &T, int tid, const PhiloxRng &rng, uint32_t episode, Store &stn, Env &en) {
+    en = Env{};
+    en.ep = episode;
+    reset_env<S>(c, T, stn, tid, en, const_cast<PhiloxRng &>(rng)); // (Philox flavour: reads the key and the env id only)
+}
+
+// ---- the packed record of the byte-parallel kernels, stored as PLANES --------------------------------------------------------------
+// A record of R bytes per env-step stored as [tick][env][R] makes every store instruction of a wave touch 64 pieces R bytes apart:
+// 40 partially written cache lines per instruction at R = 40, and the write path (TCP -> L2 requests) saturates at 4.4 TB/s of such
+// stores with no arithmetic at all (tools/store_patterns.hip aos40: 301 us for cfg3's launch; aos80: 3.6 TB/s) -- which is where the
+// rollouts had arrived once their instruction count was cut.  The same dwords stored as planes of 16-byte pieces --
+// [tick][piece][env][16 bytes], the last piece 8 and / or 4 bytes wide when R is not a multiple of 16 -- make every store instruction
+// write 1 KiB of consecutive bytes (soa40: 5.4 TB/s; cfg3 96 -> 108 G env-steps/s on the same box with nothing else changed).
+// Byte o of env b's record of tick t lives at  t * B * R + B * P(o) + b * W(o) + (o - P(o)),  P(o) = start of o's piece, W(o) its
+// width (susnet_record_layout_t::planar; record_piece() below is the same rule for the host and the consumers).
+struct RecordPiece { uint32_t start, width; };
+__host__ __device__ constexpr RecordPiece record_piece(uint32_t record_bytes, uint32_t o) {
+    const uint32_t full = record_bytes / 16u * 16u;
+    if (o < full) return RecordPiece{o / 16u * 16u, 16u};
+    const uint32_t rem = record_bytes - full; // 4, 8 or 12 (= 8 + 4)
+    if (rem >= 8u && o < full + 8u) return RecordPiece{full, 8u};
+    return RecordPiece{rem >= 8u ? full + 8u : full, 4u};
+}
+// dwords [D0, D0 + N) of my environment's record (N = 1, 2 or 4; never across a piece): one store.  d.vo = 0, d.so = the tick's slab
+template <int RECORD_DWORDS, int D0, int N>
+__device__ __forceinline__ void store_record_piece(const BufDst &d, uint32_t B, uint32_t b, const uint32_t *v) {
+    constexpr RecordPiece pc = record_piece(4u * RECORD_DWORDS, 4u * D0);
+    static_assert(4u * D0 + 4u * N <= pc.start + pc.width, "a store stays inside one piece");
+    const uint32_t at = B * pc.start + b * pc.width + (4u * D0 - pc.start);
+    if (N == 4) d.st128(at, v[0], v[1], v[2], v[3]);
+    else if (N == 2) d.st64(at, v[0], v[1]);
+    else d.st32(at, v[0]);
+}
+// all RECORD_DWORDS dwords, piece by piece
+template <int RECORD_DWORDS>
+__device__ __forceinline__ void store_record_planar(const BufDst &d, uint32_t B, uint32_t b, const uint32_t *rec) {
+    constexpr int k4 = RECORD_DWORDS / 4 * 4;
+    static_for<0, RECORD_DWORDS / 4>([&](auto p) __attribute__((always_inline)) { store_record_piece<RECORD_DWORDS, 4 * decltype(p)::value, 4>(d, B, b, rec + 4 * decltype(p)::value); });
+    if constexpr (RECORD_DWORDS - k4 >= 2) store_record_piece<RECORD_DWORDS, k4, 2>(d, B, b, rec + k4);
+    if constexpr ((RECORD_DWORDS - k4) & 1) store_record_piece<RECORD_DWORDS, RECORD_DWORDS - 1, 1>(d, B, b, rec + RECORD_DWORDS - 1);
+}
+
 // Fused random rollout of the byte-parallel (SWAR) configurations: the same contract as k_rollout, the state held as
 // packed bytes (susnet_swar.h) for the whole launch.  OUT_RECORD is not offered for these configurations.
 template <class S, int OUT, class RNG = PhiloxRng>
@@ -678,9 +729,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     frow.clear();
     constexpr bool kRec = OUT == OUT_RECORD; // one packed record per env-step: rewards f32[A] | actions u8[A] | raw obs u8[F] | done | truncated | 0-padding
     constexpr int kRecDwords = RecordLayout<S>::kDwords;
-    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(bb * a.record_bytes));
+    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, 0u); // (planes: store_record_planar adds the piece offsets)
     const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
-    if (active && a.n_ticks > 0) clear_info_if_fresh(e); // once per launch instead of once per tick
+    if (active && a.n_ticks > 0) {
+        clear_info_if_fresh(e); // once per launch instead of once per tick
+        rng.align();            // the first step aligns the event cursor; later steps find it aligned (step_swar: realign)
+    }
     // production stream: the words of a group of 4 ticks (whole Philox blocks) are generated at the group's first tick and staged
     // in LDS (GroupWords); the tick loop is rolled -- one copy of the step and of the reset path
     static_assert(HasGroupWords<S>::value && (RankLut<S>::kOk || S::kOrd == 0), "grouped action stream; a shuffled order comes from the rank tables");
@@ -731,6 +785,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         stage_a(0, true);
         stage_b();
     }
+    // the next episode of my environment, drawn ahead (production stream; see draw_episode)
+    W wn = w;
+    typename StoreFor<S>::type stn = st;
+    uint32_t impn = 0;
+    bool have_next = false;
     auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) { // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index, nothing loop-carried
             const uint32_t t32 = (uint32_t)tick;
@@ -764,9 +823,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             bool done, trunc;
             // (the win rules run unconditionally at the launch's first tick only: the state may come from outside; see step_swar)
 #ifdef SUSNET_STAMPS
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2, stage_b, jm, tick == 0);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2, stage_b, jm, tick == 0, tick != a.n_ticks - 1);
 #else
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, nullptr, stage_b, jm, tick == 0);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, nullptr, stage_b, jm, tick == 0, tick != a.n_ticks - 1);
 #endif
             KSTAMP(1);
             if (kTraj) {
@@ -780,23 +839,48 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             }
             if (kFeed(OUT) && a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)swar_imp_bits(w);
             KSTAMP(2);
-            if (__builtin_expect(done || trunc, 0)) {
-                life.add_episode(e, trunc);
-                if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
-                    uint32_t trow[(kRawF + 3) / 4];
-                    raw_row_swar<S>(w, trow, (uint32_t)c.tag_interval);
-                    store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+            const bool fin = done || trunc;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(fin) != 0ull, 0)) {
+                if constexpr (!RNG::kNumpy) {
+                    // a finishing lane without a drawn episode: draw now -- for every lane that has none (see draw_episode)
+                    if (__builtin_amdgcn_ballot_w64(fin && !have_next) != 0ull) {
+                        if (!have_next) {
+                            Env en;
+                            draw_episode<S>(c, T, tid, rng, e.ep, stn, en); // (the index of my next reset, whether or not I finish now)
+                            to_swar<S>(c, stn, en, wn);
+                            impn = en.imp;
+                            have_next = true;
+                        }
+                    }
                 }
-                jm.clear_jobs(st, S::J(c)); // the finished episode's job cells leave the map, the new ones enter
-                reset_env<S>(c, T, st, tid, e, rng);
-                jm.set_jobs(st, S::J(c));
-                to_swar<S>(c, st, e, w);
-                // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
-                // continue what the action draws (role-dependent ranges) left of their last word
-                stage_b();
-                // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed
-                if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
-                else zero_metrics(e);
+                if (fin) {
+                    life.add_episode(e, trunc);
+                    if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                        uint32_t trow[(kRawF + 3) / 4];
+                        raw_row_swar<S>(w, trow, (uint32_t)c.tag_interval);
+                        store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+                    }
+                    jm.clear_jobs(st, S::J(c)); // the finished episode's job cells leave the map, the new ones enter
+                    if constexpr (RNG::kNumpy) {
+                        reset_env<S>(c, T, st, tid, e, rng);
+                        to_swar<S>(c, st, e, w);
+                    } else { // base.py:251-324, drawn ahead: take it
+                        st = stn;
+                        w = wn;
+                        e.imp = impn;
+                        e.alive = (1u << A) - 1u;
+                        e.jd = e.used = e.timer = e.t = 0u;
+                        e.ep += 1u;
+                        have_next = false;
+                    }
+                    jm.set_jobs(st, S::J(c));
+                    // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
+                    // continue what the action draws (role-dependent ranges) left of their last word
+                    stage_b();
+                    // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed
+                    if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+                    else zero_metrics(e);
+                }
             }
             KSTAMP(3);
             if (OUT == OUT_TRAJ_RAW8) {
@@ -836,7 +920,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
 #pragma unroll
                 for (int q = 0; q < (kNB + 3) / 4; q++)
                     rec[A + q] = (uint32_t)by[4 * q] | ((uint32_t)by[4 * q + 1] << 8) | ((uint32_t)by[4 * q + 2] << 16) | ((uint32_t)by[4 * q + 3] << 24);
-                store_dwords<kRecDwords>(drec, rec);
+                store_record_planar<kRecDwords>(drec, (uint32_t)c.B, (uint32_t)bb, rec);
             }
             KSTAMP(4);
             if (OUT == OUT_ANY) {
@@ -916,10 +1000,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     BufDst dd = make_buf_dst(a.done, nt * (uint64_t)c.B, (uint32_t)b);
     BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)b);
     BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(b * kRawF));
-    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, (uint32_t)(b * a.record_bytes));
+    // the packed record as planes of 16-byte pieces (see store_record_planar): 20 dwords = rewards [0, 8) | actions [8, 10) | cells
+    // [10, 14) | alive [14, 16) | job cells [16, 18) | job status 18 | done, truncated 19; lane (b, h) stores its own four of each
+    BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, 0u);
+    const uint32_t rec_pb = (uint32_t)c.B * 16u, rec_b16 = (uint32_t)b * 16u;
+    const uint32_t at_rew = h * rec_pb + rec_b16, at_act = 2u * rec_pb + rec_b16 + 4u * h, at_pos = (2u + h) * rec_pb + rec_b16 + (h ? 0u : 8u),
+                   at_al = 3u * rec_pb + rec_b16 + 8u + 4u * h, at_tail = 4u * rec_pb + rec_b16;
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
     const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
-    if (a.n_ticks > 0) clear_info_if_fresh(e);
+    if (a.n_ticks > 0) {
+        clear_info_if_fresh(e);
+        rng.align(); // the first step aligns the event cursor; later steps find it aligned (step_swar2: realign)
+    }
     // the action stream: groups of 8 ticks = whole PAIRS of Philox blocks, lane h generating the blocks 2k + h, staged in LDS
     // (GroupWords); the tick loop is rolled -- one copy of the step and of the reset path
     static_assert(HasGroupWords<S>::value && (RankLut<S>::kOk || S::kOrd == 0), "grouped action stream; a shuffled order comes from the rank tables");
@@ -961,6 +1053,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
         stage_a(0, true);
         stage_b();
     }
+    // the next episode of my environment, drawn ahead (production stream; see draw_episode): both lanes of a pair hold their own half
+    W wn = w;
+    typename StoreFor<S>::type stn = st;
+    uint32_t impn = 0;
+    bool have_next = false;
     auto tick_body = [&](int tick) __attribute__((always_inline)) {
         if (kTraj) {
             const uint32_t t32 = (uint32_t)tick;
@@ -990,8 +1087,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
         }
         float rr[4];
         bool done, trunc;
-        if constexpr (RNG::kNumpy) step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0);
-        else step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0, stage_b);
+        if constexpr (RNG::kNumpy) step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0, false);
+        else step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0, tick != a.n_ticks - 1, stage_b);
         // (the rewards come out of LDS lookups issued at the very end of the step: they are stored LAST, behind everything else
         // the tick writes, so that nothing waits for them)
         if (kTraj) {
@@ -1001,26 +1098,51 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
                 dt.st8(0u, trunc ? 1u : 0u);
             }
         }
-        if (kRec) drec.st32(4u * A + 4u * h, act); // rewards f32[8] | actions u8[8] | ...: my four of each
+        if (kRec) drec.st32(at_act, act); // my four action bytes
         if (kFeed(OUT) && a.roles != nullptr && h == 0u) a.roles[(int64_t)tick * c.B + b] = (uint16_t)w.imp_bits;
-        if (__builtin_expect(done || trunc, 0)) { // (both lanes of the pair: done / truncated are the environment's)
-            life.add_episode(e, trunc);
-            if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
-                Swar<S> f;
-                gather_swar2<S>(w, f);
-                uint32_t trow[(kRawF + 3) / 4];
-                raw_row_swar<S>(f, trow);
-                if (h == 0u) store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+        const bool fin = done || trunc; // (both lanes of a pair: done / truncated are the environment's)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(fin) != 0ull, 0)) {
+            if constexpr (!RNG::kNumpy) {
+                // a finishing environment without a drawn episode: draw now -- for every environment of the wave that has none
+                if (__builtin_amdgcn_ballot_w64(fin && !have_next) != 0ull) {
+                    if (!have_next) {
+                        Env en;
+                        draw_episode<S>(c, T, tid, rng, e.ep, stn, en); // (the index of my next reset, whether or not I finish now)
+                        to_swar2<S>(c, stn, en, h, wn);
+                        impn = en.imp;
+                        have_next = true;
+                    }
+                }
             }
-            jm.clear_jobs(st, S::J(c)); // the finished episode's job cells leave the map, the new ones enter
-            reset_env<S>(c, T, st, tid, e, rng);
-            jm.set_jobs(st, S::J(c));
-            to_swar2<S>(c, st, e, h, w);
-            // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
-            // continue what the action draws (role-dependent ranges) left of their last word
-            if constexpr (!RNG::kNumpy) stage_b();
-            if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
-            else zero_metrics(e);
+            if (fin) {
+                life.add_episode(e, trunc);
+                if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                    Swar<S> f;
+                    gather_swar2<S>(w, f);
+                    uint32_t trow[(kRawF + 3) / 4];
+                    raw_row_swar<S>(f, trow);
+                    if (h == 0u) store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+                }
+                jm.clear_jobs(st, S::J(c)); // the finished episode's job cells leave the map, the new ones enter
+                if constexpr (RNG::kNumpy) {
+                    reset_env<S>(c, T, st, tid, e, rng);
+                    to_swar2<S>(c, st, e, h, w);
+                } else { // base.py:251-324, drawn ahead: take it
+                    st = stn;
+                    w = wn;
+                    e.imp = impn;
+                    e.alive = (1u << A) - 1u;
+                    e.jd = e.used = e.timer = e.t = 0u;
+                    e.ep += 1u;
+                    have_next = false;
+                }
+                jm.set_jobs(st, S::J(c));
+                // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
+                // continue what the action draws (role-dependent ranges) left of their last word
+                if constexpr (!RNG::kNumpy) stage_b();
+                if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+                else zero_metrics(e);
+            }
         }
         if (OUT == OUT_TRAJ_RAW8) { // flatten_state (base.py:234-235): cells [0, 16) | alive [16, 24) | job cells [24, 32) | job status [32, 36)
             const uint32_t x = w.xy & 0x0f0f0f0fu, y = (w.xy >> 4) & 0x0f0f0f0fu;
@@ -1034,11 +1156,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
         if (kRec) { // the raw row at [5A, 5A + F) -- every lane its own dwords of it -- then done | truncated | 0-padding (low lane)
             static_assert(kRawF == 36 && A == 8, "cells [0, 16) | alive [16, 24) | job cells [24, 32) | job status [32, 36)");
             const uint32_t x = w.xy & 0x0f0f0f0fu, y = (w.xy >> 4) & 0x0f0f0f0fu;
-            drec.st64(5u * A + 8u * h, __builtin_amdgcn_perm(y, x, 0x05010400u), __builtin_amdgcn_perm(y, x, 0x07030602u));
-            drec.st32(5u * A + 16u + 4u * h, w.al & k01);
+            drec.st64(at_pos, __builtin_amdgcn_perm(y, x, 0x05010400u), __builtin_amdgcn_perm(y, x, 0x07030602u));
+            drec.st32(at_al, w.al & k01);
             if (h == 0u)
-                drec.st128(5u * A + 24u, w.jobs_obs[0], w.jobs_obs[1], w.jd, (done ? 1u : 0u) | (trunc ? 0x100u : 0u));
-            drec.st128(16u * h, __float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3]));
+                drec.st128(at_tail, w.jobs_obs[0], w.jobs_obs[1], w.jd, (done ? 1u : 0u) | (trunc ? 0x100u : 0u));
+            drec.st128(at_rew, __float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3]));
         }
         if (kTraj) store_row_f32<4>(dr, rr);
     };
@@ -1112,6 +1234,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
         clear_info_if_fresh(e); // once per launch instead of once per tick
         rng.align();            // the first step aligns the event-stream cursor; later steps find it aligned (see below)
     }
+    // the next episode's spawn cells, drawn ahead (production stream; see draw_episode): one register
+    uint32_t pqn = d.pq;
+    bool have_next = false;
     auto tick_body = [&](int tick, auto par) __attribute__((always_inline)) {
         constexpr int POS = decltype(par)::value;
         if (kTraj) { // this tick's slabs: scalar offsets derived from the (wave-uniform) tick index, nothing loop-carried
@@ -1153,22 +1278,47 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             dt.st8(0u, trunc);
         }
         if (kFeed(OUT) && a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)1u; // the imposter is agent 0 (pred_prey.py:52-66, shuffle off)
-        if (__builtin_expect((done | trunc) != 0u, 0)) {
-            if (!RNG::kNumpy) rng.cur += (uint64_t)hit; // the landed kill's word of the event stream: a hit ends the episode (the crew has
-                                                        // one member), so it is counted here instead of by a 64-bit add on every tick
-            life.add_episode(e, trunc != 0u);
-            if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
-                PtrDst tp{a.term_obs + ((int64_t)tick * c.B + b) * 6};
-                tp.st32(0u, d.pq - k01);
-                tp.st16(4u, duel_alive_bytes(d));
+        const bool fin = (done | trunc) != 0u;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(fin) != 0ull, 0)) {
+            if constexpr (!RNG::kNumpy) {
+                // a finishing lane without drawn spawn cells: draw now -- for every lane of the wave that has none (see draw_episode)
+                if (__builtin_amdgcn_ballot_w64(fin && !have_next) != 0ull) {
+                    if (!have_next) {
+                        typename StoreFor<S>::type stn;
+                        Env en;
+                        draw_episode<S>(c, T, tid, rng, e.ep, stn, en); // (the index of my next reset, whether or not I finish now)
+                        Duel dn;
+                        to_duel(stn, en, dn);
+                        pqn = dn.pq;
+                        have_next = true;
+                    }
+                }
             }
-            reset_env<S>(c, T, st, tid, e, rng);
-            to_duel(st, e, d);
-            // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed.
-            // The next step will align the cursor: done right here unless this was the launch's last tick (then the stored
-            // cursor is the reset's, as if no step had followed)
-            if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
-            else { zero_metrics(e); rng.align(); }
+            if (fin) {
+                if (!RNG::kNumpy) rng.cur += (uint64_t)hit; // the landed kill's word of the event stream: a hit ends the episode (the crew has
+                                                            // one member), so it is counted here instead of by a 64-bit add on every tick
+                life.add_episode(e, trunc != 0u);
+                if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                    PtrDst tp{a.term_obs + ((int64_t)tick * c.B + b) * 6};
+                    tp.st32(0u, d.pq - k01);
+                    tp.st16(4u, duel_alive_bytes(d));
+                }
+                if constexpr (RNG::kNumpy) {
+                    reset_env<S>(c, T, st, tid, e, rng);
+                    to_duel(st, e, d);
+                } else { // base.py:251-324, drawn ahead: take it
+                    d.pq = pqn;
+                    d.lv = 0xffffffffu;
+                    e.t = 0u;
+                    e.ep += 1u;
+                    have_next = false;
+                }
+                // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed.
+                // The next step will align the event cursor: done right here unless this was the launch's last tick (then the
+                // stored cursor is the one the last step left)
+                if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
+                else { zero_metrics(e); rng.align(); }
+            }
         }
         if (OUT == OUT_TRAJ_RAW8) { // flatten_state: x0 y0 x1 y1 alive0 alive1
             dobs.st32(0u, d.pq - k01);

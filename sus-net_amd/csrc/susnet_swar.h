@@ -145,8 +145,14 @@ struct Swar {
     static constexpr bool kBase = S::kVar != SUSNET_VARIANT_ITG; // FourRoomEnv action lists (base.py:82-99); tagging.py appends the tag actions
     uint32_t xy[NW];           // cell x | y << 4, one byte per agent
     uint32_t al[NW];           // alive: 0x01 per agent
+    // the same flags in the forms the step consumes every tick, kept next to `al` by the (rare) code that changes it -- a kill that
+    // landed, a vote that ejected somebody, a reset -- instead of being derived from it tick after tick:
+    uint32_t al80[NW];         //   alive: 0x80 per agent
+    uint32_t crew80[NW];       //   living crew: 0x80 per agent (base.py:535-542)
+    uint32_t ridx[NW];         //   per agent the byte index into the reward table of "no assignment, nobody won": 16 if dead + 32 for indices [:n_imposters] (base.py:559,562)
     uint32_t im80[NW];         // imposter: 0x80 per agent (constant within an episode)
     uint32_t isel[NI];         // v_perm selector that extracts imposter s's byte (zeros elsewhere)
+    uint32_t iselb[NI];        // v_perm selector that puts imposter s's byte into ALL four bytes
     uint32_t ihot[NI][NW];     // 0x80 at imposter s's byte
     uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes (constant within an episode)
     uint32_t jobs_obs[J > 4 ? 4 : 2]; // x0 y0 x1 y1 | x2 y2 x3 y3 | ... of the job cells (observation bytes; constant within an episode)
@@ -155,6 +161,19 @@ struct Swar {
     // tagging.py: used_tag_actions (0x01 per agent), tag_counts (one byte per agent), tag_reset_timer
     uint32_t used[NW], cnt[NW], timer;
 };
+
+// al80 / crew80 / ridx from al and im80 (see Swar)
+template <class S>
+__device__ __forceinline__ void swar_refresh_alive(Swar<S> &w) {
+    using W = Swar<S>;
+    constexpr uint32_t neg32[2] = {(W::NI >= 1 ? 0x20u : 0u) | (W::NI >= 2 ? 0x2000u : 0u), 0u}; // indices [:n_imposters], NOT the imposter mask (base.py:559)
+#pragma unroll
+    for (int q = 0; q < W::NW; q++) {
+        w.al80[q] = (w.al[q] & k01) << 7;
+        w.crew80[q] = w.al80[q] & ~w.im80[q];
+        w.ridx[q] = (((w.al[q] & k01) ^ k01) << 4) + neg32[q > 0 ? 1 : 0]; // (bytes past the last agent read as dead: never looked up)
+    }
+}
 
 // (Env bitmasks + packed store) -> byte-parallel form.  Runs once per launch and after each reset.
 template <class S, class Store>
@@ -191,6 +210,9 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
         }
         seen += is;
     }
+    swar_refresh_alive<S>(w);
+#pragma unroll
+    for (int s = 0; s < W::NI; s++) w.iselb[s] = (w.isel[s] & 0xffu) * k01;
 #pragma unroll
     for (int q = 0; q < W::JW; q++) w.jd[q] = 0;
 #pragma unroll
@@ -240,6 +262,23 @@ __device__ __forceinline__ uint32_t swar_imp_bits(const Swar<S> &w) {
     return m;
 }
 
+// N values below 256, one per register, as bytes of packed words: byte picks (v_perm takes the low bytes of two registers at once)
+// instead of a shift and an OR per value
+template <int N>
+__device__ __forceinline__ void pack_digits(const uint32_t (&d)[N], uint32_t (&out)[(N + 3) / 4]) {
+#pragma unroll
+    for (int q = 0; q < (N + 3) / 4; q++) {
+        const int n = N - 4 * q < 4 ? N - 4 * q : 4;
+        if (n == 1) out[q] = d[4 * q];
+        else {
+            uint32_t lo = __builtin_amdgcn_perm(d[4 * q + 1], d[4 * q], 0x0c0c0400u); // d0 | d1 << 8
+            if (n == 3) lo |= d[4 * q + 2] << 16;
+            if (n == 4) lo |= __builtin_amdgcn_perm(d[4 * q + 3], d[4 * q + 2], 0x04000c0cu); // d2 << 16 | d3 << 24
+            out[q] = lo;
+        }
+    }
+}
+
 // base.py:326-330 on the production stream (see sample_actions_env): the action bytes, packed like every per-agent value
 template <class S, int POS = -1, class WT = Swar<S>, class AS = ActionStream>
 __device__ __forceinline__ void sample_actions_swar(const Consts &c, const WT &w, PhiloxRng &rng, AS &as, uint64_t tick,
@@ -247,8 +286,7 @@ __device__ __forceinline__ void sample_actions_swar(const Consts &c, const WT &w
     using W = Swar<S>;
     const uint64_t Wt = (uint64_t)S::kAw.W;
     uint32_t word = 0;
-#pragma unroll
-    for (int q = 0; q < W::NW; q++) act[q] = 0;
+    uint32_t dg[W::A];
 #pragma unroll
     for (int i = 0; i < W::A; i++) {
         const int k = S::kAw.word[i];
@@ -256,10 +294,11 @@ __device__ __forceinline__ void sample_actions_swar(const Consts &c, const WT &w
             word = POS >= 0 ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * Wt, (POS >= 0 ? POS : 0) * S::kAw.W + k)
                             : as.word(rng, tick * Wt + (uint64_t)k);
         const uint64_t p = (uint64_t)word * (uint64_t)w.nact[i];
-        act[i / 4] |= (uint32_t)(p >> 32) << (8 * (i & 3));
+        dg[i] = (uint32_t)(p >> 32);
         word = (uint32_t)p;
     }
     as.rem = word;
+    pack_digits<W::A>(dg, act);
 }
 template <class S>
 __device__ __forceinline__ void sample_actions_swar(const Consts &c, const Swar<S> &w, TapeRng &rng, uint32_t (&act)[Swar<S>::NW]) {
@@ -409,10 +448,13 @@ struct NoMid {
 // first: the previous tick's check covered it, or a reset replaced it) -- the win rules then run only behind a ballot on "something
 // they read changed this step" (a kill landed, a job flipped, a vote ejected somebody), or always where a game is won without
 // any of that (FourRoomEnv with no jobs, base.py:430).
+// realign (fused rollouts, every tick but the launch's last): a landed kill leaves the event cursor at the start of the next block --
+// where the NEXT step's alignment would put it -- so that no tick has to align a cursor that moves once in five hundred steps.
 template <class S, class RNG, class MID = NoMid, class JM = NoJobMap>
 __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar<S> &w, Env &e, RNG &rng, const uint32_t (&act)[Swar<S>::NW],
                                           const uint32_t (&R)[Swar<S>::NW], float (&rr)[Swar<S>::A], bool &done, bool &trunc,
-                                          unsigned long long *sg = nullptr, MID &&mid = MID(), const JM &jm = JM(), bool check_win = true) {
+                                          unsigned long long *sg = nullptr, MID &&mid = MID(), const JM &jm = JM(), bool check_win = true,
+                                          bool realign = false) {
 #ifdef SUSNET_STAMPS // diagnostic build only (tools/stamps.py): cycles of the step's sections, one wave
     unsigned long long sprev = __builtin_readcyclecounter();
 #define WSTAMP(k) do { unsigned long long tn = __builtin_readcyclecounter(); if (sg) sg[k] += tn - sprev; sprev = tn; } while (0)
@@ -423,7 +465,9 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     constexpr int A = W::A, J = W::J, NW = W::NW, NI = W::NI;
     constexpr uint32_t kLive[2] = {A >= 4 ? 0xffffffffu : (1u << (8 * (A & 3))) - 1u, A >= 8 ? 0xffffffffu : (A > 4 ? (1u << (8 * (A & 3))) - 1u : 0u)};
     e.m_steps += 1; // base.py:366
-    rng.align();
+    // production protocol: the event cursor is block-aligned at the start of a step.  It only ever moves in the kill tail (one word
+    // per landed kill), so the fused rollouts (JobMap flavour) align once per launch and again right after a kill (realign_after_kill)
+    if (!JM::kOn) rng.align();
 
     // ---- action classes (0x80 per agent): alive agents only (base.py:477) --------------------------------------------------
     uint32_t al80[NW], kill80[NW], fix80[NW], sab80[NW], mv80[NW], rows[NW], tag80[NW];
@@ -431,7 +475,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     for (int q = 0; q < NW; q++) {
         const uint32_t a = act[q];
         const uint32_t g5 = (a + 0x7b7b7b7bu) & k80, g6 = (a + 0x7a7a7a7au) & k80; // action index >= 5 / >= 6
-        al80[q] = (w.al[q] << 7) & kLive[q] & k80;
+        al80[q] = w.al80[q];
         tag80[q] = 0;
         if (W::kTag) { // base lists + the tag actions behind them (tagging.py:68-75): crew 6.., imposter 7..
             const uint32_t g7 = (a + 0x79797979u) & k80;
@@ -446,7 +490,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             const uint32_t j5 = g5 & ~g6 & al80[q];
             sab80[q] = j5 & w.im80[q];
             fix80[q] = j5 & ~w.im80[q];
-            rows[q] = a - (g6 >> 7); // row of the (action, cell) table: 0..4 = the move actions, 5 = identity (KILL index 6 -> 5)
+            rows[q] = a; // row of the (action, cell) table: 0..4 = the move actions, 5 and 6 = the identity (susnet_device.h kMoveRows)
         } else { // pred_prey.py:4-19: imposter 5 = KILL, no job actions
             kill80[q] = g5 & al80[q];
             sab80[q] = fix80[q] = 0;
@@ -462,7 +506,11 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         for (int i = 0; i < A; i++) {
             // address = row << 8 | cell: byte i of `rows` and of `xy`
             const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(i & 3)) << 8) | (uint32_t)(i & 3);
+#ifdef SUSNET_EXP_NO_DEST_LDS // diagnostic builds only (tools/build_variant.sh): what the lookup's round trip costs -- WRONG results
+            d[i] = __builtin_amdgcn_perm(rows[i / 4], w.xy[i / 4], sel) & 0xffu;
+#else
             d[i] = lds_move_lookup(__builtin_amdgcn_perm(rows[i / 4], w.xy[i / 4], sel));
+#endif
         }
 #pragma unroll
         for (int q = 0; q < NW; q++) dest[q] = 0;
@@ -478,7 +526,11 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         if (W::kBase) {
             uint32_t mj[A];
 #pragma unroll
+#ifdef SUSNET_EXP_NO_JOBMAP_LDS
+            for (int i = 0; i < A; i++) mj[i] = ((w.xy[i / 4] >> (8 * (i & 3))) & 0xffu) == 0x33u ? 0x80u : 0u;
+#else
             for (int i = 0; i < A; i++) mj[i] = jm.at((w.xy[i / 4] >> (8 * (i & 3))) & 0xffu);
+#endif
 #pragma unroll
             for (int i = 0; i < A; i++) jobat[i / 4] |= mj[i] << (8 * (i & 3));
         }
@@ -492,20 +544,25 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
     uint32_t kc80[NW], pend80[NW]; // killers that landed a kill; victims killed before their own turn
     uint32_t vk80[NI][NW], gek80[NI][NW]; // per kill turn: the victim; the agents that had not acted yet (tagging only)
+    uint32_t idx4[NW];             // reward-table byte index per agent (see the reward section): the episode's base + what this step adds
 #pragma unroll
-    for (int q = 0; q < NW; q++) kc80[q] = pend80[q] = 0;
+    for (int q = 0; q < NW; q++) {
+        kc80[q] = pend80[q] = 0;
+        idx4[q] = w.ridx[q];
+    }
 #pragma unroll
     for (int it = 0; it < NI; it++)
 #pragma unroll
         for (int q = 0; q < NW; q++) vk80[it][q] = gek80[it][q] = 0;
     {
-        uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot: kill flag (0x80 / 0), rank | 0x80, cell
+        const uint64_t cur0 = rng.cur; // the step's (aligned) event cursor: a landed kill takes word cur0 + kills landed before it
+        uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot, in ALL four bytes: kill flag (0x80 / 0), rank | 0x80, cell
 #pragma unroll
         for (int s = 0; s < NI; s++) {
             const uint32_t hi = NW > 1 ? NW - 1 : 0;
-            kb[s] = __builtin_amdgcn_perm(NW > 1 ? kill80[hi] : 0u, kill80[0], w.isel[s]);
-            rb[s] = __builtin_amdgcn_perm(NW > 1 ? R[hi] : 0u, R[0], w.isel[s]);
-            cb[s] = __builtin_amdgcn_perm(NW > 1 ? w.xy[hi] : 0u, w.xy[0], w.isel[s]);
+            kb[s] = __builtin_amdgcn_perm(NW > 1 ? kill80[hi] : 0u, kill80[0], w.iselb[s]);
+            rb[s] = __builtin_amdgcn_perm(NW > 1 ? R[hi] : 0u, R[0], w.iselb[s]);
+            cb[s] = __builtin_amdgcn_perm(NW > 1 ? w.xy[hi] : 0u, w.xy[0], w.iselb[s]);
         }
         bool second_first = false; // two imposters: the one with the earlier turn kills first
         if (NI == 2) second_first = kb[1] != 0u && (kb[0] == 0u || rb[1] < rb[0]);
@@ -513,53 +570,58 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         for (int it = 0; it < NI; it++) {
             const int s0 = it, s1 = NI - 1 - it; // slot if the natural order holds / if it is swapped
             const uint32_t kbi = second_first ? kb[s1] : kb[s0], rbi = second_first ? rb[s1] : rb[s0], cbi = second_first ? cb[s1] : cb[s0];
-            const bool attempt = kbi != 0u;
-            if (__builtin_amdgcn_ballot_w64(attempt) != 0ull) {
-                const uint32_t tb = bcast_byte0(rbi & 0x7fu), cbb = bcast_byte0(cbi);
-                uint32_t ge80[NW], cand[NW];
-                uint32_t nc = 0;
+            // (no ballot on "somebody attempts" for the first kill turn: in a wave of 64 environments somebody nearly always does;
+            // the second turn only has work where BOTH imposters attempt)
+            if (it > 0 && __builtin_amdgcn_ballot_w64(kbi != 0u) == 0ull) continue;
+            const uint32_t tb = rbi & k7f;
+            uint32_t ge80[NW], cand[NW];
+            uint32_t nc = 0;
 #pragma unroll
-                for (int q = 0; q < NW; q++) {
-                    ge80[q] = (R[q] - tb) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
-                    const uint32_t pos = sel_bytes(ff_from80(ge80[q]), w.xy[q], newt[q]);
-                    const uint32_t crew80 = (w.al[q] << 7) & ~w.im80[q] & kLive[q]; // living crew NOW (base.py:535-542)
-                    cand[q] = attempt ? (zero80(pos ^ cbb) & crew80) : 0u;
-                    nc += (uint32_t)__popc(cand[q]);
-                }
-                // Nearly every tick some lane ATTEMPTS a kill, but a crew member on the killer's cell is rare (a fraction of a
-                // percent per environment): everything below the candidate search sits behind a second ballot.
-                if (__builtin_amdgcn_ballot_w64(nc != 0u) == 0ull) continue;
-                // base.py:497: uniform among the candidates (ascending agent index).  With one candidate -- nearly always --
-                // the victim is the lowest set flag; several candidates (rare) are handled behind a wave-uniform branch.
-                uint32_t v80[NW];
-                v80[0] = cand[0] & (0u - cand[0]);
-                if (NW > 1) v80[NW - 1] = cand[0] != 0u ? 0u : (cand[NW - 1] & (0u - cand[NW - 1]));
-                const uint64_t word_pos = rng.cur; // production protocol: one word per landed kill, its value only matters with several candidates
-                if (!RNG::kNumpy) rng.cur += nc != 0u ? 1ull : 0ull;
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(nc > 1u) != 0ull, 0)) {
-                    if (nc > 1u) {
-                        if (!RNG::kNumpy) rng.cur = word_pos; // (the draw below takes the word and advances the cursor itself)
-                        const uint32_t r = rng.bounded(nc); // numpy draws nothing for a single candidate: only here
-                        uint32_t c0 = cand[0], c1 = NW > 1 ? cand[NW - 1] : 0u;
-                        for (uint32_t k = 0; k < r; k++) {
-                            const bool lo = c0 != 0u;
-                            c0 = lo ? (c0 & (c0 - 1u)) : c0;
-                            c1 = lo ? c1 : (c1 & (c1 - 1u));
-                        }
-                        v80[0] = c0 & (0u - c0);
-                        if (NW > 1) v80[NW - 1] = c0 != 0u ? 0u : (c1 & (0u - c1));
+            for (int q = 0; q < NW; q++) {
+                ge80[q] = (R[q] - tb) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
+                const uint32_t pos = sel_bytes(ff_from80(ge80[q]), w.xy[q], newt[q]);
+                cand[q] = zero80(pos ^ cbi) & w.crew80[q] & kbi; // living crew NOW on the killer's cell (base.py:535-542), if it attempts
+                nc += (uint32_t)__popc(cand[q]);
+            }
+            // A crew member on the killer's cell is rare (a fraction of a percent per environment): everything below the candidate
+            // search sits behind a ballot.
+            if (__builtin_amdgcn_ballot_w64(nc != 0u) == 0ull) continue;
+            // base.py:497: uniform among the candidates (ascending agent index).  With one candidate -- nearly always --
+            // the victim is the lowest set flag; several candidates (rare) are handled behind a wave-uniform branch.
+            uint32_t v80[NW];
+            v80[0] = cand[0] & (0u - cand[0]);
+            if (NW > 1) v80[NW - 1] = cand[0] != 0u ? 0u : (cand[NW - 1] & (0u - cand[NW - 1]));
+            uint32_t before = 0; // kills of THIS step that this environment landed already
+#pragma unroll
+            for (int q = 0; q < NW; q++) before += (uint32_t)__popc(kc80[q]);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(nc > 1u) != 0ull, 0)) {
+                if (nc > 1u) {
+                    if (!RNG::kNumpy) rng.cur = cur0 + (uint64_t)before; // production protocol: one word per landed kill, its value only matters here
+                    const uint32_t r = rng.bounded(nc); // numpy draws nothing for a single candidate: only here
+                    uint32_t c0 = cand[0], c1 = NW > 1 ? cand[NW - 1] : 0u;
+                    for (uint32_t k = 0; k < r; k++) {
+                        const bool lo = c0 != 0u;
+                        c0 = lo ? (c0 & (c0 - 1u)) : c0;
+                        c1 = lo ? c1 : (c1 & (c1 - 1u));
                     }
+                    v80[0] = c0 & (0u - c0);
+                    if (NW > 1) v80[NW - 1] = c0 != 0u ? 0u : (c1 & (0u - c1));
                 }
-                const bool hit = nc != 0u;
-                e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
+            }
+            const bool hit = nc != 0u;
+            if (!RNG::kNumpy) rng.cur = hit ? (realign ? cur0 + 4ull : cur0 + (uint64_t)before + 1ull) : rng.cur;
+            e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
 #pragma unroll
-                for (int q = 0; q < NW; q++) {
-                    w.al[q] &= ~(v80[q] >> 7);                                      // base.py:511
-                    const uint32_t hot = second_first ? w.ihot[s1][q] : w.ihot[s0][q];
-                    kc80[q] |= hit ? hot : 0u;                                      // base.py:514-515 (the victim's slot ends as dead_penalty)
-                    pend80[q] |= v80[q] & ge80[q];                                  // killed before its own turn: it never acts
-                    if (W::kTag) { vk80[it][q] = v80[q]; gek80[it][q] = ge80[q]; }
-                }
+            for (int q = 0; q < NW; q++) {
+                w.al[q] &= ~(v80[q] >> 7);                                      // base.py:511
+                w.al80[q] &= ~v80[q];
+                w.crew80[q] &= ~v80[q];
+                w.ridx[q] += v80[q] >> 3;                                       // the victim's rewards come from the "dead" rows from now on (base.py:562)
+                const uint32_t hot = hit ? (second_first ? w.ihot[s1][q] : w.ihot[s0][q]) : 0u;
+                kc80[q] |= hot;                                                 // base.py:514-515 (the victim's slot ends as dead_penalty)
+                idx4[q] += (v80[q] >> 3) + (hot >> 5);                          // RC_KILL * 4 for the killer
+                pend80[q] |= v80[q] & ge80[q];                                  // killed before its own turn: it never acts
+                if (W::kTag) { vk80[it][q] = v80[q]; gek80[it][q] = ge80[q]; }
             }
         }
     }
@@ -635,6 +697,8 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                     }
                     w.jd[0] = ((jbits & 15u) * 0x00204081u) & k01; // bits -> 0x01 per job byte (see below)
                     if (JW > 1) w.jd[jhi] = ((jbits >> 4) * 0x00204081u) & k01;
+#pragma unroll
+                    for (int q = 0; q < NW; q++) idx4[q] += (fc80[q] >> 4) + (sc80[q] >> 5) + (sc80[q] >> 4); // RC_FIX 2, RC_SAB 3, times 4
                 } else {
                     uint32_t tbits = 0;
 #pragma unroll
@@ -645,6 +709,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                         sc80[q] = succ[q] & w.im80[q];
                         e.m_fix += (uint32_t)__popc(fc80[q]);
                         e.m_sab += (uint32_t)__popc(sc80[q]);
+                        idx4[q] += (succ[q] >> 4) + (sc80[q] >> 5); // RC_FIX 2 / RC_SAB 3, times 4
                     }
                     // bits -> 0x01 per job byte: b * (1 + 2^7 + 2^14 + 2^21) puts bit k of a 4-bit b at bit 8k (the four shifted copies
                     // occupy disjoint bit ranges: no carries)
@@ -721,6 +786,8 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                 e.m_sab += (uint32_t)__popc(sc80[q]);
             }
         }
+#pragma unroll
+        for (int q = 0; q < NW; q++) idx4[q] += (fc80[q] >> 4) + (sc80[q] >> 5) + (sc80[q] >> 4); // RC_FIX 2, RC_SAB 3, times 4
     }
 
     WSTAMP(2);
@@ -772,7 +839,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             for (int q = 0; q < NW; q++) killed |= kc80[q];
             if (__builtin_amdgcn_ballot_w64(check_win || killed != 0u) != 0ull) {
 #pragma unroll
-                for (int q = 0; q < NW; q++) w.cnt[q] &= ff_from80((w.al[q] << 7) & k80);
+                for (int q = 0; q < NW; q++) w.cnt[q] &= ff_from80(w.al80[q]);
             }
         }
         w.timer += 1u;                                                               // tagging.py:182
@@ -796,6 +863,14 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             const bool vimp = ((im >> (8u * best + 7u)) & 1ull) != 0ull;
             w.al[0] &= ~(uint32_t)hot;
             if (NW > 1) w.al[hi] &= ~(uint32_t)(hot >> 32);
+#pragma unroll
+            for (int q = 0; q < NW; q++) { // (the derived forms of the alive flags: see Swar)
+                const uint32_t h1 = q == 0 ? (uint32_t)hot : (uint32_t)(hot >> 32);
+                w.al80[q] &= ~(h1 << 7);
+                w.crew80[q] &= ~(h1 << 7);
+                w.ridx[q] += h1 << 4;
+                idx4[q] += h1 << 4;
+            }
             const float vote = c.fr[RW_VOTE];
             team += out ? vote * (vimp ? -1.0f : 1.0f) : 0.0f; // tagging.py:196, sign as coded
             e.m_kv += out ? (vimp ? (1u << 16) : (1u << 24)) : 0u;
@@ -823,8 +898,8 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         int alive_imp = 0, alive_all = 0;
 #pragma unroll
         for (int q = 0; q < NW; q++) {
-            alive_all += __popc(w.al[q] & kLive[q] & k01);
-            alive_imp += __popc((w.al[q] << 7) & w.im80[q] & kLive[q]);
+            alive_all += __popc(w.al80[q]);
+            alive_imp += __popc(w.al80[q] & w.im80[q]);
         }
         int done_jobs = 0;
 #pragma unroll
@@ -840,21 +915,21 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         done = crew_won || imp_won;
         e.flags |= (crew_won ? FLAG_CREW_WON : 0u) | (imp_won ? FLAG_IMP_WON : 0u);
         wsel = crew_won ? 16u : (imp_won ? 32u : 0u);
+        if (!W::kTag) {
+#pragma unroll
+            for (int q = 0; q < NW; q++) idx4[q] += (wsel << 2) * k01; // the table's "crew won" / "imposters won" block
+        }
     }
     // ---- rewards: assignments -> _merge_rewards (base.py:553-563) -> zero fill (389-390), one lookup per agent in the
-    // host-evaluated table [win][index < n_imposters][dead][assignment code]; byte = 4 * table index
+    // host-evaluated table [win][index < n_imposters][dead][assignment code]; byte = 4 * table index.  idx4 started from the episode's
+    // base (dead / index < n_imposters: Swar::ridx) and collected this step's assignment codes and outcome where they arose
     if (!W::kTag) {
-        uint32_t idx4[NW];
 #pragma unroll
-        for (int q = 0; q < NW; q++) {
-            const uint32_t code4 = (kc80[q] >> 5) | (fc80[q] >> 4) | (sc80[q] >> 5) | (sc80[q] >> 4); // RC_KILL 1, RC_FIX 2, RC_SAB 3, times 4
-            const uint32_t dead16 = ((w.al[q] & k01) ^ k01) << 4;
-            // indices [:n_imposters], NOT the imposter mask (base.py:559)
-            constexpr uint32_t neg32[2] = {(NI >= 1 ? 0x20u : 0u) | (NI >= 2 ? 0x2000u : 0u), 0u};
-            idx4[q] = code4 + dead16 + neg32[q > 0 ? 1 : 0] + (wsel << 2) * k01;
-        }
-#pragma unroll
+#ifdef SUSNET_EXP_NO_REWARD_LDS
+        for (int i = 0; i < A; i++) rr[i] = (float)((idx4[i / 4] >> (8 * (i & 3))) & 0xffu);
+#else
         for (int i = 0; i < A; i++) rr[i] = lds_reward_lookup((idx4[i / 4] >> (8 * (i & 3))) & 0xffu);
+#endif
     } else {
         // tagging.py:162-213: every agent starts from time_step_reward (no zero fill afterwards), assignments overwrite, the team
         // reward (vote, then win) is added, indices [:n_imposters] are negated, the dead get dead_penalty.  float32 is exact here:

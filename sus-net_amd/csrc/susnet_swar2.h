@@ -33,7 +33,9 @@ struct Swar2 {
     static constexpr bool kBase = S::kVar != SUSNET_VARIANT_ITG;
     uint32_t h;                 // 0: this lane holds agents 0..3, 1: agents 4..7
     uint32_t xy, al, im80;      // my word of cells / alive (0x01) / imposter flags (0x80)
+    uint32_t al80, crew80, ridx; // derived forms of the alive flags, kept by the code that changes them (see Swar)
     uint32_t isel[NI];          // v_perm selector of imposter s's byte over the PAIR {hi word, lo word}
+    uint32_t iselb[NI];         // ... into ALL four bytes
     uint32_t ihot[NI];          // 0x80 at imposter s's byte if it is in my word
     uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes
     uint32_t jobs_obs[2], jd;   // observation bytes of the job cells; completed: 0x01 per job
@@ -50,9 +52,13 @@ __device__ __forceinline__ void to_swar2(const Consts &c, const Store &st, const
     w.xy = h ? f.xy[1] : f.xy[0];
     w.al = h ? f.al[1] : f.al[0];
     w.im80 = h ? f.im80[1] : f.im80[0];
+    w.al80 = h ? f.al80[1] : f.al80[0];
+    w.crew80 = h ? f.crew80[1] : f.crew80[0];
+    w.ridx = h ? f.ridx[1] : f.ridx[0];
 #pragma unroll
     for (int s = 0; s < Swar2<S>::NI; s++) {
         w.isel[s] = f.isel[s];
+        w.iselb[s] = f.iselb[s];
         w.ihot[s] = h ? f.ihot[s][1] : f.ihot[s][0];
     }
 #pragma unroll
@@ -112,25 +118,25 @@ __device__ __forceinline__ void gather_swar2(const Swar2<S> &w, Swar<S> &f) {
 // One step; act / R: MY word of the action bytes and of the turn ranks.  rr: the rewards of my four agents.
 // jm: the environment's column of the cell -> job map (susnet_swar.h JobMap; both lanes of a pair read the same column);
 // check_win: see step_swar.
+// realign: see step_swar (the caller aligned the event cursor once; a landed kill leaves it block-aligned for the next step).
 template <class S, class RNG, class MID = NoMid>
 __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e, RNG &rng, uint32_t act, uint32_t R, float (&rr)[4], bool &done,
-                                           bool &trunc, const JobMap &jm, bool check_win, MID &&mid = MID()) {
+                                           bool &trunc, const JobMap &jm, bool check_win, bool realign, MID &&mid = MID()) {
     using W = Swar2<S>;
     constexpr int A = W::A, J = W::J, NI = W::NI;
     const uint32_t h = w.h;
     e.m_steps += 1; // base.py:366
-    rng.align();
 
     // ---- action classes (0x80 per agent): alive agents only (base.py:477) --------------------------------------------------
     const uint32_t g5 = (act + 0x7b7b7b7bu) & k80, g6 = (act + 0x7a7a7a7au) & k80; // action index >= 5 / >= 6
-    const uint32_t al80 = (w.al << 7) & k80;
+    const uint32_t al80 = w.al80;
     uint32_t kill80, fix80 = 0, sab80 = 0, rows;
     if (W::kBase) { // crew: 5 = FIX; imposter: 5 = SABOTAGE, 6 = KILL (base.py:82-99)
         kill80 = g6 & al80;
         const uint32_t j5 = g5 & ~g6 & al80;
         sab80 = j5 & w.im80;
         fix80 = j5 & ~w.im80;
-        rows = act - (g6 >> 7);
+        rows = act; // (rows 5 and 6 of the table are both the identity: susnet_device.h kMoveRows)
     } else { // pred_prey.py:4-19: imposter 5 = KILL, no job actions
         kill80 = g5 & al80;
         rows = act;
@@ -159,60 +165,65 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
 
     // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
     uint32_t kc80 = 0, pend80 = 0;
+    uint32_t idx4 = w.ridx; // reward-table byte index per agent: the episode's base + what this step adds (see step_swar)
     bool changed = check_win; // something the win rules read moved this step (the same in both lanes of a pair)
     {
+        const uint64_t cur0 = rng.cur; // the step's (aligned) event cursor: a landed kill takes word cur0 + kills landed before it
         const Pair pk = both_halves(kill80), pr = both_halves(R), px = both_halves(w.xy);
-        uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot: kill flag (0x80 / 0), rank | 0x80, cell
+        uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot, in ALL four bytes: kill flag (0x80 / 0), rank | 0x80, cell
 #pragma unroll
         for (int s = 0; s < NI; s++) {
-            kb[s] = __builtin_amdgcn_perm(pk.hi, pk.lo, w.isel[s]);
-            rb[s] = __builtin_amdgcn_perm(pr.hi, pr.lo, w.isel[s]);
-            cb[s] = __builtin_amdgcn_perm(px.hi, px.lo, w.isel[s]);
+            kb[s] = __builtin_amdgcn_perm(pk.hi, pk.lo, w.iselb[s]);
+            rb[s] = __builtin_amdgcn_perm(pr.hi, pr.lo, w.iselb[s]);
+            cb[s] = __builtin_amdgcn_perm(px.hi, px.lo, w.iselb[s]);
         }
         bool second_first = false; // two imposters: the one with the earlier turn kills first
         if (NI == 2) second_first = kb[1] != 0u && (kb[0] == 0u || rb[1] < rb[0]);
+        uint32_t landed = 0; // kills this environment landed so far in this step
 #pragma unroll
         for (int it = 0; it < NI; it++) {
             const int s0 = it, s1 = NI - 1 - it;
             const uint32_t kbi = second_first ? kb[s1] : kb[s0], rbi = second_first ? rb[s1] : rb[s0], cbi = second_first ? cb[s1] : cb[s0];
-            const bool attempt = kbi != 0u;
-            if (__builtin_amdgcn_ballot_w64(attempt) != 0ull) {
-                const uint32_t tb = bcast_byte0(rbi & 0x7fu), cbb = bcast_byte0(cbi);
-                const uint32_t ge80 = (R - tb) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
-                const uint32_t pos = sel_bytes(ff_from80(ge80), w.xy, newt);
-                const uint32_t crew80 = (w.al << 7) & ~w.im80 & k80; // living crew NOW (base.py:535-542)
-                const uint32_t cand = attempt ? (zero80(pos ^ cbb) & crew80) : 0u;
-                const Pair pc = both_halves(cand);
-                const uint32_t nc = (uint32_t)__popc(pc.lo) + (uint32_t)__popc(pc.hi);
-                // (a crew member on the killer's cell is rare: the rest sits behind a second ballot)
-                if (__builtin_amdgcn_ballot_w64(nc != 0u) == 0ull) continue;
-                // base.py:497: uniform among the candidates (ascending agent index); with one candidate the lowest set flag
-                uint32_t v0 = pc.lo & (0u - pc.lo), v1 = pc.lo != 0u ? 0u : (pc.hi & (0u - pc.hi));
-                const uint64_t word_pos = rng.cur; // production protocol: one word per landed kill
-                if (!RNG::kNumpy) rng.cur += nc != 0u ? 1ull : 0ull;
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(nc > 1u) != 0ull, 0)) {
-                    if (nc > 1u) {
-                        if (!RNG::kNumpy) rng.cur = word_pos;
-                        const uint32_t r = rng.bounded(nc);
-                        uint32_t c0 = pc.lo, c1 = pc.hi;
-                        for (uint32_t k = 0; k < r; k++) {
-                            const bool lo = c0 != 0u;
-                            c0 = lo ? (c0 & (c0 - 1u)) : c0;
-                            c1 = lo ? c1 : (c1 & (c1 - 1u));
-                        }
-                        v0 = c0 & (0u - c0);
-                        v1 = c0 != 0u ? 0u : (c1 & (0u - c1));
+            // (no ballot on "somebody attempts" for the first kill turn: some environment of the wave nearly always does; the second
+            // turn only has work where BOTH imposters attempt)
+            if (it > 0 && __builtin_amdgcn_ballot_w64(kbi != 0u) == 0ull) continue;
+            const uint32_t ge80 = (R - (rbi & k7f)) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
+            const uint32_t pos = sel_bytes(ff_from80(ge80), w.xy, newt);
+            const uint32_t cand = zero80(pos ^ cbi) & w.crew80 & kbi; // living crew NOW on the killer's cell (base.py:535-542), if it attempts
+            // (a crew member on the killer's cell is rare: the rest -- the exchange between the two lanes included -- sits behind a ballot)
+            if (__builtin_amdgcn_ballot_w64(cand != 0u) == 0ull) continue;
+            const Pair pc = both_halves(cand);
+            const uint32_t nc = (uint32_t)__popc(pc.lo) + (uint32_t)__popc(pc.hi);
+            // base.py:497: uniform among the candidates (ascending agent index); with one candidate the lowest set flag
+            uint32_t v0 = pc.lo & (0u - pc.lo), v1 = pc.lo != 0u ? 0u : (pc.hi & (0u - pc.hi));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(nc > 1u) != 0ull, 0)) {
+                if (nc > 1u) {
+                    if (!RNG::kNumpy) rng.cur = cur0 + (uint64_t)landed; // production protocol: one word per landed kill, its value only matters here
+                    const uint32_t r = rng.bounded(nc);
+                    uint32_t c0 = pc.lo, c1 = pc.hi;
+                    for (uint32_t k = 0; k < r; k++) {
+                        const bool lo = c0 != 0u;
+                        c0 = lo ? (c0 & (c0 - 1u)) : c0;
+                        c1 = lo ? c1 : (c1 & (c1 - 1u));
                     }
+                    v0 = c0 & (0u - c0);
+                    v1 = c0 != 0u ? 0u : (c1 & (0u - c1));
                 }
-                const uint32_t v80 = h ? v1 : v0;
-                const bool hit = nc != 0u;
-                changed |= hit;
-                e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
-                w.al &= ~(v80 >> 7);     // base.py:511
-                const uint32_t hot = second_first ? w.ihot[s1] : w.ihot[s0];
-                kc80 |= hit ? hot : 0u;  // base.py:514-515 (the victim's slot ends as dead_penalty)
-                pend80 |= v80 & ge80;    // killed before its own turn: it never acts
             }
+            const uint32_t v80 = h ? v1 : v0;
+            const bool hit = nc != 0u;
+            if (!RNG::kNumpy) rng.cur = hit ? (realign ? cur0 + 4ull : cur0 + (uint64_t)landed + 1ull) : rng.cur;
+            landed += hit ? 1u : 0u;
+            changed |= hit;
+            e.m_kv += hit ? 1u : 0u; // IMP_KILLED_CREW, base.py:508
+            w.al &= ~(v80 >> 7);     // base.py:511
+            w.al80 &= ~v80;
+            w.crew80 &= ~v80;
+            w.ridx += v80 >> 3;      // the victim's rewards come from the "dead" rows from now on (base.py:562)
+            const uint32_t hot = hit ? (second_first ? w.ihot[s1] : w.ihot[s0]) : 0u;
+            kc80 |= hot;             // base.py:514-515 (the victim's slot ends as dead_penalty)
+            idx4 += (v80 >> 3) + (hot >> 5); // RC_KILL * 4 for the killer
+            pend80 |= v80 & ge80;    // killed before its own turn: it never acts
         }
     }
     w.xy = sel_bytes(ff_from80(pend80), w.xy, newt); // a victim that had not acted yet stays where it was
@@ -269,6 +280,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
                 w.jd = (jbits * 0x00204081u) & k01; // bits -> 0x01 per job byte
                 fc80 = h ? f2[1] : f2[0];
                 sc80 = h ? s2[1] : s2[0];
+                idx4 += (fc80 >> 4) + (sc80 >> 5) + (sc80 >> 4); // RC_FIX 2, RC_SAB 3, times 4
                 changed |= (f2[0] | f2[1] | s2[0] | s2[1]) != 0u;
             } else {
                 // bits -> 0x01 per job byte (see step_swar); without a crowd every job has at most one actor, so the sums are ORs
@@ -278,6 +290,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
                 w.jd ^= tog_env;
                 fc80 = succ & ~w.im80;
                 sc80 = succ & w.im80;
+                idx4 += (succ >> 4) + (sc80 >> 5); // RC_FIX 2 / RC_SAB 3, times 4
                 changed |= tog_env != 0u;
             }
         }
@@ -288,7 +301,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     done = false;
     if (W::kBase && J == 0) changed = true; // FourRoomEnv's "all jobs done" holds at every step when there are none (base.py:430)
     if (__builtin_amdgcn_ballot_w64(changed) != 0ull) { // (only when a kill landed / a job flipped this step: see step_swar)
-        const uint32_t mine = (uint32_t)__popc(w.al & k01) | ((uint32_t)__popc((w.al << 7) & w.im80 & k80) << 8);
+        const uint32_t mine = (uint32_t)__popc(w.al80) | ((uint32_t)__popc(w.al80 & w.im80) << 8);
         const Pair pa = both_halves(mine);
         const uint32_t sum = pa.lo + pa.hi;
         const int alive_all = (int)(sum & 0xffu), alive_imp = (int)(sum >> 8);
@@ -304,13 +317,11 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
         done = crew_won || imp_won;
         e.flags |= (crew_won ? FLAG_CREW_WON : 0u) | (imp_won ? FLAG_IMP_WON : 0u);
         wsel = crew_won ? 16u : (imp_won ? 32u : 0u);
+        idx4 += (wsel << 2) * k01; // the table's "crew won" / "imposters won" block
     }
-    // ---- rewards: one lookup per agent in the host-evaluated table [win][index < n_imposters][dead][assignment code] -------------
+    // ---- rewards: one lookup per agent in the host-evaluated table [win][index < n_imposters][dead][assignment code]; idx4 started
+    // from the episode's base (Swar2::ridx) and collected this step's assignment codes and outcome where they arose
     {
-        const uint32_t code4 = (kc80 >> 5) | (fc80 >> 4) | (sc80 >> 5) | (sc80 >> 4); // RC_KILL 1, RC_FIX 2, RC_SAB 3, times 4
-        const uint32_t dead16 = ((w.al & k01) ^ k01) << 4;
-        constexpr uint32_t neg32 = (NI >= 1 ? 0x20u : 0u) | (NI >= 2 ? 0x2000u : 0u); // indices [:n_imposters]: all in the low word
-        const uint32_t idx4 = code4 + dead16 + (h ? 0u : neg32) + (wsel << 2) * k01;
 #pragma unroll
         for (int i = 0; i < 4; i++) rr[i] = lds_reward_lookup((idx4 >> (8 * i)) & 0xffu);
     }

@@ -661,15 +661,54 @@ class BatchedFourRoomEnv:
         L.check(self.lib.susnet_record_layout(self._h, C.byref(lay)))
         return lay if lay.record_bytes else None
 
+    @staticmethod
+    def record_pieces(record_bytes: int):
+        """``[(start, width), ...]``: how a ``planar`` packed record is cut (susnet_record_layout_t: 16-byte pieces, then an 8- and / or a
+        4-byte piece).  Piece ``(s, w)`` of tick ``t`` is the ``[B][w]`` byte array at ``t * B * R + B * s``."""
+        full = record_bytes // 16 * 16
+        pieces = [(s, 16) for s in range(0, full, 16)]
+        rem = record_bytes - full
+        if rem >= 8:
+            pieces.append((full, 8))
+        if rem in (4, 12):
+            pieces.append((full + (8 if rem == 12 else 0), 4))
+        return pieces
+
+    def unpack_record(self, record: torch.Tensor) -> torch.Tensor:
+        """uint8 ``[T, B, record_bytes]`` records in field order (``susnet_record_layout_t`` offsets) from the buffer a packed rollout
+        wrote: the buffer itself where the handle stores whole records, a gathered COPY where it stores them as planes of 16-byte pieces
+        (``planar``: the multi-agent kernels)."""
+        lay = self.record_layout()
+        if not lay.planar:
+            return record
+        T, B, R = record.shape
+        flat = record.reshape(T, B * R)
+        out = torch.empty_like(record)
+        for s, w in self.record_pieces(R):
+            out[:, :, s:s + w] = flat[:, B * s:B * s + B * w].reshape(T, B, w)
+        return out
+
+    def record_fields(self, record: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """``actions / rewards / done / truncated / obs`` of a packed record buffer, shaped like the separate trajectory tensors: strided
+        VIEWS into the buffer for whole-record layouts, slices of the unpacked copy for planar ones."""
+        lay, A, F = self.record_layout(), self.n_agents, self.flattened_state_size
+        rec = self.unpack_record(record)
+        return {"rewards": rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].view(torch.float32) if not lay.planar else
+                           rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].contiguous().view(torch.float32),
+                "actions": rec[:, :, lay.off_actions:lay.off_actions + A],
+                "done": rec[:, :, lay.off_done].view(torch.bool), "truncated": rec[:, :, lay.off_truncated].view(torch.bool),
+                "obs": rec[:, :, lay.off_obs:lay.off_obs + F]}
+
     def alloc_rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None,
                       packed: bool = False, replay_feed: bool = False):
         """Allocate (once) the trajectory buffers a fused rollout of up to ``n_ticks`` ticks writes:
         actions u8 [T, B, A], rewards f32 [T, B, A], done / truncated bool [T, B], obs [T, B, ...].
 
         ``packed=True`` (compiled-in configurations, full trajectory + raw uint8 observation only): ONE buffer
-        ``record`` u8 [T, B, record_bytes] holding the same fields per env-step, which a lane writes with one or two wide
-        stores; the returned ``actions / rewards / done / truncated / obs`` are strided VIEWS into it (same shapes and
-        dtypes as the separate tensors).
+        ``record`` u8 [T, B, record_bytes] holding the same fields per env-step, which a lane writes with a few wide
+        stores; for whole-record layouts the returned ``actions / rewards / done / truncated / obs`` are strided VIEWS into it
+        (same shapes and dtypes as the separate tensors); the multi-agent kernels store the record as planes of 16-byte pieces
+        (``record_layout().planar``): ``record_fields`` / ``unpack_record`` gather it after a launch.
 
         ``replay_feed=True`` (full trajectory + raw uint8 observation): also ``term_obs`` u8 [T, B, S] -- written only where
         an episode ended: its true terminal state -- and ``roles`` int16 [T, B] (imposter bitmask of the acting episode): what
@@ -682,13 +721,11 @@ class BatchedFourRoomEnv:
             assert set(store) == {"actions", "rewards", "done", "truncated"} and obs is not None and obs.mode == "raw" \
                 and obs.dtype == torch.uint8, "packed=True carries the full trajectory and the raw uint8 observation"
             rec = torch.empty(T, B, lay.record_bytes, dtype=torch.uint8, device=self.device)
-            F = self.flattened_state_size
             out["record"] = rec
-            out["rewards"] = rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].view(torch.float32)
-            out["actions"] = rec[:, :, lay.off_actions:lay.off_actions + A]
-            out["done"] = rec[:, :, lay.off_done].view(torch.bool)
-            out["truncated"] = rec[:, :, lay.off_truncated].view(torch.bool)
-            out["obs"] = rec[:, :, lay.off_obs:lay.off_obs + F]
+            if not lay.planar:  # whole records: the fields are views that every launch refreshes
+                out.update(self.record_fields(rec))
+            # (planar records -- the multi-agent kernels: the fields are gathered after a launch, `record_fields(bufs["record"])`;
+            # `rollout()` does it)
             return out
         if "actions" in store:
             out["actions"] = torch.empty(T, B, A, dtype=torch.uint8, device=self.device)
@@ -740,6 +777,8 @@ class BatchedFourRoomEnv:
         Returns a dict of trajectory tensors with a leading tick dimension."""
         bufs = self.alloc_rollout(n_ticks, store, obs, packed=packed)
         self.rollout_into(n_ticks, bufs)
+        if packed and "actions" not in bufs:  # planar records: gather the fields (copies)
+            bufs.update(self.record_fields(bufs["record"]))
         return bufs
 
     def observe(self, obs: Optional[ObsConfig] = None):

@@ -617,7 +617,7 @@ def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch
                        (lay.off_obs, env.flattened_state_size)):
             assert not used[off:off + n].any(), "record fields overlap"
             used[off:off + n] = True
-        assert not np_(traj["record"])[:, :, ~used].any(), "padding bytes are zero"
+        assert not np_(env.unpack_record(traj["record"]))[:, :, ~used].any(), "padding bytes are zero"
     env._export(full=True)
     compare_full_state(env, ob, f"{name} after packed rollouts")
 
