@@ -264,6 +264,12 @@ typedef struct susnet_record_layout_t {
      * P(o) = the start of o's piece, W(o) its width: with full = record_bytes / 16 * 16, P(o) = o / 16 * 16, W = 16 for o < full;
      * then an 8-byte piece when record_bytes - full >= 8, then a 4-byte piece when record_bytes - full is 4 or 12. */
     int32_t planar;
+    /* The raw observation (flatten_state order, obs_raw_size bytes) as the concatenation of n_obs_segments byte ranges of the record.
+     * One segment (off_obs, obs_raw_size) for the fully compiled-in games; the multi-agent FAMILY kernels (any job count up to 8)
+     * keep a record layout that does not depend on the job count -- eight job slots -- and report up to four segments: cells + alive,
+     * job cells, job status, the tagging tail.  off_obs = the first segment's offset. */
+    int32_t n_obs_segments;
+    struct { int32_t off, len; } obs_segments[4];
 } susnet_record_layout_t;
 int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out);
 

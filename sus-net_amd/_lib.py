@@ -96,7 +96,8 @@ class PolicyOpts(C.Structure):
 
 class RecordLayout(C.Structure):
     _fields_ = [("record_bytes", C.c_int32), ("off_rewards", C.c_int32), ("off_actions", C.c_int32), ("off_done", C.c_int32),
-                ("off_truncated", C.c_int32), ("off_obs", C.c_int32), ("planar", C.c_int32)]
+                ("off_truncated", C.c_int32), ("off_obs", C.c_int32), ("planar", C.c_int32), ("n_obs_segments", C.c_int32),
+                ("obs_segments", (C.c_int32 * 2) * 4)]
 
 
 class StateView(C.Structure):

@@ -14,13 +14,32 @@
 #include <type_traits>
 
 #include "susnet_kernels.h"
+#include "susnet_family.h"
 #include "susnet_qnet.h"
 
 namespace susnet {
 SUSNET_DECLARE(GenericSpec) SUSNET_DECLARE(SpecCfg2) SUSNET_DECLARE(SpecCfg3) SUSNET_DECLARE(SpecCfg4) SUSNET_DECLARE(SpecTag5)
 SUSNET_DECLARE(SpecA<2>) SUSNET_DECLARE(SpecA<3>) SUSNET_DECLARE(SpecA<4>) SUSNET_DECLARE(SpecA<5>) SUSNET_DECLARE(SpecA<6>) SUSNET_DECLARE(SpecA<7>) SUSNET_DECLARE(SpecA<8>)
+#define X SUSNET_FAMILY_DECLARE
+SUSNET_FAMILY(X)
+#undef X
 } // namespace susnet
 using namespace susnet;
+
+// the byte-parallel family (susnet_family.h): which instantiation serves (agents, variant, order, imposters), and its launchers
+struct FamilyEntry {
+    int A, variant, order_random, n_imp;
+    void (*rollout)(bool, int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &);
+    void (*step)(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
+    int record_dwords, head_dwords, tagging;
+};
+#define X(A_, V_, O_, N_) {A_, V_, O_, N_, &launch_rollout<SpecFam<A_, V_, O_, N_>>, &launch_step<SpecFam<A_, V_, O_, N_>>, \
+                           FamRecord<SpecFam<A_, V_, O_, N_>>::kDwords, FamRecord<SpecFam<A_, V_, O_, N_>>::kHeadDwords, V_ == SUSNET_VARIANT_TAGGING},
+static const FamilyEntry kFamily[] = {SUSNET_FAMILY(X)};
+#undef X
+constexpr int kFamilySpecBase = 100; // pick_spec() values kFamilySpecBase + i = kFamily[i]
+static inline bool is_family(int spec) { return spec >= kFamilySpecBase; }
+static inline bool is_swar_spec(int spec) { return spec == 3 || spec == 4 || spec == 6 || is_family(spec); }
 
 // ---------------------------------------------------------------------------------------------------
 // kernels
@@ -312,7 +331,11 @@ static int pick_spec(const Consts &c, bool float_exact, bool force_generic) {
     if (c.A == 3 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 1) return 3;
     if (c.A == 8 && c.J == 4 && c.variant == SUSNET_VARIANT_BASE && c.order_random && c.n_imp == 2) return 4;
     if (c.A == 5 && c.J == 5 && c.variant == SUSNET_VARIANT_TAGGING && c.order_random && c.n_imp == 1) return 6;
-    if (c.A >= 2 && c.A <= 8 && c.J <= 8) return 10 + c.A; // SpecA<A>
+    if (c.J <= 8) // the byte-parallel family: any job count up to 8, roles shuffled or not
+        for (size_t i = 0; i < sizeof(kFamily) / sizeof(kFamily[0]); i++)
+            if (kFamily[i].A == c.A && kFamily[i].variant == c.variant && kFamily[i].order_random == (c.order_random ? 1 : 0) && kFamily[i].n_imp == c.n_imp)
+                return kFamilySpecBase + (int)i;
+    if (c.A >= 2 && c.A <= 8 && c.J <= 8) return 10 + c.A; // SpecA<A>: the per-turn kernels (1v1 on a wall map, three or more imposters)
     return 0;
 }
 
@@ -766,7 +789,7 @@ static int build_obs(const susnet_env *env, const susnet_obs_spec *spec, ObsArgs
 // rollout: the launch is a fused rollout (the byte-parallel ones also keep the cell -> job map there: susnet_swar.h JobMap)
 static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset, int spec = 0, bool rollout = false) {
     const Consts &c = env->c;
-    const bool swar = spec == 3 || spec == 4 || spec == 6;
+    const bool swar = is_swar_spec(spec);
     size_t core = (size_t)lds_core_words(c.A, c.J, spec == 0, swar, (swar && rollout) ? c.N : 0) * 4;
     size_t perm = (may_reset && env->cfg.rng_mode == SUSNET_RNG_TAPE) ? (size_t)c.n_valid * kBlock : 0;
     size_t stage = (size_t)(o.words1 + o.words2) * 4;
@@ -1054,7 +1077,8 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
         env->ticks += 1;
         return SUSNET_OK;
     }
-    switch (spec) {
+    if (is_family(spec)) kFamily[spec - kFamilySpecBase].step(tape, g, blk, sh, st, env->c, env->s, a, o);
+    else switch (spec) {
     case 2: launch_step<SpecCfg2>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     case 3: launch_step<SpecCfg3>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     case 4: launch_step<SpecCfg4>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
@@ -1095,8 +1119,30 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
     if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
     const int spec = env->spec; // (TAPE handles too: the reference's numpy streams run through the same kernels)
-    if (spec != 2 && spec != 3 && spec != 4 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode
     const int A = env->c.A, F = env->layout.obs_raw_size;
+    if (is_family(spec)) { // FamRecord (susnet_kernels.h): a layout independent of the job count, the observation in segments
+        const FamilyEntry &fe = kFamily[spec - kFamilySpecBase];
+        const int J = env->c.J;
+        out->record_bytes = 4 * fe.record_dwords;
+        out->off_rewards = 0;
+        out->off_actions = 4 * A;
+        const int head_bytes = A + 3 * A + (fe.tagging ? 2 * A + 1 : 0) + 2;
+        out->off_done = 4 * A + head_bytes - 2;
+        out->off_truncated = out->off_done + 1;
+        out->off_obs = 5 * A;
+        const int off_cells = 4 * (A + fe.head_dwords);
+        int n = 0;
+        out->obs_segments[n].off = 5 * A; out->obs_segments[n++].len = 3 * A;            // cells, alive
+        if (J > 0 || fe.tagging) {
+            out->obs_segments[n].off = off_cells; out->obs_segments[n++].len = 2 * J;    // job cells
+            out->obs_segments[n].off = off_cells + 16; out->obs_segments[n++].len = J;   // job status
+        }
+        if (fe.tagging) { out->obs_segments[n].off = 8 * A; out->obs_segments[n++].len = 2 * A + 1; } // used, counts, steps until the vote
+        out->n_obs_segments = n;
+        out->planar = 1;
+        return SUSNET_OK;
+    }
+    if (spec != 2 && spec != 3 && spec != 4 && spec != 6) return SUSNET_OK; // record_bytes = 0: no packed mode
     out->off_rewards = 0;
     out->off_actions = 4 * A;
     out->off_done = 5 * A;
@@ -1113,6 +1159,9 @@ extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_
         out->off_truncated = 5 * A + F + 1;
         out->planar = 1; // stored as planes of 16-byte pieces (susnet_kernels.h store_record_planar)
     }
+    out->n_obs_segments = 1;
+    out->obs_segments[0].off = out->off_obs;
+    out->obs_segments[0].len = F;
     return SUSNET_OK;
 }
 
@@ -1197,7 +1246,8 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             if (a.term_obs) a.term_obs += (uint64_t)chunk * (uint64_t)o.tick_stride;
             if (a.roles) a.roles += (uint64_t)chunk * (uint64_t)env->c.B;
         }
-        switch (spec) {
+        if (is_family(spec)) kFamily[spec - kFamilySpecBase].rollout(tape, out, g, blk, sh, st, env->c, env->s, a, o);
+        else switch (spec) {
         case 2: launch_rollout<SpecCfg2>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         case 3: launch_rollout<SpecCfg3>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         case 4: launch_rollout<SpecCfg4>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;

@@ -910,8 +910,8 @@ __device__ __forceinline__ uint32_t bcast_byte0(uint32_t v) { return __builtin_a
 // R[w]: byte i % 4 of word i / 4 = rank[i] | 0x80 (the flag bit makes the byte-wise compare below borrow-free).
 // have_rem: the caller sampled this tick's actions just before through the same ActionStream (its `rem` is valid);
 // otherwise the shared word's remainder is rebuilt from the action ranges.
-template <class S, int POS = -1, int NW>
-__device__ __forceinline__ void ranks_from_stream(const Consts &c, uint32_t imp_bits, PhiloxRng &rng, ActionStream &as, uint64_t tick, bool have_rem,
+template <class S, int POS = -1, int NW, class AS = ActionStream>
+__device__ __forceinline__ void ranks_from_stream(const Consts &c, uint32_t imp_bits, PhiloxRng &rng, AS &as, uint64_t tick, bool have_rem,
                                                   uint32_t (&R)[NW]) {
     const int A = S::A(c);
     const uint64_t W = (uint64_t)S::aw_W(c);

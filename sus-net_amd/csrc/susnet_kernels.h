@@ -373,6 +373,22 @@ struct RecordLayout {
     static constexpr int kBytesTail = (S::kA > 0 ? S::kA : 0) + 2 + (S::kRawF > 0 ? S::kRawF : 0);
     static constexpr int kDwords = (S::kA > 0 ? S::kA : 0) + (kBytesTail + 3) / 4;
 };
+// The packed record of the byte-parallel FAMILY (job count read at run time: susnet_swar.h): a layout that does not depend on the job
+// count -- rewards f32[A] | actions u8[A] | cells 2A | alive A | [tagging: used A | counts A | steps until the vote] | done | truncated |
+// 0-padding to a dword | EIGHT job-cell slots (16 bytes) | EIGHT job-status slots (8 bytes) -- so that it is assembled from registers
+// with static byte moves and stored as planes like the compiled-in records.  The raw observation (flatten_state order) is the
+// concatenation of up to four SEGMENTS of it (susnet_record_layout_t::obs_segments): cells + alive, 2J job-cell bytes, J status bytes,
+// the tagging tail.
+template <class S>
+struct FamRecord {
+    static constexpr int A = S::kA > 0 ? S::kA : 1;
+    static constexpr bool kTag = S::kVar == SUSNET_VARIANT_TAGGING;
+    static constexpr int kHeadBytes = A + 3 * A + (kTag ? 2 * A + 1 : 0) + 2;
+    static constexpr int kHeadDwords = (kHeadBytes + 3) / 4;
+    static constexpr int kDwords = A + kHeadDwords + 4 + 2;
+    static constexpr int kOffActions = 4 * A, kOffCells = 5 * A, kOffTag = 8 * A, kOffDone = 4 * A + kHeadBytes - 2,
+                         kOffJobCells = 4 * (A + kHeadDwords), kOffJobStatus = kOffJobCells + 16;
+};
 template <class S, int OUT, class RNG = PhiloxRng>
 __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutArgs a, ObsArgs o) {
     extern __shared__ uint32_t smem[];
@@ -701,7 +717,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     }
     constexpr bool kFlat = OUT == OUT_TRAJ_FLAT; // (cooperative feature stores: every lane stays)
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ || kFlat;
-    if (((kTraj && !kFlat) || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
+    // the family's raw row has a run-time length: it goes through the cooperative LDS writer (every lane stays)
+    constexpr bool kCoopRaw = OUT == OUT_TRAJ_RAW8 && S::kRawF < 0;
+    if (((kTraj && !kFlat && !kCoopRaw) || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
     W w;
     to_swar<S>(c, st, e, w);
     uint64_t tick_base = a.tick_base;
@@ -728,7 +746,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     FlatRowT frow;
     frow.clear();
     constexpr bool kRec = OUT == OUT_RECORD; // one packed record per env-step: rewards f32[A] | actions u8[A] | raw obs u8[F] | done | truncated | 0-padding
-    constexpr int kRecDwords = RecordLayout<S>::kDwords;
+    constexpr bool kFam = S::kRawF < 0;      // run-time job count: the family's record layout (FamRecord)
+    constexpr int kRecDwords = kFam ? FamRecord<S>::kDwords : RecordLayout<S>::kDwords;
     BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, 0u); // (planes: store_record_planar adds the piece offsets)
     const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
     if (active && a.n_ticks > 0) {
@@ -737,7 +756,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     }
     // production stream: the words of a group of 4 ticks (whole Philox blocks) are generated at the group's first tick and staged
     // in LDS (GroupWords); the tick loop is rolled -- one copy of the step and of the reset path
-    static_assert(HasGroupWords<S>::value && (RankLut<S>::kOk || S::kOrd == 0), "grouped action stream; a shuffled order comes from the rank tables");
+    static_assert(HasGroupWords<S>::value, "grouped action stream");
+    // (a shuffled order comes from the rank tables where the tick's shuffle digits sit in the words the tables assume -- RankLut::kOk;
+    // elsewhere from the insertion rule itself, ranks_from_stream)
     using GW = GroupWords<S::kAw.W, false>;
     GW gw;
     gw.init(kGroupWordsWord<S>(), tid);
@@ -754,9 +775,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
 #else
 #define KSTAMP(k) do {} while (0)
 #endif
-    uint32_t act_n[NW];
+    uint32_t act_n[NW], R_n[NW];
     RankRaw raw_n = {0u, 0u, 0u, 0u};
     TickWords<GW::W> tw_n;
+    identity_ranks<S>(R_n);
 #pragma unroll
     for (int q = 0; q < NW; q++) act_n[q] = 0u;
 #pragma unroll
@@ -779,6 +801,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             TickWords<GW::W> tw = tw_n;
             sample_actions_swar<S, 0>(c, w, rng, tw, 0ull, act_n);
             if constexpr (RankLut<S>::kOk) raw_n = ranks_lut_issue<S, 0>(rng, tw, 0ull);
+            else if constexpr (S::kOrd > 0) ranks_from_stream<S, 0>(c, 0u, rng, tw, 0ull, true, R_n);
         }
     };
     if (!RNG::kNumpy && active && a.n_ticks > 0) {
@@ -813,7 +836,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
 #pragma unroll
                 for (int q = 0; q < NW; q++) act[q] = act_n[q];
                 if constexpr (RankLut<S>::kOk) ranks_lut_finish<S>(raw_n, R); // stage C
-                else identity_ranks<S>(R);
+                else {
+#pragma unroll
+                    for (int q = 0; q < NW; q++) R[q] = R_n[q];
+                }
                 stage_a(tick + 1, false); // (also past the launch's last tick: nothing of it is kept)
                 KSTAMP(0);
             }
@@ -856,9 +882,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 if (fin) {
                     life.add_episode(e, trunc);
                     if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
-                        uint32_t trow[(kRawF + 3) / 4];
-                        raw_row_swar<S>(w, trow, (uint32_t)c.tag_interval);
-                        store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+                        if constexpr (kFam) { // (run-time row length: byte by byte, from the store form -- rare path)
+                            from_swar<S>(c, w, st, e);
+                            fill_raw<S>(c, st, e, a.term_obs + ((int64_t)tick * c.B + b) * o.F);
+                        } else {
+                            uint32_t trow[(kRawF + 3) / 4];
+                            raw_row_swar<S>(w, trow, (uint32_t)c.tag_interval);
+                            store_packed_bytes<kRawF>(PtrDst{a.term_obs + ((int64_t)tick * c.B + b) * kRawF}, trow);
+                        }
                     }
                     jm.clear_jobs(st, S::J(c)); // the finished episode's job cells leave the map, the new ones enter
                     if constexpr (RNG::kNumpy) {
@@ -883,7 +914,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 }
             }
             KSTAMP(3);
-            if (OUT == OUT_TRAJ_RAW8) {
+            if constexpr (OUT == OUT_TRAJ_RAW8 && !kFam) {
                 uint32_t row[(kRawF + 3) / 4];
                 raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
                 store_packed_bytes<kRawF>(dobs, row);
@@ -899,7 +930,44 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 }
                 frow.build(fx, fy, fal);
             }
-            if (kRec) { // (byte moves between statically known positions: the compiler folds them into v_perm / v_alignbyte)
+            if constexpr (kRec && kFam) { // the family's record (FamRecord): nothing in it depends on the job count
+                using FR = FamRecord<S>;
+                uint8_t by[FR::kHeadDwords * 4];
+                int k = 0;
+#pragma unroll
+                for (int i = 0; i < A; i++) by[k++] = (uint8_t)(act[i / 4] >> (8 * (i & 3)));
+#pragma unroll
+                for (int i = 0; i < A; i++) { // cells as flatten_state has them: x0 y0 x1 y1 ...
+                    const uint32_t cell = w.xy[i / 4] >> (8 * (i & 3));
+                    by[k++] = (uint8_t)(cell & 15u);
+                    by[k++] = (uint8_t)((cell >> 4) & 15u);
+                }
+#pragma unroll
+                for (int i = 0; i < A; i++) by[k++] = (uint8_t)((w.al[i / 4] >> (8 * (i & 3))) & 1u);
+                if (W::kTag) { // tagging.py:220-230: used_tag_actions, tag_counts, steps until the vote
+#pragma unroll
+                    for (int i = 0; i < A; i++) by[k++] = (uint8_t)((w.used[i / 4] >> (8 * (i & 3))) & 1u);
+#pragma unroll
+                    for (int i = 0; i < A; i++) by[k++] = (uint8_t)(w.cnt[i / 4] >> (8 * (i & 3)));
+                    by[k++] = (uint8_t)((uint32_t)c.tag_interval - w.timer);
+                }
+                by[k++] = done ? 1 : 0;
+                by[k++] = trunc ? 1 : 0;
+#pragma unroll
+                for (; k < FR::kHeadDwords * 4; k++) by[k] = 0;
+                uint32_t rec[kRecDwords];
+#pragma unroll
+                for (int i = 0; i < A; i++) rec[i] = __float_as_uint(rr[i]);
+#pragma unroll
+                for (int q = 0; q < FR::kHeadDwords; q++)
+                    rec[A + q] = (uint32_t)by[4 * q] | ((uint32_t)by[4 * q + 1] << 8) | ((uint32_t)by[4 * q + 2] << 16) | ((uint32_t)by[4 * q + 3] << 24);
+#pragma unroll
+                for (int q = 0; q < 4; q++) rec[A + FR::kHeadDwords + q] = w.jobs_obs[q]; // the eight job-cell slots (x, y bytes; zeros past the job count)
+                rec[A + FR::kHeadDwords + 4] = w.jd[0];                                    // the eight job-status slots
+                rec[A + FR::kHeadDwords + 5] = w.jd[W::JW - 1];
+                store_record_planar<kRecDwords>(drec, (uint32_t)c.B, (uint32_t)bb, rec);
+            }
+            if constexpr (kRec && !kFam) { // (byte moves between statically known positions: the compiler folds them into v_perm / v_alignbyte)
                 uint32_t row[(kRawF + 3) / 4];
                 raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
                 constexpr int kNB = A + 2 + kRawF;
@@ -933,6 +1001,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         if (OUT == OUT_ANY) { // any observation mode: through the cooperative writer, on the bitmask / packed-store form
             if (active) from_swar<S>(c, w, st, e);
             write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        }
+        if constexpr (kCoopRaw) { // the family's raw uint8 rows (run-time length): the wave's rows built in LDS, copied out in 16-byte pieces
+            if (active) from_swar<S>(c, w, st, e);
+            write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
         }
         if constexpr (kFlat) flat_store_wave(frow, T.stage, tid, nrows, dflat.r, dflat.vo + (uint32_t)tick * (slab_o * 4u));
     };
@@ -1426,11 +1498,12 @@ void launch_step(bool tape, dim3 g, dim3 blk, size_t sh, hipStream_t st, const C
     if (tape) hipLaunchKernelGGL((k_step<TapeRng, SPEC>), g, blk, sh, st, c, s, a, o);
     else hipLaunchKernelGGL((k_step<PhiloxRng, SPEC>), g, blk, sh, st, c, s, a, o);
 }
-#define SUSNET_DECLARE(SPEC)                                                                                              \
-    extern template void launch_rollout<SPEC>(bool, int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
-    extern template void launch_step<SPEC>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
-#define SUSNET_INSTANTIATE(SPEC)                                                                                          \
-    template void launch_rollout<SPEC>(bool, int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
-    template void launch_step<SPEC>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
+// (variadic: a specialisation's name may contain commas)
+#define SUSNET_DECLARE(...)                                                                                               \
+    extern template void launch_rollout<__VA_ARGS__>(bool, int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
+    extern template void launch_step<__VA_ARGS__>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
+#define SUSNET_INSTANTIATE(...)                                                                                           \
+    template void launch_rollout<__VA_ARGS__>(bool, int, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const RolloutArgs &, const ObsArgs &); \
+    template void launch_step<__VA_ARGS__>(bool, dim3, dim3, size_t, hipStream_t, const Consts &, const State &, const StepArgs &, const ObsArgs &);
 
 } // namespace susnet

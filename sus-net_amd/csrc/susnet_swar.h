@@ -29,7 +29,9 @@ namespace susnet {
 
 template <class S>
 struct UseSwar {
-    static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kA <= 8 && S::kJ >= 0 && S::kJ <= 8 && S::kOrd >= 0 &&
+    // (kJ = -1: the job count is read at run time -- at most 8 -- : the FAMILY of byte-parallel kernels, one instantiation per agent
+    // count, variant, order and imposter count, serving every job count: susnet_kernels.h SpecFam)
+    static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kA <= 8 && S::kJ >= -1 && S::kJ <= 8 && S::kOrd >= 0 &&
                                   (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG || S::kVar == SUSNET_VARIANT_TAGGING) &&
                                   (S::kNI == 1 || S::kNI == 2);
 };
@@ -140,7 +142,8 @@ struct TickWords {
 
 template <class S>
 struct Swar {
-    static constexpr int A = S::kA, J = S::kJ, NW = (S::kA + 3) / 4, NI = S::kNI > 0 ? S::kNI : 1, JW = S::kJ > 4 ? 2 : 1;
+    // J: the compiled-in job count, or -1 = run time (then JMAX = 8 slots are carried and every loop over jobs is guarded)
+    static constexpr int A = S::kA, J = S::kJ, JMAX = S::kJ >= 0 ? S::kJ : 8, NW = (S::kA + 3) / 4, NI = S::kNI > 0 ? S::kNI : 1, JW = JMAX > 4 ? 2 : 1;
     static constexpr bool kTag = S::kVar == SUSNET_VARIANT_TAGGING;
     static constexpr bool kBase = S::kVar != SUSNET_VARIANT_ITG; // FourRoomEnv action lists (base.py:82-99); tagging.py appends the tag actions
     uint32_t xy[NW];           // cell x | y << 4, one byte per agent
@@ -154,8 +157,8 @@ struct Swar {
     uint32_t isel[NI];         // v_perm selector that extracts imposter s's byte (zeros elsewhere)
     uint32_t iselb[NI];        // v_perm selector that puts imposter s's byte into ALL four bytes
     uint32_t ihot[NI][NW];     // 0x80 at imposter s's byte
-    uint32_t jb[J > 0 ? J : 1]; // job cell in all four bytes (constant within an episode)
-    uint32_t jobs_obs[J > 4 ? 4 : 2]; // x0 y0 x1 y1 | x2 y2 x3 y3 | ... of the job cells (observation bytes; constant within an episode)
+    uint32_t jb[JMAX > 0 ? JMAX : 1]; // job cell in all four bytes (constant within an episode)
+    uint32_t jobs_obs[JMAX > 4 ? 4 : 2]; // x0 y0 x1 y1 | x2 y2 x3 y3 | ... of the job cells (observation bytes; constant within an episode)
     uint32_t jd[JW];           // completed: 0x01 per job
     uint32_t nact[A];          // len(agent_action_map[i]) (constant within an episode)
     // tagging.py: used_tag_actions (0x01 per agent), tag_counts (one byte per agent), tag_reset_timer
@@ -216,12 +219,13 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
 #pragma unroll
     for (int q = 0; q < W::JW; q++) w.jd[q] = 0;
 #pragma unroll
-    for (int q = 0; q < (W::J > 4 ? 4 : 2); q++) w.jobs_obs[q] = 0;
+    for (int q = 0; q < (W::JMAX > 4 ? 4 : 2); q++) w.jobs_obs[q] = 0;
+    const int Jr = S::J(c);
 #pragma unroll
-    for (int j = 0; j < W::J; j++) {
-        const uint32_t cell = st.job(j);
+    for (int j = 0; j < W::JMAX; j++) {
+        const uint32_t cell = j < Jr ? st.job(j) : 0u;
         w.jb[j] = cell * k01;
-        w.jd[j / 4] |= ((e.jd >> j) & 1u) << (8 * (j & 3));
+        w.jd[j / 4] |= (j < Jr ? (e.jd >> j) & 1u : 0u) << (8 * (j & 3));
         w.jobs_obs[j / 2] |= ((cell & 15u) | ((cell >> 4) << 8)) << (16 * (j & 1));
     }
 }
@@ -238,7 +242,7 @@ __device__ __forceinline__ void from_swar(const Consts &c, const Swar<S> &w, Sto
         e.alive |= ((w.al[q] >> sh) & 1u) << i;
     }
 #pragma unroll
-    for (int j = 0; j < W::J; j++) e.jd |= ((w.jd[j / 4] >> (8 * (j & 3))) & 1u) << j;
+    for (int j = 0; j < W::JMAX; j++) e.jd |= ((w.jd[j / 4] >> (8 * (j & 3))) & 1u) << j; // (slots past the job count hold 0)
     if (W::kTag) {
         e.used = 0;
 #pragma unroll
@@ -462,7 +466,8 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 #define WSTAMP(k) do {} while (0)
 #endif
     using W = Swar<S>;
-    constexpr int A = W::A, J = W::J, NW = W::NW, NI = W::NI;
+    constexpr int A = W::A, J = W::JMAX, NW = W::NW, NI = W::NI; // (J: job SLOTS; the job count itself is Jn)
+    const int Jn = S::J(c);
     constexpr uint32_t kLive[2] = {A >= 4 ? 0xffffffffu : (1u << (8 * (A & 3))) - 1u, A >= 8 ? 0xffffffffu : (A > 4 ? (1u << (8 * (A & 3))) - 1u : 0u)};
     e.m_steps += 1; // base.py:366
     // production protocol: the event cursor is block-aligned at the start of a step.  It only ever moves in the kill tail (one word
@@ -735,7 +740,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             uint32_t n = 0, n_on = 0;
 #pragma unroll
             for (int q = 0; q < NW; q++) {
-                on[j][q] = zero80(w.xy[q] ^ w.jb[j]) & ja80[q];
+                on[j][q] = (W::J >= 0 || j < Jn) ? zero80(w.xy[q] ^ w.jb[j]) & ja80[q] : 0u; // (a slot past a run-time job count matches nobody)
                 n_on += (uint32_t)__popc(on[j][q]);
                 const uint32_t succ = on[j][q] & ~(w.im80[q] ^ dj80); // crew (flag 0) on an open job, imposter (0x80) on a completed one
                 acted[q] |= succ;
@@ -887,7 +892,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
     uint32_t wsel = 0u; // reward-table row of THIS step's outcome: 0 none, 16 crew won, 32 imposters won
     done = false;
-    bool win_inputs_changed = check_win || (W::kBase && J == 0); // (J == 0: FourRoomEnv's "all jobs done" holds at every step, base.py:430)
+    bool win_inputs_changed = check_win || (W::kBase && Jn == 0); // (no jobs: FourRoomEnv's "all jobs done" holds at every step, base.py:430)
     if (!win_inputs_changed) { // alive flags / job status moved this step?
         uint32_t ev = 0;
 #pragma unroll
@@ -906,10 +911,10 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         for (int q = 0; q < W::JW; q++) done_jobs += __popc(w.jd[q]);
         bool crew_won, imp_won; // (selects, no branches: every lane evaluates both rules)
         if (!W::kBase) {
-            crew_won = J != 0 && done_jobs == J;
+            crew_won = Jn != 0 && done_jobs == Jn;
             imp_won = !crew_won && alive_all - alive_imp == 0;
         } else {
-            crew_won = alive_imp == 0 || done_jobs == J;
+            crew_won = alive_imp == 0 || done_jobs == Jn;
             imp_won = !crew_won && alive_all - alive_imp <= alive_imp;
         }
         done = crew_won || imp_won;

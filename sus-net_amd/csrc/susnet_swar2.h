@@ -16,7 +16,7 @@ namespace susnet {
 
 template <class S>
 struct UseSplit {
-    static constexpr bool value = UseSwar<S>::value && S::kA == 8 && S::kVar != SUSNET_VARIANT_TAGGING && S::kJ <= 4;
+    static constexpr bool value = UseSwar<S>::value && S::kA == 8 && S::kVar != SUSNET_VARIANT_TAGGING && S::kJ >= 0 && S::kJ <= 4;
 };
 
 struct Pair {

@@ -611,9 +611,12 @@ class BatchedFourRoomEnv:
     def supports_qnet_policy_step(self, net: "PackedQNet") -> bool:
         """Whether ``qnet_policy_step`` serves this env: the compiled-in 1v1 9x9 ITG / 1v2 14x14 4-job games on the production stream
         (a packed record layout exists exactly for the compiled-in games, and among them the agent count names the game)."""
-        if self.rng_kind != "philox" or net.dims[-1] != self.n_imposter_actions or self.record_layout() is None:
+        if self.rng_kind != "philox" or net.dims[-1] != self.n_imposter_actions:
             return False
-        return (self.n_agents, self.n_rows) in ((2, 9), (3, 14))
+        lay = self.record_layout()
+        if lay is None or lay.n_obs_segments != 1:  # (one observation segment: a fully compiled-in game, not a family kernel)
+            return False
+        return (self.VARIANT, self.n_agents, self.n_jobs, self.n_rows) in ((L.VARIANT_ITG, 2, 0, 9), (L.VARIANT_BASE, 3, 4, 14))
 
     def qnet_policy_step(self, net: "PackedQNet", actions_out: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None,
                          epsilon: float = 0.0, mask_dead: bool = False):
@@ -697,7 +700,8 @@ class BatchedFourRoomEnv:
                            rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].contiguous().view(torch.float32),
                 "actions": rec[:, :, lay.off_actions:lay.off_actions + A],
                 "done": rec[:, :, lay.off_done].view(torch.bool), "truncated": rec[:, :, lay.off_truncated].view(torch.bool),
-                "obs": rec[:, :, lay.off_obs:lay.off_obs + F]}
+                "obs": (rec[:, :, lay.off_obs:lay.off_obs + F] if lay.n_obs_segments == 1 else  # (several segments: the family kernels' records)
+                        torch.cat([rec[:, :, lay.obs_segments[k][0]:lay.obs_segments[k][0] + lay.obs_segments[k][1]] for k in range(lay.n_obs_segments)], dim=2))}
 
     def alloc_rollout(self, n_ticks: int, store=("actions", "rewards", "done", "truncated"), obs: Optional[ObsConfig] = None,
                       packed: bool = False, replay_feed: bool = False):

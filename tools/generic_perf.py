@@ -1,4 +1,6 @@
-"""Throughput of configurations that run the GENERIC (LDS-table) kernels. GPU box only."""
+"""Throughput of configurations OTHER than the four fully compiled-in BASELINE games: the byte-parallel family kernels (any job count up
+to 8, 3..8 agents, at most 2 imposters: susnet_family.h) and the per-turn kernels behind them. GPU box only.
+Both trajectory layouts: separate tensors (actions, rewards, done, truncated, raw uint8 observation) and packed records."""
 import importlib
 import sys
 
@@ -7,26 +9,42 @@ import torch
 sys.path.insert(0, ".")
 pkg = importlib.import_module("sus-net_amd")
 B, T, reps = 65536, 128, 8
+kw = dict(batch=B, auto_reset=True, export_state=False, check_errors=False)
 cases = {
-    "itg 1v3 j2 (generic)": lambda: pkg.BatchedImposterTrainingGround(3, 2, 0, -3, 1, 5, batch=B, auto_reset=True, export_state=False, check_errors=False),
-    "base 1v3 j5 (generic)": lambda: pkg.BatchedFourRoomEnv(1, 3, 5, batch=B, auto_reset=True, export_state=False, check_errors=False),
-    "base 3v9 j8 16x16 (generic)": lambda: pkg.BatchedFourRoomEnv(3, 9, 8, batch=B, grid_size=16, auto_reset=True, export_state=False, check_errors=False),
-    "tagging 2v6 j4 14x14 (generic)": lambda: pkg.BatchedFourRoomEnvWithTagging(2, 6, 4, batch=B, grid_size=14, auto_reset=True, export_state=False, check_errors=False),
-    "tagging 1v4 j5 (compiled-in)": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 5, batch=B, auto_reset=True, export_state=False, check_errors=False),
+    "itg 1v3 j2": lambda: pkg.BatchedImposterTrainingGround(3, 2, 0, -3, 1, 5, **kw),
+    "itg 1v10 (visualizing_games.ipynb)": lambda: pkg.BatchedImposterTrainingGround(10, 0, 0, -3, 0, 0, **kw),
+    "base 1v3 j5 (replay_buffer_test.ipynb)": lambda: pkg.BatchedFourRoomEnv(1, 3, 5, **kw),
+    "base 1v2 j4 14x14 (cfg3: compiled in)": lambda: pkg.BatchedFourRoomEnv(1, 2, 4, grid_size=14, **kw),
+    "base 1v2 j3 14x14": lambda: pkg.BatchedFourRoomEnv(1, 2, 3, grid_size=14, **kw),
+    "base 2v6 j5 14x14": lambda: pkg.BatchedFourRoomEnv(2, 6, 5, grid_size=14, **kw),
+    "base 3v9 j8 16x16 (per-turn kernels)": lambda: pkg.BatchedFourRoomEnv(3, 9, 8, grid_size=16, **kw),
+    "tagging 2v6 j4 14x14": lambda: pkg.BatchedFourRoomEnvWithTagging(2, 6, 4, grid_size=14, **kw),
+    "tagging 1v4 j5 (tag5: compiled in)": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 5, **kw),
+    "tagging 1v4 j4": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 4, **kw),
 }
+only = sys.argv[1:]
 for name, make in cases.items():
+    if only and not any(o in name for o in only):
+        continue
     env = make()
     env.reset()
-    bufs = env.alloc_rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
-    for _ in range(2):
-        env.rollout_into(T, bufs)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        env.rollout_into(T, bufs)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    print(f"{name:34s} {ms*1e3/T:7.3f} us/tick  {B*T/ms/1e6:7.2f} G env-steps/s")
-    del env, bufs
+    line = f"{name:40s}"
+    for packed in (False, True):
+        if packed and env.record_layout() is None:
+            line += "   packed: none"
+            continue
+        bufs = env.alloc_rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8), packed=packed)
+        for _ in range(2):
+            env.rollout_into(T, bufs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            env.rollout_into(T, bufs)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        line += f"   {'packed' if packed else 'separate'}: {ms*1e3/T:6.3f} us/tick {B*T/ms/1e6:7.2f} G"
+        del bufs
+    print(line, flush=True)
+    del env
