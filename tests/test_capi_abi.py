@@ -141,7 +141,23 @@ def test_packed_record_layouts(pkg):
         assert (lay.off_obs < lay.off_done) == want_obs_first, kw
         if want_obs_first:  # the byte-parallel kernels: raw row right behind the actions, its job cells on a dword boundary
             assert lay.off_obs == 5 * A and (lay.off_obs + 3 * A) % 4 == 0
-    A, F = layout(n_imposters=1, n_crew=3, n_jobs=2)  # not compiled in: no packed mode
+        assert lay.planar == (1 if want_obs_first else 0) and lay.n_obs_segments == 1 and tuple(lay.obs_segments[0]) == (lay.off_obs, F)
+    # the byte-parallel family (job count at run time): a layout independent of the job count, the observation in segments
+    sizes = set()
+    for jobs in (0, 2, 5, 8):
+        A, F = layout(n_imposters=1, n_crew=3, n_jobs=jobs)
+        sizes.add(lay.record_bytes)
+        assert lay.record_bytes > 0 and lay.record_bytes % 4 == 0 and lay.planar == 1
+        segs = [tuple(lay.obs_segments[k]) for k in range(lay.n_obs_segments)]
+        assert sum(n for _, n in segs) == F and segs[0] == (lay.off_obs, 3 * A) and lay.n_obs_segments == (1 if jobs == 0 else 3)
+        used = [False] * lay.record_bytes
+        for off, n in [(lay.off_rewards, 4 * A), (lay.off_actions, A), (lay.off_done, 1), (lay.off_truncated, 1)] + segs:
+            assert 0 <= off and off + n <= lay.record_bytes and not any(used[off:off + n]), (jobs, off, n)
+            used[off:off + n] = [True] * n
+    assert len(sizes) == 1
+    A, F = layout(variant=L.VARIANT_TAGGING, n_imposters=2, n_crew=5, n_jobs=3)
+    assert lay.n_obs_segments == 4 and sum(lay.obs_segments[k][1] for k in range(4)) == F
+    A, F = layout(n_imposters=3, n_crew=5, n_jobs=2)  # three imposters: the per-turn kernels, no packed mode
     assert lay.record_bytes == 0
 
 
