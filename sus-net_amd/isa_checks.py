@@ -94,9 +94,10 @@ def parse_notes(obj: str):
     return [k for k in kernels if "mangled" in k and "vgpr" in k]
 
 
-def parse_disasm(obj: str):
+def parse_disasm(obj: str, asm: str | None = None):
     """mangled kernel name -> static instruction statistics"""
-    asm = disassemble(obj)
+    if asm is None:
+        asm = disassemble(obj)
     stats, cur = {}, None
     for ln in asm.splitlines():
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", ln)
@@ -220,44 +221,52 @@ def check_limits(rows):
     return bad
 
 
-def verify_library(lib: str = LIB):
-    """Everything build_hip.build() requires of a freshly linked library; returns (rows, problems)."""
-    problems, rows = [], []
+def _analyse(obj: str):
+    """One code object: (kernel rows, problems, wide stores seen) from ONE disassembly (the library holds some forty code objects:
+    analysed in parallel -- the work is in the llvm tools' subprocesses)."""
+    asm = disassemble(obj)
+    problems = []
+    hz = store_data_hazards(asm)
+    if hz:
+        problems.append(f"{os.path.basename(obj)}: {len(hz)} wide-store data hazards, e.g. {hz[:2]}")
+    sc = scratch_instructions(asm)
+    if sc:
+        problems.append(f"{os.path.basename(obj)}: {len(sc)} scratch instructions, e.g. {sc[:2]}")
+    notes = parse_notes(obj)
+    dis = parse_disasm(obj, asm)
+    names = demangle([k["mangled"] for k in notes])
+    for k in notes:
+        k["name"] = short_name(names.get(k["mangled"], k["mangled"]))
+        k.update(dis.get(k["mangled"], {}))
+        k["spill_moves"] = k.get("v_readlane", 0) + k.get("v_writelane", 0) + k.get("v_accvgpr", 0) + k.get("scratch", 0)
+    return notes, problems, asm.count("_store_dwordx4")
+
+
+def _analyse_all(lib: str):
+    from concurrent.futures import ThreadPoolExecutor
+
     with tempfile.TemporaryDirectory() as wd:
         objs = code_objects(lib, wd)
-        if not objs:
-            problems.append("no gfx950 code object in the library")
-        stores = 0
-        for obj in objs:
-            asm = disassemble(obj)
-            stores += asm.count("_store_dwordx4")
-            hz = store_data_hazards(asm)
-            if hz:
-                problems.append(f"{os.path.basename(obj)}: {len(hz)} wide-store data hazards, e.g. {hz[:2]}")
-            sc = scratch_instructions(asm)
-            if sc:
-                problems.append(f"{os.path.basename(obj)}: {len(sc)} scratch instructions, e.g. {sc[:2]}")
-        if objs and stores < 100:
-            problems.append("disassembly looks empty")
-    rows = collect(lib)
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            parts = list(pool.map(_analyse, objs))
+    rows = sorted((k for notes, _, _ in parts for k in notes), key=lambda r: r["name"])
+    problems = [p for _, ps, _ in parts for p in ps]
+    return objs, rows, problems, sum(n for _, _, n in parts)
+
+
+def verify_library(lib: str = LIB):
+    """Everything build_hip.build() requires of a freshly linked library; returns (rows, problems)."""
+    objs, rows, problems, stores = _analyse_all(lib)
+    if not objs:
+        problems.append("no gfx950 code object in the library")
+    elif stores < 100:
+        problems.append("disassembly looks empty")
     problems += check_limits(rows)
     return rows, problems
 
 
 def collect(lib: str = LIB):
-    rows = []
-    with tempfile.TemporaryDirectory() as wd:
-        for obj in code_objects(lib, wd):
-            notes = parse_notes(obj)
-            dis = parse_disasm(obj)
-            names = demangle([k["mangled"] for k in notes])
-            for k in notes:
-                k["name"] = short_name(names.get(k["mangled"], k["mangled"]))
-                k.update(dis.get(k["mangled"], {}))
-                k["spill_moves"] = k.get("v_readlane", 0) + k.get("v_writelane", 0) + k.get("v_accvgpr", 0) + k.get("scratch", 0)
-                rows.append(k)
-    rows.sort(key=lambda r: r["name"])
-    return rows
+    return _analyse_all(lib)[1]
 
 
 COLS = ["vgpr", "agpr", "sgpr", "sgpr_spill", "vgpr_spill", "scratch_bytes", "instructions", "code_bytes", "v_readlane", "v_writelane", "v_accvgpr",
