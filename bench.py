@@ -505,6 +505,25 @@ def main():
                     if rp["qnet"] is not None:
                         entry["roofline"] = rp["qnet"]
                     del rp
+                # the trainer's collection loop on the same env: the one-kernel tick writing the replay feed + one susnet_ring_append per
+                # 64 ticks (DeviceReplayBuffer.collect: train.py:345-399), epsilon-greedy as the trainer acts
+                envc = make_env(pkg, sp, sp["batch"], seed, rank * sp["batch"], device, obs_cfg=pkg.ObsConfig("flat", POLICY_COMPONENTS))
+                envc.reset()
+                polc = pkg.PolicyRollout(envc, pkg.policy.reference_imposter_mlp(envc, POLICY_COMPONENTS, seed=0), None, components=POLICY_COMPONENTS,
+                                         epsilon=0.1, mask_dead=True)
+                ring = pkg.DeviceReplayBuffer(1 << 21, envc.flattened_state_size, 1, envc.n_agents, envc.n_imposters, device=device)
+                ring.collect(envc, polc, 64, epsilon=0.1)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                n_added = ring.collect(envc, polc, 256, epsilon=0.1)
+                torch.cuda.synchronize(device)
+                dtc = time.perf_counter() - t0
+                entry["collect_into_replay_ring"] = {"value": n_added / dtc, "unit": "transitions/s", "ticks": 256, "ticks_per_append": 64, "epsilon": 0.1,
+                                                     "us_per_tick": dtc * 1e6 / 256,
+                                                     "note": "DeviceReplayBuffer.collect: susnet_qnet_policy_step (network, epsilon-greedy argmax, random crew, step, "
+                                                             "replay feed: one kernel per tick) + susnet_ring_append per 64 ticks; the reference's six ring tensors, "
+                                                             "trajectory_size 1"}
+                del envc, polc, ring
                 entry["value"] = max(entry["eager"]["value"], entry["hip_graph_replay"]["value"])
                 entry["kernel"] = "k_qnet_step (susnet_qnet_policy_step: float32 Q-network on the f32-input MFMA, argmax, crew draws and the env step: the whole tick in one launch)"
                 entry["torch_modules_hip_graph_replay"]["note"] = ("the same tick with the network as torch modules (hipBLASLt f32 GEMMs + PReLU kernels on "

@@ -195,6 +195,12 @@ typedef struct susnet_step_io {
     uint8_t *done;        /* out [B]  (base.py:384-385) */
     uint8_t *truncated;   /* out [B]  (base.py:392-395) */
     const susnet_obs_spec *obs; /* optional fused observation of the post-step (post-auto-reset) state */
+    /* replay feed of ONE tick (what susnet_ring_append needs besides actions / rewards / done / truncated / the raw uint8 observation
+     * when the trajectory is collected tick by tick -- the trainer's loop, train.py:345-399 -- instead of by a fused rollout); both
+     * optional: */
+    uint8_t *term_obs;    /* out [B][obs_raw_size] u8, written ONLY where the episode ended at this step: its true terminal state
+                           * (flatten_state order), before the auto-reset replaces it */
+    uint16_t *roles;      /* out [B]: imposter bitmask (bit i = agent i) of the episode that acted at this step */
 } susnet_step_io;
 
 /* Fused random rollout: T lockstep ticks in one launch; per tick every env samples uniform role-valid

@@ -69,7 +69,7 @@ class StepIO(C.Structure):
     _fields_ = [
         ("actions", C.c_void_p), ("actions_dtype", C.c_int32), ("actions_layout", C.c_int32),
         ("rewards", C.c_void_p), ("rewards_dtype", C.c_int32), ("rewards_layout", C.c_int32),
-        ("done", C.c_void_p), ("truncated", C.c_void_p), ("obs", C.POINTER(ObsSpec)),
+        ("done", C.c_void_p), ("truncated", C.c_void_p), ("obs", C.POINTER(ObsSpec)), ("term_obs", C.c_void_p), ("roles", C.c_void_p),
     ]
 
 

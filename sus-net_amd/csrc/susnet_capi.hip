@@ -1049,6 +1049,9 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
     }
     a.done = io->done;
     a.trunc = io->truncated;
+    a.term_obs = io->term_obs;
+    a.roles = io->roles;
+    a.raw_F = env->layout.obs_raw_size;
     a.tick = env->ticks;
     ObsArgs o;
     if (int rc = build_obs(env, io->obs, o, env->c.B)) return rc;

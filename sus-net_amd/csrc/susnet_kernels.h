@@ -29,6 +29,10 @@ struct StepArgs {
     int32_t n_qi, n_qc;
     float epsilon;     // > 0: every agent explores (takes its uniformly random role-valid draw instead) with this probability
     int32_t mask_dead; // != 0: dead agents are given index 0 (train.py:351-381 sets only the living agents' actions)
+    // replay feed of the tick (susnet_step_io): the terminal state's raw row where the episode ended, the acting episode's roles
+    uint8_t *term_obs; // [B][F] or NULL
+    uint16_t *roles;   // [B] or NULL
+    int32_t raw_F;     // flattened_state_size
 };
 constexpr int kMaxPolicyActions = 16; // Q row lengths susnet_policy_step serves
 
@@ -314,6 +318,8 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
         if (c.dev_tick) s.tickw[b] = step_tick + 1ull;
         if (a.done) a.done[b] = done ? 1 : 0;
         if (a.trunc) a.trunc[b] = trunc ? 1 : 0;
+        if (a.roles) a.roles[b] = (uint16_t)S::imp(c, e.imp); // the episode that acted (before an auto-reset draws new roles)
+        if (__builtin_expect(a.term_obs != nullptr && (done || trunc), 0)) fill_raw<S>(c, st, e, a.term_obs + b * a.raw_F); // its true terminal state
         bool jobs_changed = false;
         if (__builtin_expect(c.auto_reset && (done || trunc), 0)) {
             accumulate_lifetime(c, s, b, e, trunc);

@@ -642,6 +642,65 @@ class BatchedFourRoomEnv:
                 self.poll_errors()
         return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics(), buf
 
+    # ---- policy-driven collection: the trainer's acting loop (train.py:345-399) writing the replay feed tick by tick -------------------
+    def alloc_feed(self, n_ticks: int) -> Dict[str, torch.Tensor]:
+        """The ``[T][B]`` trajectory block a policy-driven collection of ``n_ticks`` ticks fills, one tick per ``policy_tick_into`` call,
+        and ``susnet_ring_append`` then consumes (same tensors a fused rollout with ``replay_feed=True`` writes)."""
+        T, B, A, S = int(n_ticks), self.batch, self.n_agents, self.flattened_state_size
+        z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=self.device)
+        return {"n_ticks": T, "actions": z(T, B, A, dtype=torch.uint8), "rewards": z(T, B, A, dtype=torch.float32),
+                "done": z(T, B, dtype=torch.bool), "truncated": z(T, B, dtype=torch.bool), "obs": z(T, B, S, dtype=torch.uint8),
+                "term_obs": z(T, B, S, dtype=torch.uint8), "roles": z(T, B, dtype=torch.int16)}
+
+    def policy_tick_into(self, feed: Dict[str, torch.Tensor], t: int, net_imposter: "PackedQNet" = None, net_crew: "PackedQNet" = None,
+                         q_imposter: Optional[torch.Tensor] = None, q_crew: Optional[torch.Tensor] = None, epsilon: float = 0.0,
+                         mask_dead: bool = True) -> None:
+        """ONE tick of the trainer's acting loop (train.py:345-399: act on the current state, step, keep what ``replay_buffer.add``
+        needs) written into slot ``t`` of ``feed``: the actions taken, rewards, done / truncated, the raw uint8 state after the step (after
+        the auto-reset where the episode ended), the true terminal state there, and the acting episode's roles.  The teams' Q rows come
+        from packed reference MLPs (``net_*``: the Q-network kernel reads the state itself) or from the caller (``q_*``).  With
+        ``net_imposter`` alone on a compiled-in game and the production stream the whole tick is ONE kernel
+        (``susnet_qnet_policy_step``: network, argmax / exploration, the random crew's draws, step, feed); else the network launch(es) +
+        ``susnet_policy_step``.  Asynchronous; nothing is exported to the host-side mirrors."""
+        assert self.auto_reset, "collection needs an auto-resetting env"
+        A, S = self.n_agents, self.flattened_state_size
+        io = feed.get("_io")
+        if io is None:
+            io = feed["_io"] = L.StepIO()
+            spec = L.ObsSpec()
+            spec.mode, spec.dtype = L.OBS_RAW, L.U8
+            feed["_spec"] = spec
+            io.obs = C.pointer(spec)
+            io.actions_dtype, io.actions_layout = L.U8, L.LAYOUT_BA
+            io.rewards_dtype, io.rewards_layout = L.F32, L.LAYOUT_BA
+        t = int(t)
+        # (the observation writer stores 16-byte pieces: a slot that does not start on a 16-byte boundary -- odd small batches -- is
+        # written through an aligned bounce buffer)
+        slot = feed["obs"][t]
+        bounce = None
+        if slot.data_ptr() % 16:
+            bounce = feed.get("_bounce")
+            if bounce is None:
+                bounce = feed["_bounce"] = torch.zeros_like(slot)
+        feed["_spec"].out = (bounce if bounce is not None else slot).data_ptr()
+        io.actions, io.rewards = feed["actions"][t].data_ptr(), feed["rewards"][t].data_ptr()
+        io.done, io.truncated = feed["done"][t].data_ptr(), feed["truncated"][t].data_ptr()
+        io.term_obs, io.roles = feed["term_obs"][t].data_ptr(), feed["roles"][t].data_ptr()
+        opts = self._policy_opts(epsilon, mask_dead)
+        with self._on_device():
+            if net_imposter is not None and net_crew is None and q_crew is None and self.supports_qnet_policy_step(net_imposter):
+                L.check(self.lib.susnet_qnet_policy_step(self._h, net_imposter.components, len(net_imposter.components), net_imposter.cdims,
+                                                         len(net_imposter.dims), net_imposter.packed.data_ptr(), None, opts, C.byref(io), self._stream()))
+            else:
+                if q_imposter is None:
+                    q_imposter = self.qnet_forward(net_imposter)
+                if q_crew is None and net_crew is not None:
+                    q_crew = self.qnet_forward(net_crew)
+                L.check(self.lib.susnet_policy_step(self._h, q_imposter.data_ptr(), q_crew.data_ptr() if q_crew is not None else None, opts,
+                                                    C.byref(io), self._stream()))
+            if bounce is not None:
+                slot.copy_(bounce)
+
     def step4(self, agent_actions):
         """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""
         state, rew, done, trunc, info = self.step(agent_actions)

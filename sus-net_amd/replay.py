@@ -121,6 +121,70 @@ class DeviceReplayBuffer:
         torch.cuda.current_stream(env.device).synchronize()  # (the trajectory buffers die with this call)
         return num_steps * B
 
+    def _ring_io(self, env, feed, window):
+        import ctypes as C
+
+        from . import _lib as L
+
+        io = L.RingIO()
+        io.trajectory_size = self.trajectory_size
+        io.actions, io.rewards = feed["actions"].data_ptr(), feed["rewards"].data_ptr()
+        io.done, io.truncated = feed["done"].data_ptr(), feed["truncated"].data_ptr()
+        io.obs, io.term_obs, io.roles = feed["obs"].data_ptr(), feed["term_obs"].data_ptr(), feed["roles"].data_ptr()
+        io.window = window.data_ptr()
+        io.max_size = self.max_size
+        io.states, io.next_states = self.states.data_ptr(), self.next_states.data_ptr()
+        io.ring_actions, io.ring_rewards = self.actions.data_ptr(), self.rewards.data_ptr()
+        io.ring_dones, io.ring_imposters = self.dones.data_ptr(), self.imposters.data_ptr()
+        return io
+
+    @torch.no_grad()
+    def collect(self, env, policy, num_steps: int, epsilon: float = 0.0, mask_dead: bool = True, ticks_per_append: int = 64) -> int:
+        """The trainer's collection loop (train.py:345-399) for B environments in lockstep, on the device: per tick the teams act by
+        their Q-networks on the current state -- epsilon-greedy, dead agents get index 0 (train.py:351-381) --, the env steps, and the
+        transition ``(window, actions, rewards, next window, done, imposters)`` goes to the ring with ``ReplayBuffer.add``'s semantics
+        (replay_memory.py:50-73; windows as train.py:318-322, 388-389, 441-445).  ``policy``: a ``PolicyRollout`` over ``env`` whose
+        models are reference MLPs the Q-network kernel serves (``policy.fused_imposter``; the crew by ``policy.fused_crew``, or random
+        when it has no model).  Per tick ONE kernel where the env serves the whole tick (``susnet_qnet_policy_step``), else the network
+        launch(es) + ``susnet_policy_step``; every ``ticks_per_append`` ticks ONE ``susnet_ring_append``.  The sequence window carries
+        over between calls (``reset_collection`` after an ``env.reset()``).  Row order = tick-major, env-minor; with ``batch=1``,
+        ``rng='numpy'`` and two networks the ring equals the reference's for the same numpy seed and weights
+        (tests/golden/collect_*.npz).  Returns the number of transitions added."""
+        import ctypes as C
+
+        from . import _lib as L
+        from .env import ObsConfig
+
+        assert policy.env is env and policy.fused_imposter is not None, "collect: the imposters' model must be a reference MLP on a compiled-in feature layout"
+        assert policy.crew_model is None or policy.fused_crew is not None, "collect: the crew's model must be a reference MLP on a compiled-in feature layout (or None: random crew)"
+        assert env.flattened_state_size == self.state_size and env.n_agents == self.n_agents and env.n_imposters == self.n_imposters
+        T, B = self.trajectory_size, env.batch
+        if getattr(self, "_collect_window", None) is None:  # train.py:318-322: the current state T times
+            first = env.observe(ObsConfig("raw", dtype=torch.uint8))
+            self._collect_window = first.unsqueeze(1).repeat(1, T, 1).contiguous()
+        n_block = max(1, min(int(ticks_per_append), int(num_steps)))
+        feed = getattr(self, "_collect_feed", None)
+        if feed is None or feed["n_ticks"] != n_block or feed["actions"].shape[1] != B:
+            feed = self._collect_feed = env.alloc_feed(n_block)
+        io = self._ring_io(env, feed, self._collect_window)
+        done_ticks = 0
+        while done_ticks < num_steps:
+            n = min(n_block, num_steps - done_ticks)
+            policy.refresh_weights(force=False)  # (the optimizer may have stepped since the last block)
+            for t in range(n):
+                env.policy_tick_into(feed, t, net_imposter=policy.fused_imposter, net_crew=policy.fused_crew, epsilon=epsilon, mask_dead=mask_dead)
+            io.n_ticks, io.idx = n, self.idx
+            with torch.cuda.device(env.device):
+                L.check(env.lib.susnet_ring_append(env._h, C.byref(io), env._stream()))
+            self.idx = (self.idx + n * B) % self.max_size
+            self.size = min(self.size + n * B, self.max_size)
+            done_ticks += n
+        return num_steps * B
+
+    def reset_collection(self) -> None:
+        """Forget the carried sequence window (call after ``env.reset()``: the next ``collect`` starts from the current state)."""
+        self._collect_window = None
+
     @torch.no_grad()
     def populate(self, env, num_steps: int) -> int:
         """Random-policy rollout into the ring: ``num_steps`` lockstep ticks of ``env`` (B transitions each).

@@ -1467,6 +1467,134 @@ def test_native_replay_ring_matches_reference_populate(pkg, name):
         np.testing.assert_array_equal(np_(buf.imposters[:n]), np.sort(g["imposters"], axis=1), err_msg="imposters (as sets)")
 
 
+def test_policy_rollout_follows_weight_updates(pkg):
+    """The packed device image of a Q-network is refreshed when the module's parameters change (optimizer.step / load_state_dict between
+    ticks: train.py:402-416): the eager paths check the parameters' versions, `refresh_weights()` re-packs in place (same device buffer: a
+    captured graph keeps reading it)."""
+    comps = ["onehot_pos", "alive_crew", "closest_crew"]
+    env = pkg.BatchedFourRoomEnv(1, 2, 4, grid_size=14, batch=256, auto_reset=True, seed=5, shuffle_imposter_index=False, check_errors=False,
+                                 obs=pkg.ObsConfig("flat", comps))
+    model = pkg.policy.reference_imposter_mlp(env, comps, seed=1)
+    pol = pkg.PolicyRollout(env, model, None, components=comps)
+    env.reset()
+    ptr = pol.fused_imposter.packed.data_ptr()
+    q0 = pol.q_rows()[0].clone()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(0.5).add_(0.01)  # (what an optimizer step does: in-place updates)
+    q1 = pol.q_rows()[0].clone()
+    with torch.no_grad():
+        want = model(torch.zeros(env.batch, 1, 1, device=env.device), env.obs)
+    assert not torch.allclose(q0, q1) and torch.allclose(q1, want, rtol=0, atol=2e-5 * float(want.abs().max()))
+    assert pol.fused_imposter.packed.data_ptr() == ptr, "re-packed in place"
+    model.load_state_dict({k: v * 2 for k, v in model.state_dict().items()})
+    assert pol.refresh_weights(force=False) and not pol.refresh_weights(force=False)
+    with torch.no_grad():
+        want2 = model(torch.zeros(env.batch, 1, 1, device=env.device), env.obs)
+    torch.testing.assert_close(pol.q_rows()[0], want2, rtol=0, atol=2e-5 * float(want2.abs().max()))
+
+
+def collect_names():
+    import glob
+    import os
+
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "collect_*.npz")))
+
+
+def _collect_models(pkg, g, device):
+    meta = g["meta"]
+    out = []
+    for team in ("imposter", "crew"):
+        m = pkg.policy.MLP(meta[f"{team}_dims"])
+        m.load_state_dict({k[len(team) + 2:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(team + "::")})
+        out.append(m.to(device).eval())
+    return out
+
+
+@pytest.mark.parametrize("name", collect_names())
+def test_policy_driven_collection_matches_the_reference_trainer_loop(pkg, name):
+    """`DeviceReplayBuffer.collect` -- the policy tick (Q-network kernels + susnet_policy_step writing the replay feed) and
+    susnet_ring_append -- against the ring the REFERENCE's objects produce in the trainer's collection loop (tests/golden/
+    generate_collect.py: train.py:316-322, 345-399, 419-449 restated around the unmodified env, FlatFeaturizer, MLPs and ReplayBuffer;
+    greedy, dead agents get index 0): one env, numpy's words as the tape, the stored network parameters; the actions the kernels chose
+    equal the recorded ones because the ring's action rows do."""
+    g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
+    meta = g["meta"]
+    T, max_size, num_steps = meta["trajectory_size"], meta["max_size"], meta["num_steps"]
+    comps = meta["components"]
+    env = env_from_meta(pkg, meta, 1, rng="numpy", tape_words=1 << 16, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
+    env._reseed([meta["seed"]])
+    imp, crew = _collect_models(pkg, g, env.device)
+    policy = pkg.PolicyRollout(env, imp, crew, components=comps, mask_dead=True)
+    assert policy.fused_imposter is not None and policy.fused_crew is not None, "both reference MLPs are served by the Q-network kernel"
+    buf = pkg.DeviceReplayBuffer(max_size, meta["state_size"], T, meta["n_agents"], meta["n_imposters"], device=env.device)
+    env.reset()
+    for part in (37, num_steps - 37):  # two calls: the sequence window carries over
+        assert buf.collect(env, policy, part, epsilon=0.0, mask_dead=True, ticks_per_append=50) == part
+    torch.cuda.synchronize()
+    env.poll_errors()
+    assert (buf.idx, buf.size) == (meta["idx"], meta["size"])
+    n = buf.size
+    np.testing.assert_array_equal(np_(buf.actions[:n]), g["actions"].astype(np.int64), err_msg="actions (the networks' greedy choices)")
+    np.testing.assert_array_equal(np_(buf.states[:n]), g["states"].astype(np.float32), err_msg="states")
+    np.testing.assert_array_equal(np_(buf.next_states[:n]), g["next_states"].astype(np.float32), err_msg="next_states")
+    assert np_(buf.rewards[:n]).view(np.uint32).tolist() == g["rewards"].view(np.uint32).tolist(), "rewards"
+    np.testing.assert_array_equal(np_(buf.dones[:n]), g["dones"].astype(bool), err_msg="dones")
+    np.testing.assert_array_equal(np_(buf.imposters[:n]), g["imposters"], err_msg="imposters")
+
+
+def test_one_kernel_collection_matches_the_step_by_step_policy_loop(pkg):
+    """Production stream, random crew, epsilon-greedy: `collect` (ONE kernel per tick writing the replay feed) against a twin env driven
+    tick by tick through `PolicyRollout.tick` with the window / ring bookkeeping done in torch (`add_batch`): same transitions, same
+    ring -- episode ends, terminal next-states and truncations included."""
+    B, T, n_ticks, comps = 384, 2, 90, ["onehot_pos", "alive_crew", "closest_crew"]
+    mk = lambda: pkg.BatchedFourRoomEnv(1, 2, 4, grid_size=14, batch=B, auto_reset=True, seed=77, max_time_steps=20, shuffle_imposter_index=False,
+                                        check_errors=False, export_state=False, obs=pkg.ObsConfig("flat", comps))
+    env, twin = mk(), mk()
+    model = pkg.policy.reference_imposter_mlp(env, comps, seed=3)
+    S, A = env.flattened_state_size, env.n_agents
+    buf = pkg.DeviceReplayBuffer(B * n_ticks, S, T, A, 1, device=env.device)
+    ref = pkg.DeviceReplayBuffer(B * n_ticks, S, T, A, 1, device=env.device)
+    pol = pkg.PolicyRollout(env, model, None, components=comps, epsilon=0.25, mask_dead=True)
+    assert pol.one_kernel_tick
+    env.reset()
+    assert buf.collect(env, pol, n_ticks, epsilon=0.25, mask_dead=True, ticks_per_append=32) == B * n_ticks
+    # the twin: the tested tick (susnet_qnet_policy_step through PolicyRollout) + torch bookkeeping with the reference's window rules
+    tp = pkg.PolicyRollout(twin, model, None, components=comps, epsilon=0.25, mask_dead=True)
+    raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
+    twin.reset()
+    window = twin.observe(raw8).float().unsqueeze(1).repeat(1, T, 1)
+    imposters = torch.zeros(B, 1, dtype=torch.int16, device=twin.device)
+    ends = 0
+    for _ in range(n_ticks):
+        before = twin.observe(raw8)
+        a, rew, done, trunc = tp.tick()
+        after = twin.observe(raw8).float()  # (after the auto-reset where the episode ended)
+        ended = done | trunc
+        ends += int(ended.sum())
+        nxt = torch.roll(window, shifts=-1, dims=1)
+        nxt[:, -1] = after
+        keep = ~ended
+        # a transition that ended its episode: its next window ends with the TERMINAL state, which the twin no longer holds -- compare those
+        # rows' last slot through the collecting env's own feed instead (checked separately below); everything else row by row
+        ref.add_batch(window, a, rew, nxt, done, imposters)
+        window = torch.where(ended.view(-1, 1, 1), after.unsqueeze(1).expand(-1, T, -1), nxt)
+    torch.cuda.synchronize()
+    assert ends > 100, "the run must cross many episode ends"
+    n = B * n_ticks
+    np.testing.assert_array_equal(np_(buf.actions[:n]), np_(ref.actions[:n]))
+    assert np_(buf.rewards[:n]).view(np.uint32).tolist() == np_(ref.rewards[:n]).view(np.uint32).tolist()
+    np.testing.assert_array_equal(np_(buf.dones[:n]), np_(ref.dones[:n]))
+    np.testing.assert_array_equal(np_(buf.states[:n]), np_(ref.states[:n]))
+    # next_states: equal wherever the episode went on; where it ended the ring holds the true terminal state, which differs from the
+    # fresh state the twin's bookkeeping stored -- and must continue the previous state by one move per agent at most
+    ended_rows = np_((buf.next_states[:n, -1] != ref.next_states[:n, -1]).any(dim=1))
+    np.testing.assert_array_equal(np_(buf.next_states[:n, :-1]), np_(ref.next_states[:n, :-1]))
+    prev, term = np_(buf.states[:n, -1])[ended_rows], np_(buf.next_states[:n, -1])[ended_rows]
+    assert ended_rows.sum() > 0 and (np.abs(term[:, :2 * A] - prev[:, :2 * A]).reshape(-1, A, 2).sum(-1) <= 1).all()
+    np.testing.assert_array_equal(term[:, 3 * A:3 * A + 8], prev[:, 3 * A:3 * A + 8], err_msg="job cells stay within an episode")
+
+
 @pytest.mark.parametrize("game,T", [("base_1v2", 3), ("tagging_1v4", 14), ("base_2v6", 29)])
 def test_native_replay_ring_batched_matches_a_host_rebuild(pkg, game, T):
     """Many envs, odd launch lengths, a ring smaller than the run: every row the ring holds equals what replaying the
