@@ -90,7 +90,7 @@ def stored_bytes_per_step(A, J, N, obs, raw_size=None, record_bytes=None):
     return b
 
 
-def profiled_traffic(config, obs, packed, batch, ticks):
+def profiled_traffic(config, obs, packed, batch, ticks, bytes_per_step=None):
     """HBM bytes per bench step of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_pmc_summary.json, written by tools/summarize_profiles.py: one entry per config, separate --pmc runs for
     FETCH_SIZE and WRITE_SIZE, KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  bench.py cannot
@@ -105,6 +105,8 @@ def profiled_traffic(config, obs, packed, batch, ticks):
         d = d.get(config, d if config == "cfg2" else {})  # (round-1 summaries held cfg2 only, at top level)
         cmd = d.get("command")  # (round >= 3 summaries: what the profiled command was)
         if cmd is not None and obs == "raw" and (bool(cmd.get("packed")) != bool(packed) or cmd.get("batch") != batch or cmd.get("ticks") != ticks):
+            return None, None
+        if cmd is not None and cmd.get("bytes_per_env_step") not in (None, bytes_per_step):  # (another record format of the same configuration)
             return None, None
         if cmd is None and obs == "raw" and not packed:  # (older summaries profiled the packed default)
             return None, None
@@ -129,7 +131,7 @@ def roofline_block(config, spec, B, ticks, obs, packed, raw_size, record_bytes, 
     b_stored = stored_bytes_per_step(A, J, N, obs, raw_size, record_bytes if packed else None)
     b_8d = algorithmic_bytes_per_step(A, J, N, obs)
     achieved = steps * b_stored / avg_launch_s / 1e9
-    traffic, src = profiled_traffic(config, obs, packed, B, ticks) if with_traffic else (None, None)
+    traffic, src = profiled_traffic(config, obs, packed, B, ticks, b_stored) if with_traffic else (None, None)
     kernel = KERNEL_NAMES.get(config, "k_rollout")
     if config == "cfg4" and B != 32768:
         kernel = "k_rollout_swar<Spec<8,4,..>, OUT, PhiloxRng>"
@@ -246,7 +248,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--packed", type=int, default=-1, help="fused + raw obs: 1 = one packed record per env-step (compiled-in configurations: "
                     "the same fields, one or a few wide stores per lane instead of one narrow store per tensor), 0 = separate "
-                    "trajectory tensors, -1 (default) = packed where the configuration has it")
+                    "trajectory tensors, 2 = the COMPACT record where the configuration has one (cfg2: 16 bytes, actions and flags in one "
+                    "byte), -1 (default) = compact, else packed, where the configuration has it")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-launch timed region is run this many more times back to back (after the "
+                    "headline measurement, which stays as it is): median / min / max of the repeats are reported in `repeats`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the step-API leg, the observation sweep and other_configs")
     args = ap.parse_args()
@@ -309,7 +314,7 @@ def main():
             env.step(a)
         return 2 * n_ticks
 
-    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0, policy_fused=True):
+    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0, policy_fused=True, n_repeats=0):
         """W untimed + K timed bench steps of one configuration.  fused: a step is one launch of `ticks` ticks; step / policy:
         one tick (policy with graph_ticks > 0: the tick loop replayed as hipGraphs of graph_ticks ticks, K rounded up to whole graphs)."""
         oc = obs_config(obs_mode) if mode == "fused" else None
@@ -320,9 +325,14 @@ def main():
         env.reset()
         lay = env.record_layout()
         packed = (mode == "fused" and obs_mode == "raw" and want_packed != 0 and lay is not None)
-        if want_packed == 1 and mode == "fused" and obs_mode == "raw":
+        if want_packed in (1, 2) and mode == "fused" and obs_mode == "raw":
             assert packed, "this configuration has no packed record mode"
-        bufs = env.alloc_rollout(ticks, obs=oc, packed=packed) if mode == "fused" else None
+        compact = packed and want_packed in (-1, 2) and env.record_layout("compact") is not None
+        if want_packed == 2:
+            assert compact, "this configuration has no compact record"
+        if compact:
+            lay = env.record_layout("compact")
+        bufs = env.alloc_rollout(ticks, obs=oc, packed=("compact" if compact else packed)) if mode == "fused" else None
         if mode == "policy":
             model = pkg.policy.reference_imposter_mlp(env, POLICY_COMPONENTS, seed=0)
             pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS, fused=policy_fused)
@@ -353,6 +363,20 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)  # HIP events around the timed region, on the launch stream
+        # the same K-launch region `repeats` more times, back to back (outside the headline's timed region): how much one such
+        # measurement moves on this box
+        rep = None
+        if n_repeats > 0 and mode == "fused":
+            vals = []
+            for _ in range(n_repeats):
+                r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                r0.record(stream)
+                runner(K)
+                r1.record(stream)
+                torch.cuda.synchronize(device)
+                vals.append(r0.elapsed_time(r1) * 1e3 / K)
+            vals.sort()
+            rep = {"n": n_repeats, "launches_each": K, "median_launch_us": vals[len(vals) // 2], "min_launch_us": vals[0], "max_launch_us": vals[-1]}
         pair_us = None
         if mode == "fused":  # cross-check OUTSIDE the timed region: 8 launches, each bracketed by its own event pair
             pairs = []
@@ -405,7 +429,10 @@ def main():
                             "(35 % of the model's multiply-adds) is a gather of W1 columns and issues no MFMA, so model_tflops exceeds it"}
         return dict(seconds=dt, launches=launches, device_ms=dev_ms, metrics=metrics, pair_us=pair_us, packed=packed, steps=K, warmup=W,
                     raw_size=env.flattened_state_size, record_bytes=lay.record_bytes if lay is not None else None,
-                    launch_us_ranks=launch_us_ranks, qnet=qnet)
+                    launch_us_ranks=launch_us_ranks, qnet=qnet, repeats=rep,
+                    layout=("compact record per env-step (16 bytes: rewards f32[2] | raw obs u8[6] | actions and flags in one byte | 0)" if mode == "fused" and compact
+                            else ("packed record per env-step" + (", stored as planes of 16-byte pieces" if lay is not None and lay.planar else "")) if packed
+                            else "separate tensors"))
 
     K, W = args.steps, args.warmup
     spec = CONFIGS[args.config]
@@ -414,7 +441,7 @@ def main():
     if spec.get("policy"):
         args.mode, args.obs = "policy", "flat"
     ticks_per_step = args.ticks if args.mode == "fused" else 1
-    res = measure(spec, B, args.mode, args.obs, K, W, args.ticks, args.packed)
+    res = measure(spec, B, args.mode, args.obs, K, W, args.ticks, args.packed, n_repeats=args.repeats if world == 1 else 0)
     steps_per_launch = B * ticks_per_step          # env-steps one launch of the dominant kernel processes (this rank)
     total_steps = steps_per_launch * world * K
     value = total_steps / res["seconds"]
@@ -436,12 +463,17 @@ def main():
                    "step_definition": (f"one susnet_rollout launch = {ticks_per_step} lockstep ticks x {B} envs per GPU" if args.mode == "fused"
                                        else "one lockstep tick (sample_actions + step)"),
                    "env_steps_per_bench_step": steps_per_launch * world,
-                   "trajectory_layout": "packed record per env-step" if res["packed"] else "separate tensors",
+                   "trajectory_layout": res["layout"],
                    "rng": "philox4x32-10 in-kernel", "auto_reset": True, "parallelism": f"dp{world}",
                    "agent_steps_per_s": value * A},
         "roofline": roof,
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
+    if res["repeats"]:
+        rp = res["repeats"]
+        rp["median_value"] = steps_per_launch / (rp["median_launch_us"] * 1e-6)
+        rp["note"] = "the K-launch timed region repeated back to back after the headline measurement (HIP events per repeat); value at the median launch time"
+        line["repeats"] = rp
     if args.mode == "policy":  # the tick's dominant kernel is the Q-network: its roofline is the f32 matrix peak
         line["roofline"] = dict(res["qnet"])
         line["dtype"] = "f32"
@@ -536,13 +568,17 @@ def main():
             line["other_configs"].append({
                 "config": name, "workload": sp["workload"], "value": sp["batch"] * 512 * 20 / ro["seconds"], "unit": "env-steps/s",
                 "steps": 20, "warmup": 5, "ticks_per_launch": 512, "batch": sp["batch"],
-                "trajectory_layout": "packed record per env-step" if ro["packed"] else "separate tensors",
+                "trajectory_layout": ro["layout"],
                 "avg_launch_us": rb["avg_launch_us"], "avg_launch_us_event_pairs": rb["avg_launch_us_event_pairs"], "kernel": rb["kernel"],
                 "bytes_per_env_step": rb["bytes_per_env_step"], "achieved_GBs": rb["achieved"], "frac": rb["frac"],
                 "survey_8d_bytes_per_env_step": rb["survey_8d_bytes_per_env_step"], "survey_8d_frac": rb["survey_8d_frac"],
                 "traffic": rb["traffic"], "traffic_frac": rb["traffic_frac"], "traffic_source": rb["traffic_source"],
                 "episodes": ro["metrics"].get("episodes"), "episode_steps": ro["metrics"].get("episode_steps")})
             del ro
+    if "other_configs" in line:  # the same numbers in a compact top-level key (the long entries above get truncated in driver records)
+        line["others"] = {e["config"]: {"value": e["value"], "frac": (e.get("frac") if "frac" in e else e.get("roofline", {}).get("frac")),
+                                        **({"collect_transitions_per_s": e["collect_into_replay_ring"]["value"]} if "collect_into_replay_ring" in e else {})}
+                          for e in line["other_configs"]}
     if world > 1:
         dist.barrier()  # the timed region and its collectives are over on every rank before rank 0 spends host time below
     if rank == 0 and not args.no_cpu_baseline:

@@ -217,11 +217,19 @@ typedef struct susnet_rollout_io {
     void *record;       /* alternative to ALL of the above (which must then be NULL): one packed record per env-step,
                          * [T][B][record_bytes] -- the same fields, laid out for one wide store per lane
                          * (susnet_record_layout); only for the compiled-in configurations */
-    /* replay feed (susnet_ring_append); both optional, both need obs = RAW / U8 next to the full trajectory */
+    /* replay feed (susnet_ring_append); both optional, both need obs = RAW / U8 next to the full trajectory (term_obs also goes with
+     * `record` on handles whose records are whole -- susnet_record_layout_t.planar == 0) */
     uint8_t *term_obs;  /* out [T][B][obs_raw_size] u8, written ONLY at (tick, env) where the episode ended: the true
                          * post-step state (the obs row of such a tick already holds the next episode's first state) */
     uint16_t *roles;    /* out [T][B]: imposter bitmask (bit i = agent i) of the episode that acted at the tick */
+    int32_t record_format; /* which record `record` receives: SUSNET_RECORD_DEFAULT, or SUSNET_RECORD_COMPACT where the handle has one
+                            * (susnet_record_layout_of) */
 } susnet_rollout_io;
+#define SUSNET_RECORD_DEFAULT 0
+/* the 1v1 game on a grid without walls (BASELINE configs[1]): 16 bytes -- rewards f32[2] | raw observation u8[6] | ONE byte holding
+ * actions and flags (susnet_record_layout_t.flags_packed) | 0 -- so that an env-step is one 16-byte store and a wave writes 1 KiB of
+ * consecutive bytes per tick (+8 % env-steps/s over the 20-byte default, whose bytes stay as they are) */
+#define SUSNET_RECORD_COMPACT 1
 
 /* Device replay ring fed from a fused rollout: the reference's ReplayBuffer tensors (src/replay_memory.py:33-44) written by
  * ONE launch from the [T][B] trajectory of susnet_rollout, with ReplayBuffer.populate's semantics (replay_memory.py:96-143):
@@ -250,6 +258,11 @@ typedef struct susnet_ring_io {
     float *ring_rewards;        /* [max_size][A] */
     uint8_t *ring_dones;        /* [max_size][1] */
     int16_t *ring_imposters;    /* [max_size][n_imposters] */
+    /* alternative to actions / rewards / done / truncated / obs (which must then be NULL): the [T][B] packed records a fused rollout
+     * wrote (susnet_rollout_io.record, format record_format), read in place -- for handles that store whole records
+     * (susnet_record_layout_t.planar == 0: the 1v1 kernels); term_obs as above */
+    const uint8_t *record;
+    int32_t record_format;
 } susnet_ring_io;
 int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, void *stream);
 
@@ -276,8 +289,12 @@ typedef struct susnet_record_layout_t {
      * job cells, job status, the tagging tail.  off_obs = the first segment's offset. */
     int32_t n_obs_segments;
     struct { int32_t off, len; } obs_segments[4];
+    /* flags_packed = 1 (SUSNET_RECORD_COMPACT, two agents): off_actions = off_done = off_truncated = ONE byte
+     * a0 | a1 << 3 | done << 6 | truncated << 7 (role-relative action indices below 8). */
+    int32_t flags_packed;
 } susnet_record_layout_t;
-int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out);
+int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out);        /* the default record */
+int susnet_record_layout_of(const susnet_env *env, int32_t record_format, susnet_record_layout_t *out); /* record_bytes = 0: the handle has no such record */
 
 /* The trajectory modes of susnet_rollout address every output array with 32-bit offsets: one launch covers at most as many ticks
  * as keep each array below `bytes` (default and maximum 2^31 - 1); longer requests run as consecutive launches.  bytes = 0

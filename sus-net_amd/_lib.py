@@ -22,6 +22,7 @@ LAYOUT_AB, LAYOUT_BA = 0, 1
 OBS_NONE, OBS_RAW, OBS_FLAT, OBS_PLANES, OBS_PERSP = 0, 1, 2, 3, 4
 E_INVALID, E_HIP, E_STATE, E_ACTION_ASSERT, E_ACTION_INDEX, E_TAPE, E_ROW = -1, -2, -3, -4, -5, -6, -7
 
+RECORD_DEFAULT, RECORD_COMPACT = 0, 1
 FLAT_COMPONENTS = {"onehot_pos": 0, "coord_pos": 1, "alive_crew": 2, "l1_crew": 3, "closest_crew": 4,
                    "walls3x3": 5, "dist_to_imp": 6, "room_loc": 7}
 LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_killed_crew", "completed_jobs",
@@ -31,7 +32,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
     "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_policy_actions", "susnet_qnet_packed_floats", "susnet_qnet_pack", "susnet_qnet_forward", "susnet_step", "susnet_policy_step", "susnet_qnet_policy_step",
-    "susnet_rollout", "susnet_record_layout", "susnet_set_launch_limit", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
+    "susnet_rollout", "susnet_record_layout", "susnet_record_layout_of", "susnet_set_launch_limit", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append", "susnet_scent",
 ]
 
@@ -77,7 +78,7 @@ class RolloutIO(C.Structure):
     _fields_ = [
         ("n_ticks", C.c_int32), ("actions", C.c_void_p), ("rewards", C.c_void_p), ("done", C.c_void_p),
         ("truncated", C.c_void_p), ("obs", C.POINTER(ObsSpec)), ("record", C.c_void_p),
-        ("term_obs", C.c_void_p), ("roles", C.c_void_p),
+        ("term_obs", C.c_void_p), ("roles", C.c_void_p), ("record_format", C.c_int32),
     ]
 
 
@@ -87,6 +88,7 @@ class RingIO(C.Structure):
         ("done", C.c_void_p), ("truncated", C.c_void_p), ("obs", C.c_void_p), ("term_obs", C.c_void_p), ("roles", C.c_void_p),
         ("window", C.c_void_p), ("max_size", C.c_int64), ("idx", C.c_int64), ("states", C.c_void_p), ("next_states", C.c_void_p),
         ("ring_actions", C.c_void_p), ("ring_rewards", C.c_void_p), ("ring_dones", C.c_void_p), ("ring_imposters", C.c_void_p),
+        ("record", C.c_void_p), ("record_format", C.c_int32),
     ]
 
 
@@ -97,7 +99,7 @@ class PolicyOpts(C.Structure):
 class RecordLayout(C.Structure):
     _fields_ = [("record_bytes", C.c_int32), ("off_rewards", C.c_int32), ("off_actions", C.c_int32), ("off_done", C.c_int32),
                 ("off_truncated", C.c_int32), ("off_obs", C.c_int32), ("planar", C.c_int32), ("n_obs_segments", C.c_int32),
-                ("obs_segments", (C.c_int32 * 2) * 4)]
+                ("obs_segments", (C.c_int32 * 2) * 4), ("flags_packed", C.c_int32)]
 
 
 class StateView(C.Structure):

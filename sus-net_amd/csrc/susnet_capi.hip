@@ -1118,6 +1118,23 @@ extern "C" int susnet_qnet_policy_step(susnet_env *env, const int32_t *component
     return step_impl(env, io, nullptr, nullptr, stream, &f, opts);
 }
 
+extern "C" int susnet_record_layout_of(const susnet_env *env, int32_t record_format, susnet_record_layout_t *out) {
+    if (record_format == SUSNET_RECORD_DEFAULT) return susnet_record_layout(env, out);
+    if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    if (record_format != SUSNET_RECORD_COMPACT) return fail(SUSNET_E_INVALID, "susnet_record_layout_of: unknown record format");
+    if (env->spec != 2 || !env->c.duel_fast) return SUSNET_OK; // record_bytes = 0: only the 1v1 no-walls kernel has the compact record
+    out->record_bytes = 16;
+    out->off_rewards = 0;
+    out->off_obs = 8;
+    out->off_actions = out->off_done = out->off_truncated = 14;
+    out->flags_packed = 1;
+    out->n_obs_segments = 1;
+    out->obs_segments[0].off = 8;
+    out->obs_segments[0].len = 6;
+    return SUSNET_OK;
+}
+
 extern "C" int susnet_record_layout(const susnet_env *env, susnet_record_layout_t *out) {
     if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
@@ -1197,8 +1214,8 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         if (a.actions || a.rewards || a.done || a.trunc || o.mode != SUSNET_OBS_NONE)
             return fail(env, SUSNET_E_INVALID, "susnet_rollout: record is an alternative to the separate outputs, not an addition");
         susnet_record_layout_t lay;
-        susnet_record_layout(env, &lay);
-        if (lay.record_bytes == 0) return fail(env, SUSNET_E_INVALID, "susnet_rollout: this configuration has no packed record mode");
+        if (int rc = susnet_record_layout_of(env, io->record_format, &lay)) return rc;
+        if (lay.record_bytes == 0) return fail(env, SUSNET_E_INVALID, "susnet_rollout: this configuration has no packed record of the requested format");
         if ((uintptr_t)a.record % 16) return fail(SUSNET_E_INVALID, "record buffer must be 16-byte aligned");
         a.record_bytes = lay.record_bytes;
     }
@@ -1224,22 +1241,27 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const uint64_t limit = env->launch_limit; // (susnet_set_launch_limit; tests exercise the chunking on small batches)
     const uint64_t fit = limit / tick_bytes;
     if (a.record && fit < 1) return fail(env, SUSNET_E_INVALID, "susnet_rollout: one tick of records exceeds 2 GiB");
-    const int out = a.record                                ? OUT_RECORD
+    const int out = a.record                                ? (io->record_format == SUSNET_RECORD_COMPACT ? OUT_RECORD16 : OUT_RECORD)
                     : (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
                     : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
                     : (traj_flat && fit >= 1)               ? OUT_TRAJ_FLAT
                                                             : OUT_ANY;
-    if ((a.term_obs || a.roles) && !(all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8))
-        return fail(env, SUSNET_E_INVALID, "susnet_rollout: term_obs / roles go with the full trajectory and the raw uint8 observation");
-    if (tape && out != OUT_TRAJ_RAW8 && out != OUT_RECORD)
+    const bool rec_term = a.record && a.term_obs && !a.roles && spec == 2 && env->c.duel_fast; // whole records of the 1v1 kernel + the terminal states
+    if ((a.term_obs || a.roles) && !rec_term && !(all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8))
+        return fail(env, SUSNET_E_INVALID, "susnet_rollout: term_obs / roles go with the full trajectory and the raw uint8 observation (term_obs also "
+                                           "with the records of the 1v1 no-walls kernel)");
+    if (tape && out != OUT_TRAJ_RAW8 && out != OUT_RECORD && out != OUT_RECORD16)
         return fail(env, SUSNET_E_INVALID, "susnet_rollout on a TAPE handle stores the full trajectory with the raw uint8 observation, as separate "
                                       "tensors or as packed records (nothing else)");
-    const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD || out == OUT_TRAJ_FLAT) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
+    const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD || out == OUT_RECORD16 || out == OUT_TRAJ_FLAT) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);
         a.tick_base = env->ticks + (uint64_t)t0;
-        if (t0 > 0 && a.record) a.record += (uint64_t)chunk * tick_bytes;
+        if (t0 > 0 && a.record) {
+            a.record += (uint64_t)chunk * tick_bytes;
+            if (a.term_obs) a.term_obs += (uint64_t)chunk * (uint64_t)env->c.B * (uint64_t)env->layout.obs_raw_size;
+        }
         if (t0 > 0 && !a.record) { // only reached in the trajectory modes: the four trajectory outputs are bound, [T][B][...] slabs
             a.actions += (uint64_t)chunk * AB;
             a.rewards += (uint64_t)chunk * AB;
@@ -1313,11 +1335,33 @@ struct RingArgs {
     int64_t B, n0, n1; // envs; first / one-past-last transition (n = tick * B + env) this launch writes
     int32_t A, S, n_imp;
     int32_t rows_per_wave; // 64, or fewer when 64 rows of 2 x trajectory_size x S bytes would not fit the LDS images
+    // the trajectory as PACKED RECORDS (io.record; whole records only: the 1v1 kernels), wave-uniform: record size (0 = separate
+    // tensors) and field offsets; rec_packed: actions and flags share one byte (SUSNET_RECORD_COMPACT)
+    int32_t rec_bytes, rec_obs, rec_act, rec_rew, rec_done, rec_trunc, rec_packed;
 };
+// the trajectory's fields at (tick u, env b), from the separate tensors or from the records (a wave-uniform choice)
+__device__ __forceinline__ const uint8_t *ring_rec(const RingArgs &r, int64_t u, int64_t b) { return r.io.record + ((size_t)u * r.B + b) * (size_t)r.rec_bytes; }
+__device__ __forceinline__ uint32_t ring_done(const RingArgs &r, int64_t u, int64_t b) {
+    if (r.rec_bytes) return r.rec_packed ? (ring_rec(r, u, b)[r.rec_done] >> 6) & 1u : (uint32_t)ring_rec(r, u, b)[r.rec_done];
+    return r.io.done[u * r.B + b];
+}
+__device__ __forceinline__ uint32_t ring_trunc(const RingArgs &r, int64_t u, int64_t b) {
+    if (r.rec_bytes) return r.rec_packed ? (uint32_t)(ring_rec(r, u, b)[r.rec_trunc] >> 7) : (uint32_t)ring_rec(r, u, b)[r.rec_trunc];
+    return r.io.truncated[u * r.B + b];
+}
+__device__ __forceinline__ uint32_t ring_action(const RingArgs &r, int64_t t, int64_t b, int i) {
+    if (r.rec_bytes) return r.rec_packed ? (ring_rec(r, t, b)[r.rec_act] >> (3 * i)) & 7u : (uint32_t)ring_rec(r, t, b)[r.rec_act + i];
+    return r.io.actions[((size_t)t * r.B + b) * r.A + i];
+}
+__device__ __forceinline__ float ring_reward(const RingArgs &r, int64_t t, int64_t b, int i) {
+    if (r.rec_bytes) return reinterpret_cast<const float *>(ring_rec(r, t, b) + r.rec_rew)[i];
+    return r.io.rewards[((size_t)t * r.B + b) * r.A + i];
+}
 // the flattened state an env's window holds at virtual tick u (= the state after tick u; u < 0: the carried-in window)
 __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t u, int64_t b) {
     const int Tw = r.io.trajectory_size;
     if (u < 0) return r.io.window + ((size_t)b * Tw + (size_t)(Tw + u < 0 ? 0 : Tw + u)) * r.S; // window[Tw - 1] = state before tick 0
+    if (r.rec_bytes) return ring_rec(r, u, b) + r.rec_obs;
     return r.io.obs + ((size_t)u * r.B + b) * r.S;
 }
 // One wave per 64 consecutive transitions (32 / 16 / 8 for long windows: RingArgs::rows_per_wave).  Lane r gathers what its row needs into flat images in LDS, laid out exactly as the
@@ -1354,17 +1398,17 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
             for (int k = 1; k <= kRingFlagsUnroll; k++) { // every lane loads (tick clamped): no per-lane branch, no wait between the loads
                 const int64_t u = t - k < 0 ? 0 : t - k;
                 const bool want = k <= Tw; // (wave-uniform)
-                fd[k - 1] = want ? (uint32_t)r.io.done[u * r.B + b] : 0u;
-                ft[k - 1] = want ? (uint32_t)r.io.truncated[u * r.B + b] : 0u;
+                fd[k - 1] = want ? ring_done(r, u, b) : 0u;
+                ft[k - 1] = want ? ring_trunc(r, u, b) : 0u;
             }
 #pragma unroll
             for (int k = kRingFlagsUnroll; k >= 1; k--)
                 if ((fd[k - 1] | ft[k - 1]) != 0u && t - k >= 0) e = t - k; // (descending k: the most recent boundary wins)
         } else {
             for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
-                if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
+                if (ring_done(r, u, b) | ring_trunc(r, u, b)) { e = u; break; }
         }
-        const uint32_t dn = r.io.done[t * r.B + b], tr = r.io.truncated[t * r.B + b];
+        const uint32_t dn = ring_done(r, t, b), tr = ring_trunc(r, t, b);
         const uint32_t role_bits = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << NI) - 1u);
         uint8_t *my_st = st_img + (size_t)lane * TS, *my_nx = nx_img + (size_t)lane * TS;
         // The row needs Tw + 1 source states (replay_memory.py:108-113, 122-127): the window's Tw states -> states[k], and shifted by one
@@ -1373,7 +1417,7 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
         // byte tail.  All loads of a group of kRingGroup states are issued before the first LDS store: one memory round trip per group,
         // not one per dword (the rolled load -> store loop this replaces made 18 dependent round trips per row and left the kernel
         // latency-bound at 3.7 TB/s).
-        const uint8_t *nxt = ((dn | tr) ? r.io.term_obs : r.io.obs) + ((size_t)t * r.B + b) * S;
+        const uint8_t *nxt = (dn | tr) ? r.io.term_obs + ((size_t)t * r.B + b) * S : ring_state(r, t, b);
         auto source = [&](int k) -> const uint8_t * {
             if (k >= Tw) return nxt;
             int64_t u = t - Tw + k;
@@ -1427,8 +1471,8 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
 #pragma unroll
             for (int q = 0; q < 8; q++)
                 if (i0 + q < A) {
-                    av[q] = r.io.actions[((size_t)t * r.B + b) * A + i0 + q];
-                    rv[q] = r.io.rewards[((size_t)t * r.B + b) * A + i0 + q];
+                    av[q] = (uint8_t)ring_action(r, t, b, i0 + q);
+                    rv[q] = ring_reward(r, t, b, i0 + q);
                 }
 #pragma unroll
             for (int q = 0; q < 8; q++)
@@ -1507,7 +1551,7 @@ __global__ __launch_bounds__(64) void k_ring_window(RingArgs r) {
     const int64_t t = r.io.n_ticks;
     int64_t e = -(1ll << 62);
     for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
-        if (r.io.done[u * r.B + b] | r.io.truncated[u * r.B + b]) { e = u; break; }
+        if (ring_done(r, u, b) | ring_trunc(r, u, b)) { e = u; break; }
     // in place, slots ascending: slot k of the new window comes from obs, or (launches shorter than the window) from slot
     // k + t > k of the old one, which has not been overwritten yet
     // (a group's loads are all issued before its first store, as in k_ring_append: a slot read from the old window lies above every slot
@@ -1555,7 +1599,10 @@ extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, voi
     if (!env || !io) return fail(SUSNET_E_INVALID, "null argument");
     if (io->n_ticks < 1 || io->trajectory_size < 1 || io->max_size < 1 || io->idx < 0 || io->idx >= io->max_size)
         return fail(SUSNET_E_INVALID, "susnet_ring_append: n_ticks, trajectory_size, max_size must be positive and 0 <= idx < max_size");
-    if (!io->actions || !io->rewards || !io->done || !io->truncated || !io->obs || !io->term_obs || !io->window || !io->states ||
+    const bool from_records = io->record != nullptr;
+    if (from_records && (io->actions || io->rewards || io->done || io->truncated || io->obs))
+        return fail(SUSNET_E_INVALID, "susnet_ring_append: record is an alternative to the separate trajectory tensors, not an addition");
+    if ((!from_records && (!io->actions || !io->rewards || !io->done || !io->truncated || !io->obs)) || !io->term_obs || !io->window || !io->states ||
         !io->next_states || !io->ring_actions || !io->ring_rewards || !io->ring_dones || !io->ring_imposters)
         return fail(SUSNET_E_INVALID, "susnet_ring_append: null buffer");
     if (!io->roles && env->c.shuffle_imp) return fail(SUSNET_E_INVALID, "susnet_ring_append: roles are drawn per episode here (shuffle_imposter_index): pass roles");
@@ -1565,6 +1612,16 @@ extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, voi
     r.A = env->c.A;
     r.S = env->layout.obs_raw_size;
     r.n_imp = env->c.n_imp;
+    r.rec_bytes = 0;
+    if (from_records) { // the trajectory as the packed records a fused rollout wrote (whole records: the 1v1 kernels)
+        susnet_record_layout_t lay;
+        if (int rc = susnet_record_layout_of(env, io->record_format, &lay)) return rc;
+        if (lay.record_bytes == 0 || lay.planar || lay.n_obs_segments != 1)
+            return fail(env, SUSNET_E_INVALID, "susnet_ring_append: reads packed records where the handle stores them whole (the 1v1 kernels); the "
+                                               "multi-agent kernels' planar records go through the separate trajectory tensors");
+        r.rec_bytes = lay.record_bytes; r.rec_obs = lay.off_obs; r.rec_act = lay.off_actions; r.rec_rew = lay.off_rewards;
+        r.rec_done = lay.off_done; r.rec_trunc = lay.off_truncated; r.rec_packed = lay.flags_packed;
+    }
     const int64_t total = (int64_t)io->n_ticks * r.B;
     r.n0 = total > io->max_size ? total - io->max_size : 0; // (earlier rows would be overwritten by later ones of this same launch)
     r.n1 = total;

@@ -366,7 +366,9 @@ __global__ __launch_bounds__(kBlock) void k_step(Consts c, State s, StepArgs a, 
 // that is instruction-fetch bound): OUT_ANY = whatever pointers are non-null / any observation mode;
 // OUT_NONE = nothing (state-only fast-forward); OUT_TRAJ_RAW8 = actions + rewards + done + truncated + the raw
 // uint8 observation (the populate()-shaped record)
-enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4, OUT_TRAJ_FLAT = 5 };
+enum : int { OUT_ANY = 0, OUT_NONE = 1, OUT_TRAJ_RAW8 = 2, OUT_TRAJ = 3, OUT_RECORD = 4, OUT_TRAJ_FLAT = 5, OUT_RECORD16 = 6 };
+// OUT_RECORD16 (the 1v1 no-walls kernel only): the COMPACT record -- 16 bytes, one full-line store per env-step: rewards f32[2] | x0 y0 x1 y1
+// alive0 alive1 (the raw row, whole bytes) | one byte a0 | a1 << 3 | done << 6 | truncated << 7 | 0 (SUSNET_RECORD_COMPACT)
 // OUT_TRAJ_FLAT = OUT_TRAJ + the float32 FlatFeaturizer row of the configuration's compiled-in layout (susnet_flat.h)
 // the replay feed (term_obs, roles) only exists next to the full trajectory with the raw uint8 observation (susnet_rollout refuses
 // it elsewhere): the other instantiations carry neither the two pointers nor their per-tick tests
@@ -1296,9 +1298,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     life.clear();
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ || kFlat;
     constexpr bool kRec = OUT == OUT_RECORD; // one 20-byte record per env-step: rewards | actions done truncated | x0 y0 x1 y1 | alive0 alive1 0 0
+    constexpr bool kRec16 = OUT == OUT_RECORD16; // the compact 16-byte record (see OUT_RECORD16)
+    constexpr uint32_t kRecBytes = kRec16 ? 16u : 20u;
     const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     const uint64_t B = (uint64_t)c.B;
-    BufDst drec = make_buf_dst(a.record, nt * 20u * B, (uint32_t)bl * 20u);
+    BufDst drec = make_buf_dst(a.record, nt * kRecBytes * B, (uint32_t)bl * kRecBytes);
     BufDst da = make_buf_dst(a.actions, nt * 2u * B, (uint32_t)bl * 2u + ghost);
     BufDst dr = make_buf_dst(a.rewards, nt * 8u * B, (uint32_t)bl * 8u + ghost);
     BufDst dd = make_buf_dst(a.done, nt * B, (uint32_t)bl + ghost);
@@ -1321,7 +1325,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * (2u * slab_d); dr.so = t32 * (8u * slab_d); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
-        if (kRec) drec.so = (uint32_t)tick * (20u * slab_d);
+        if (kRec || kRec16) drec.so = (uint32_t)tick * (kRecBytes * slab_d);
         uint32_t a0, a1;
         if constexpr (RNG::kNumpy) { // base.py:326-330 with numpy's own words
             a0 = rng.bounded(6u);
@@ -1376,7 +1380,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
                 if (!RNG::kNumpy) rng.cur += (uint64_t)hit; // the landed kill's word of the event stream: a hit ends the episode (the crew has
                                                             // one member), so it is counted here instead of by a 64-bit add on every tick
                 life.add_episode(e, trunc != 0u);
-                if (kFeed(OUT) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
+                if ((kFeed(OUT) || kRec || kRec16) && a.term_obs != nullptr) { // the terminal state, before the in-launch reset replaces it
                     PtrDst tp{a.term_obs + ((int64_t)tick * c.B + b) * 6};
                     tp.st32(0u, d.pq - k01);
                     tp.st16(4u, duel_alive_bytes(d));
@@ -1406,6 +1410,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             drec.st128(0u, __float_as_uint(r0), __float_as_uint(r1), a0 | (a1 << 8) | (done << 16) | (trunc << 24), d.pq - k01);
             drec.st32(16u, duel_alive_bytes(d));
         }
+        if (kRec16) // rewards | x0 y0 x1 y1 | alive0 alive1, a0 | a1 << 3 | done << 6 | truncated << 7, 0: ONE store, a whole 16-byte piece of a line
+            drec.st128(0u, __float_as_uint(r0), __float_as_uint(r1), d.pq - k01, duel_alive_bytes(d) | ((a0 | (a1 << 3) | (done << 6) | (trunc << 7)) << 16));
         if constexpr (kFlat) { // onehot_pos of the state after the step (and after an in-launch reset)
             const uint32_t pos = d.pq - k01;
             const uint32_t fx[2] = {pos & 0xffu, (pos >> 16) & 0xffu}, fy[2] = {(pos >> 8) & 0xffu, pos >> 24}, fal[2] = {d.lv & 1u, d.lv >> 31};
@@ -1453,8 +1459,10 @@ template <class SPEC>
 void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
     constexpr bool kDuelSpec = !SPEC::kGeneric && SPEC::kA == 2 && SPEC::kJ == 0 && SPEC::kVar == SUSNET_VARIANT_ITG && SPEC::kStaticRoles && SPEC::kFixedOrder;
     if constexpr (kDuelSpec) {
-        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD || out == OUT_TRAJ_FLAT)) { // susnet_duel.h
+        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD || out == OUT_TRAJ_FLAT || out == OUT_RECORD16)) { // susnet_duel.h
             if (out == OUT_TRAJ_FLAT) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_FLAT>), g, blk, sh, st, c, s, a, o);
+            else if (tape && out == OUT_RECORD16) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD16>), g, blk, sh, st, c, s, a, o);
+            else if (out == OUT_RECORD16) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD16>), g, blk, sh, st, c, s, a, o);
             else if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
             else if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
             else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);

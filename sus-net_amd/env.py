@@ -717,10 +717,16 @@ class BatchedFourRoomEnv:
         longer trajectories run as consecutive launches.  Launch plumbing only -- results do not depend on it."""
         L.check(self.lib.susnet_set_launch_limit(self._h, int(nbytes)))
 
-    def record_layout(self):
-        """Field offsets of the packed per-env-step trajectory record, or None when the configuration has none."""
+    @staticmethod
+    def _record_format(packed) -> int:
+        """``packed`` of ``alloc_rollout`` / ``rollout``: True = the handle's default record, "compact" = SUSNET_RECORD_COMPACT."""
+        return L.RECORD_COMPACT if packed == "compact" else L.RECORD_DEFAULT
+
+    def record_layout(self, packed=True):
+        """Field offsets of the packed per-env-step trajectory record (``packed="compact"``: the 16-byte record of the 1v1 no-walls
+        game), or None when the configuration has none."""
         lay = L.RecordLayout()
-        L.check(self.lib.susnet_record_layout(self._h, C.byref(lay)))
+        L.check(self.lib.susnet_record_layout_of(self._h, self._record_format(packed), C.byref(lay)))
         return lay if lay.record_bytes else None
 
     @staticmethod
@@ -736,11 +742,11 @@ class BatchedFourRoomEnv:
             pieces.append((full + (8 if rem == 12 else 0), 4))
         return pieces
 
-    def unpack_record(self, record: torch.Tensor) -> torch.Tensor:
+    def unpack_record(self, record: torch.Tensor, packed=True) -> torch.Tensor:
         """uint8 ``[T, B, record_bytes]`` records in field order (``susnet_record_layout_t`` offsets) from the buffer a packed rollout
         wrote: the buffer itself where the handle stores whole records, a gathered COPY where it stores them as planes of 16-byte pieces
         (``planar``: the multi-agent kernels)."""
-        lay = self.record_layout()
+        lay = self.record_layout(packed)
         if not lay.planar:
             return record
         T, B, R = record.shape
@@ -750,11 +756,17 @@ class BatchedFourRoomEnv:
             out[:, :, s:s + w] = flat[:, B * s:B * s + B * w].reshape(T, B, w)
         return out
 
-    def record_fields(self, record: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def record_fields(self, record: torch.Tensor, packed=True) -> Dict[str, torch.Tensor]:
         """``actions / rewards / done / truncated / obs`` of a packed record buffer, shaped like the separate trajectory tensors: strided
-        VIEWS into the buffer for whole-record layouts, slices of the unpacked copy for planar ones."""
-        lay, A, F = self.record_layout(), self.n_agents, self.flattened_state_size
-        rec = self.unpack_record(record)
+        VIEWS into the buffer for whole-record layouts, slices of the unpacked copy for planar ones; decoded COPIES of actions and flags
+        where they share a byte (``flags_packed``: the compact 1v1 record)."""
+        lay, A, F = self.record_layout(packed), self.n_agents, self.flattened_state_size
+        rec = self.unpack_record(record, packed)
+        if lay.flags_packed:  # one byte: a0 | a1 << 3 | done << 6 | truncated << 7
+            fb = rec[:, :, lay.off_actions]
+            return {"rewards": rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].view(torch.float32),
+                    "actions": torch.stack([(fb >> (3 * i)) & 7 for i in range(A)], dim=2), "done": ((fb >> 6) & 1).to(torch.bool),
+                    "truncated": (fb >> 7).to(torch.bool), "obs": rec[:, :, lay.off_obs:lay.off_obs + F]}
         return {"rewards": rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].view(torch.float32) if not lay.planar else
                            rec[:, :, lay.off_rewards:lay.off_rewards + 4 * A].contiguous().view(torch.float32),
                 "actions": rec[:, :, lay.off_actions:lay.off_actions + A],
@@ -779,14 +791,18 @@ class BatchedFourRoomEnv:
         T, A, B = int(n_ticks), self.n_agents, self.batch
         out = {"n_ticks": T}
         if packed:
-            lay = self.record_layout()
-            assert lay is not None, "this configuration has no packed record mode"
+            lay = self.record_layout(packed)
+            assert lay is not None, "this configuration has no packed record mode" + (" of the compact format" if packed == "compact" else "")
+            out["_record_format"] = self._record_format(packed)
             assert set(store) == {"actions", "rewards", "done", "truncated"} and obs is not None and obs.mode == "raw" \
                 and obs.dtype == torch.uint8, "packed=True carries the full trajectory and the raw uint8 observation"
             rec = torch.empty(T, B, lay.record_bytes, dtype=torch.uint8, device=self.device)
             out["record"] = rec
-            if not lay.planar:  # whole records: the fields are views that every launch refreshes
-                out.update(self.record_fields(rec))
+            if not lay.planar and not lay.flags_packed:  # whole records: the fields are views that every launch refreshes
+                out.update(self.record_fields(rec, packed))
+            if replay_feed:  # (whole records only: the 1v1 kernels) the true terminal states, for susnet_ring_append reading the records
+                assert not lay.planar, "replay_feed with packed records: handles that store whole records (the 1v1 kernels)"
+                out["term_obs"] = torch.zeros(T, B, self.flattened_state_size, dtype=torch.uint8, device=self.device)
             # (planar records -- the multi-agent kernels: the fields are gathered after a launch, `record_fields(bufs["record"])`;
             # `rollout()` does it)
             return out
@@ -820,6 +836,9 @@ class BatchedFourRoomEnv:
             io = L.RolloutIO()
             if "record" in bufs:
                 io.record = bufs["record"].data_ptr()
+                io.record_format = bufs.get("_record_format", L.RECORD_DEFAULT)
+                if "term_obs" in bufs:
+                    io.term_obs = bufs["term_obs"].data_ptr()
             else:
                 for name in ("actions", "rewards", "done", "truncated"):
                     if name in bufs:
@@ -840,8 +859,8 @@ class BatchedFourRoomEnv:
         Returns a dict of trajectory tensors with a leading tick dimension."""
         bufs = self.alloc_rollout(n_ticks, store, obs, packed=packed)
         self.rollout_into(n_ticks, bufs)
-        if packed and "actions" not in bufs:  # planar records: gather the fields (copies)
-            bufs.update(self.record_fields(bufs["record"]))
+        if packed and "actions" not in bufs:  # planar records / shared flag bytes: gather the fields (copies)
+            bufs.update(self.record_fields(bufs["record"], packed))
         return bufs
 
     def observe(self, obs: Optional[ObsConfig] = None):

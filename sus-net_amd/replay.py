@@ -79,11 +79,13 @@ class DeviceReplayBuffer:
                      imposters=self.imposters[i], dones=self.dones[i])
 
     @torch.no_grad()
-    def populate_fused(self, env, num_steps: int, ticks_per_launch: int = 256) -> int:
+    def populate_fused(self, env, num_steps: int, ticks_per_launch: int = 256, packed=False) -> int:
         """``ReplayBuffer.populate`` (src/replay_memory.py:96-143) for B environments in lockstep, on the device:
         ``env.reset()``, then ``num_steps`` ticks of the fused random rollout, appended to the ring by ``susnet_ring_append``.
         Row order = tick-major, env-minor (what B sequential ``add`` calls per tick produce); with ``batch=1`` and
-        ``rng='numpy'`` the ring equals the reference's for the same numpy seed.  ``env`` must auto-reset."""
+        ``rng='numpy'`` the ring equals the reference's for the same numpy seed.  ``env`` must auto-reset.  ``packed`` (True / "compact";
+        handles that store whole records: the 1v1 kernels): the rollout writes packed records and ``susnet_ring_append`` reads them in
+        place -- no separate trajectory tensors."""
         import ctypes as C
 
         from . import _lib as L
@@ -97,12 +99,15 @@ class DeviceReplayBuffer:
         first = env.observe(raw8)
         window = first.unsqueeze(1).repeat(1, T, 1).contiguous()  # replay_memory.py:108-113: the first state T times
         n_launch = max(1, min(int(ticks_per_launch), int(num_steps)))
-        bufs = env.alloc_rollout(n_launch, obs=raw8, replay_feed=True)
+        bufs = env.alloc_rollout(n_launch, obs=raw8, replay_feed=True, packed=packed)
         io = L.RingIO()
         io.trajectory_size = T
-        io.actions, io.rewards = bufs["actions"].data_ptr(), bufs["rewards"].data_ptr()
-        io.done, io.truncated = bufs["done"].data_ptr(), bufs["truncated"].data_ptr()
-        io.obs, io.term_obs, io.roles = bufs["obs"].data_ptr(), bufs["term_obs"].data_ptr(), bufs["roles"].data_ptr()
+        if packed:
+            io.record, io.record_format, io.term_obs = bufs["record"].data_ptr(), bufs["_record_format"], bufs["term_obs"].data_ptr()
+        else:
+            io.actions, io.rewards = bufs["actions"].data_ptr(), bufs["rewards"].data_ptr()
+            io.done, io.truncated = bufs["done"].data_ptr(), bufs["truncated"].data_ptr()
+            io.obs, io.term_obs, io.roles = bufs["obs"].data_ptr(), bufs["term_obs"].data_ptr(), bufs["roles"].data_ptr()
         io.window = window.data_ptr()
         io.max_size = self.max_size
         io.states, io.next_states = self.states.data_ptr(), self.next_states.data_ptr()

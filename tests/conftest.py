@@ -30,7 +30,7 @@ def load_golden(path):
 
 
 def trace_names(prefix=""):
-    return [os.path.basename(p)[:-4] for p in golden_files(prefix) if not os.path.basename(p).startswith(("feat_", "crc_", "model_", "replay_"))]
+    return [os.path.basename(p)[:-4] for p in golden_files(prefix) if not os.path.basename(p).startswith(("feat_", "crc_", "model_", "replay_", "collect_"))]
 
 
 def crc_names():

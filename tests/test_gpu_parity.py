@@ -180,8 +180,12 @@ def test_hip_matches_reference_crc_streams(pkg, name, kernels, monkeypatch):
 
 
 @pytest.mark.parametrize("epw", [16, 32, 64])
-@pytest.mark.parametrize("layout", ["separate", "packed"])
-@pytest.mark.parametrize("name", crc_names())
+def _tape_layouts():
+    # (the compact 16-byte record exists for the 1v1 game on a grid without walls only)
+    return [(n, lay) for n in crc_names() for lay in ("separate", "packed") + (("compact",) if n.startswith("crc_itg_1v1_nw") else ())]
+
+
+@pytest.mark.parametrize("name,layout", _tape_layouts())
 def test_fused_rollout_on_numpy_tapes_matches_reference_crc_streams(pkg, oracle_mod, name, layout, epw, monkeypatch):
     """The FUSED rollout kernels fed numpy's own MT19937 words, through the very instantiations bench.py times: trajectory as
     separate tensors (OUT_TRAJ_RAW8) and as PACKED RECORDS (OUT_RECORD: the headline layout), at 16, 32 and 64 environments
@@ -206,9 +210,9 @@ def test_fused_rollout_on_numpy_tapes_matches_reference_crc_streams(pkg, oracle_
     env = env_from_meta(pkg, meta, B, rng="numpy", tape_words=1 << 14, auto_reset=True, check_errors=False)
     lay = env.native_layout()
     assert lay.envs_per_wave == epw and lay.test_overrides == 2  # SUSNET_OVERRIDE_EPW, read when the handle was created
-    packed = layout == "packed"
-    if packed and env.record_layout() is None:
-        pytest.skip("configuration not compiled in: no packed record")
+    packed = {"separate": False, "packed": True, "compact": "compact"}[layout]  # (compact: the 16-byte record of the 1v1 no-walls kernel)
+    if packed and env.record_layout(packed) is None:
+        pytest.skip("no packed record of this format for the configuration")
     if not packed and epw == 32 and env.record_layout() is None:
         pytest.skip("generic kernels: 16 and 64 environments per wave cover the lane masking")
     env._reseed(seeds)
@@ -1439,8 +1443,13 @@ def replay_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "replay_*.npz")))
 
 
-@pytest.mark.parametrize("name", replay_names())
-def test_native_replay_ring_matches_reference_populate(pkg, name):
+def _replay_feeds():
+    # (susnet_ring_append reads packed records in place where the handle stores them whole: the 1v1 kernels)
+    return [(n, f) for n in replay_names() for f in ("tensors",) + (("records", "compact") if n.startswith("replay_itg_1v1") else ())]
+
+
+@pytest.mark.parametrize("name,feed", _replay_feeds())
+def test_native_replay_ring_matches_reference_populate(pkg, name, feed):
     """susnet_ring_append fed by the fused rollout against the REFERENCE's own `ReplayBuffer.populate` tensors
     (tests/golden/generate_replay.py: unmodified src/replay_memory.py on the unmodified env after np.random.seed): one env,
     numpy's words as the tape, several launches (the window is carried across them; one fixture wraps the ring)."""
@@ -1450,7 +1459,11 @@ def test_native_replay_ring_matches_reference_populate(pkg, name):
     env = env_from_meta(pkg, meta, 1, rng="numpy", tape_words=1 << 16, auto_reset=True, check_errors=False)
     env._reseed([meta["seed"]])
     buf = pkg.DeviceReplayBuffer(max_size, meta["state_size"], T, meta["n_agents"], meta["n_imposters"], device=env.device)
-    assert buf.populate_fused(env, num_steps, ticks_per_launch=256) == num_steps
+    if feed != "tensors":  # susnet_ring_append reading the rollout's packed records in place (whole records: the 1v1 kernels)
+        lay = env.record_layout(True if feed == "records" else "compact")
+        if lay is None or lay.planar:
+            pytest.skip("whole packed records of this format: the 1v1 kernels only")
+    assert buf.populate_fused(env, num_steps, ticks_per_launch=256, packed={"tensors": False, "records": True, "compact": "compact"}[feed]) == num_steps
     env.poll_errors()
     assert (buf.idx, buf.size) == (meta["idx"], meta["size"])
     n = buf.size

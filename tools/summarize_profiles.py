@@ -30,8 +30,9 @@ for cdir in sorted(glob.glob(f"{root}/*")):
                 open(f"profiles/{tag}_{cfg}_bench_under_rocprofv3.json", "w").write(ln)
                 c = json.loads(ln)["config"]
                 # what was profiled: bench.py attaches these PMC bytes only to a run of the same layout / batch / ticks
-                per["command"] = {"packed": c.get("trajectory_layout", "").startswith("packed"), "batch": c.get("batch_per_gpu"),
-                                  "ticks": c.get("ticks_per_launch")}
+                per["command"] = {"packed": c.get("trajectory_layout", "").startswith(("packed", "compact")), "batch": c.get("batch_per_gpu"),
+                                  "ticks": c.get("ticks_per_launch"), "bytes_per_env_step": json.loads(ln)["roofline"].get("bytes_per_env_step"),
+                                  "trajectory_layout": c.get("trajectory_layout")}
     for d in sorted(glob.glob(f"{cdir}/pmc_*")):
         if not os.path.isdir(d):
             continue
