@@ -179,12 +179,12 @@ def test_hip_matches_reference_crc_streams(pkg, name, kernels, monkeypatch):
     assert bad.size == 0, f"{name}: first mismatch at (seed index, step) = {bad[0].tolist()}"
 
 
-@pytest.mark.parametrize("epw", [16, 32, 64])
 def _tape_layouts():
     # (the compact 16-byte record exists for the 1v1 game on a grid without walls only)
     return [(n, lay) for n in crc_names() for lay in ("separate", "packed") + (("compact",) if n.startswith("crc_itg_1v1_nw") else ())]
 
 
+@pytest.mark.parametrize("epw", [16, 32, 64])
 @pytest.mark.parametrize("name,layout", _tape_layouts())
 def test_fused_rollout_on_numpy_tapes_matches_reference_crc_streams(pkg, oracle_mod, name, layout, epw, monkeypatch):
     """The FUSED rollout kernels fed numpy's own MT19937 words, through the very instantiations bench.py times: trajectory as
