@@ -3,6 +3,8 @@ be bit-exact against (a) the golden traces of the reference and (b) the CPU orac
 import importlib
 import re
 
+import sys
+
 import numpy as np
 import pytest
 
@@ -501,6 +503,44 @@ def test_graph_replayed_random_steps_match_oracle(pkg, oracle_mod):
         compare_full_state(env, ob, f"{name} after graph replays")
 
 
+def test_two_rank_bench_line_equals_one_process_over_the_same_env_ids(pkg):
+    """bench.py's N > 1 path end to end on this one-GPU box: `bench.launch_command(2, ...)` started as a CHILD process (two ranks under
+    torch.distributed.run, gloo rendezvous on 127.0.0.1, both ranks on device 0: SUSNET_BENCH_BACKEND / SUSNET_BENCH_ONE_DEVICE) -- rank 1
+    executes the timed path, the all-gather of the episode metrics and the per-rank launch times.  The JSON line's episode metrics must
+    equal a one-process run over the same GLOBAL env ids (batch 2 x 4096, same seed, same launches): sharding is invisible."""
+    import importlib.util
+    import json
+    import os
+    import socket
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    Bshard, K, W, T = 4096, 3, 1, 64
+    flags = ["--steps", str(K), "--warmup", str(W), "--ticks", str(T), "--config", "cfg3", "--no-cpu-baseline", "--no-secondary", "--repeats", "0"]
+    env = dict(os.environ, SUSNET_BENCH_BACKEND="gloo", SUSNET_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(bench.launch_command(2, port, ["--gpus", "2", "--batch", str(Bshard)] + flags), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 2 * Bshard and two["scaling"] == "weak"
+    per_rank = two["roofline"]["avg_launch_us_per_rank"]
+    assert len(per_rank["all"]) == 2 and per_rank["min"] > 0
+    assert two["episode_metrics"]["env_steps"] == 2 * Bshard * T * (K + W + 8)  # (warm-up + timed + the 8 event-pair launches)
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", str(2 * Bshard)] + flags, env=dict(os.environ),
+                       capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-2000:]
+    one = json.loads([ln for ln in q.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert one["episode_metrics"] == two["episode_metrics"], (one["episode_metrics"], two["episode_metrics"])
+    assert one["episode_metrics"]["episodes"] > 0
+
+
 def test_node_metrics_over_rccl(pkg):
     """The one collective of the path (dist.node_metrics: device reduction + all_gather_into_tensor) through the real
     RCCL backend, single rank (a one-GPU box cannot host two RCCL ranks; the two-rank control flow is the gloo test)."""
@@ -650,15 +690,17 @@ def test_long_trajectory_launches_are_chunked(pkg, oracle_mod, monkeypatch):
     assert int(env.tick) == T
 
 
-@pytest.mark.parametrize("name,B", [("base_2v6_j4_14", 32768 + 96), ("itg_1v1_nowalls", 65536 + 32), ("base_1v2_j4_14", 40000),
-                                    ("tagging_1v4_j5", 4096), ("itg_1v5_j3", 2048)])
-def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B):
-    """Batches >= 32768 / 65536 run 32 / 64 environments per wave (smaller ones 16): same results."""
+@pytest.mark.parametrize("name,B,packed", [("base_2v6_j4_14", 32768 + 96, False), ("itg_1v1_nowalls", 65536 + 32, False), ("base_1v2_j4_14", 65536 + 32, False),
+                                           ("base_1v2_j4_14", 65536 + 32, True), ("base_2v6_j4_14", 32768, True), ("itg_1v1_nowalls", 65536, "compact"),
+                                           ("tagging_1v4_j5", 4096, False), ("itg_1v5_j3", 2048, False)])
+def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B, packed):
+    """Batches >= 32768 / 65536 run 32 / 64 environments per wave (smaller ones 16): same results.  The BASELINE configurations at the
+    benchmark's batch (+ a ragged last wave), separate tensors and the records bench.py times, against the oracle (OpenMP batch)."""
     T, seed = 24, 31
     env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
     env.reset()
     ob.reset(threads=0)
-    traj = env.rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8))
+    traj = env.rollout(T, obs=pkg.ObsConfig("raw", dtype=torch.uint8), packed=packed)
     torch.cuda.synchronize()
     acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
     for s in range(T):
@@ -1280,12 +1322,13 @@ def test_one_kernel_policy_tick_long_horizon_and_full_size(pkg, oracle_mod):
             np.testing.assert_array_equal(np_(env.obs), ob.obs_flat(comps), err_msg=f"fused flat obs tick {tick}")
         ends += int(odone.sum()) + int(otrunc.sum())
     assert ends > 50, "episodes ended inside the one-kernel tick"
-    # full size, against the two-launch tick
+    # full size (the benchmark's 65 536 envs): against the two-launch tick on a twin handle AND against the oracle (OpenMP batch)
     Bf = 65536
     e1, _ = make_pair(pkg, oracle_mod, name, Bf, seed, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
-    e2, _ = make_pair(pkg, oracle_mod, name, Bf, seed, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
+    e2, obf = make_pair(pkg, oracle_mod, name, Bf, seed, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
     e1.reset()
     e2.reset()
+    obf.reset(threads=0)
     two = pkg.PolicyRollout(e1, model, crew_model=None, components=comps, epsilon=0.1, mask_dead=True)
     one = pkg.PolicyRollout(e2, model, crew_model=None, components=comps, epsilon=0.1, mask_dead=True)
     two.one_kernel_tick = False
@@ -1295,6 +1338,12 @@ def test_one_kernel_policy_tick_long_horizon_and_full_size(pkg, oracle_mod):
         a2, r2, d2, t2 = one.tick()
         assert torch.equal(a1, a2) and torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2) and torch.equal(t1, t2), tick
         assert torch.equal(e1.obs, e2.obs), tick
+        orew, odone, otrunc, rc = obf.step(np_(a2), threads=0)
+        assert rc == 0 and np.array_equal(np_(r2).astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"full size: rewards tick {tick}"
+        np.testing.assert_array_equal(np_(d2), odone.astype(bool), err_msg=f"full size: done tick {tick}")
+        np.testing.assert_array_equal(np_(t2), otrunc.astype(bool), err_msg=f"full size: truncated tick {tick}")
+        obf.reset(mask=(odone | otrunc).astype(bool))
+    np.testing.assert_array_equal(np_(e2.obs), obf.obs_flat(comps), err_msg="full size: fused flat obs after 12 ticks")
 
 
 @pytest.mark.parametrize("name,comps,hidden,slopes,B", [
