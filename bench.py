@@ -250,6 +250,10 @@ def main():
                     "the same fields, one or a few wide stores per lane instead of one narrow store per tensor), 0 = separate "
                     "trajectory tensors, 2 = the COMPACT record where the configuration has one (cfg2: 16 bytes, actions and flags in one "
                     "byte), -1 (default) = compact, else packed, where the configuration has it")
+    ap.add_argument("--settle-ms", type=float, default=150.0, help="before the W warm-up steps: untimed launches of the same bench step until the device "
+                    "has been busy this long.  An MI355X that has been idle takes tens of milliseconds of sustained load to reach its steady clocks: 5 "
+                    "warm-up launches of 0.1-0.3 ms each leave the timed region on the ramp (cfg3: 107 G with 5 warm-up launches, 118.5 G with 50 "
+                    "or 400 -- same box, same binary).  Reported in the line as `settle_ms`; 0 = none")
     ap.add_argument("--repeats", type=int, default=5, help="the K-launch timed region is run this many more times back to back (after the "
                     "headline measurement, which stays as it is): median / min / max of the repeats are reported in `repeats`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -352,6 +356,12 @@ def main():
                     return n
         else:
             runner = (lambda n: run_fused(env, n, ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
+        if args.settle_ms > 0:  # steady clocks first (see --settle-ms): untimed, not part of the W warm-up steps
+            unit = graph_ticks if (mode == "policy" and graph_ticks > 0) else 1
+            t_s = time.perf_counter()
+            while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+                runner(4 * unit)
+                torch.cuda.synchronize(device)
         runner(W)
         sync_all()
         stream = torch.cuda.current_stream(device)
@@ -457,7 +467,7 @@ def main():
     line = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": res["seconds"] * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
+        "dtype": "u8", "data": "synthetic", "settle_ms": args.settle_ms,
         "config": {"workload": spec["workload"], "mode": args.mode, "obs": args.obs, "batch_per_gpu": B,
                    "global_batch": B * world, "ticks_per_launch": ticks_per_step,
                    "step_definition": (f"one susnet_rollout launch = {ticks_per_step} lockstep ticks x {B} envs per GPU" if args.mode == "fused"

@@ -1238,9 +1238,12 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const bool traj_flat = all_traj && !tape && o.mode == SUSNET_OBS_FLAT && o.dtype == SUSNET_F32 && (flat1 || flat3) && !a.term_obs && !a.roles;
     const uint64_t obs_tick_bytes = (uint64_t)o.tick_stride * (o.dtype == SUSNET_F32 ? 4u : 1u);
     const uint64_t tick_bytes = a.record ? (uint64_t)env->c.B * (uint64_t)a.record_bytes : std::max<uint64_t>(4u * AB, traj_flat ? obs_tick_bytes : (uint64_t)o.tick_stride);
-    const uint64_t limit = env->launch_limit; // (susnet_set_launch_limit; tests exercise the chunking on small batches)
+    // (susnet_set_launch_limit; tests exercise the chunking on small batches).  Records are addressed slab by slab (record_slab): unless a limit
+    // was set, a record launch takes any number of ticks
+    const uint64_t limit = (a.record && env->launch_limit == env->launch_limit_default && !(env->layout.test_overrides & SUSNET_OVERRIDE_TRAJ_MAX_BYTES))
+                               ? ~0ull : env->launch_limit;
     const uint64_t fit = limit / tick_bytes;
-    if (a.record && fit < 1) return fail(env, SUSNET_E_INVALID, "susnet_rollout: one tick of records exceeds 2 GiB");
+    if (a.record && (fit < 1 || tick_bytes > (1ull << 31) - 1u)) return fail(env, SUSNET_E_INVALID, "susnet_rollout: one tick of records exceeds 2 GiB");
     const int out = a.record                                ? (io->record_format == SUSNET_RECORD_COMPACT ? OUT_RECORD16 : OUT_RECORD)
                     : (none_traj && o.mode == SUSNET_OBS_NONE) ? OUT_NONE
                     : (traj && fit >= 1)                    ? OUT_TRAJ_RAW8

@@ -376,6 +376,13 @@ __host__ __device__ constexpr bool kFeed(int out) { return out == OUT_TRAJ_RAW8;
 // OUT_TRAJ = OUT_TRAJ_RAW8 without an observation; OUT_RECORD = the OUT_TRAJ_RAW8 fields packed into ONE record per
 // env-step (rewards f32[A] | actions u8[A] | done | truncated | raw obs u8[F], padded to a dword): a lane stores its
 // record with one or two wide stores through a single buffer descriptor instead of six stores through five
+// The record array of a launch is addressed TICK BY TICK: the buffer descriptor's base moves to the tick's slab (a 64-bit scalar add), its
+// size is one slab, and every per-lane offset is an offset inside the slab -- so a launch is not limited to the 2 GiB a 32-bit offset from
+// ONE base could span (tag5 at 65 536 envs used to need two launches for 512 ticks), and the 128-bit stores need no tick offset added
+// on the vector unit (BufDst::st128).
+__device__ __forceinline__ BufDst record_slab(uint8_t *record, uint32_t slab_bytes, int tick, uint32_t lane_off) {
+    return make_buf_dst(record + (uint64_t)(uint32_t)tick * (uint64_t)slab_bytes, (uint64_t)slab_bytes, lane_off);
+}
 template <class S>
 struct RecordLayout {
     static constexpr int kBytesTail = (S::kA > 0 ? S::kA : 0) + 2 + (S::kRawF > 0 ? S::kRawF : 0);
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
-        if (kRec) drec.so = (uint32_t)tick * slab_rec;
+        if (kRec) drec = record_slab(a.record, slab_rec, tick, (uint32_t)(bb * a.record_bytes));
         if (active) {
             sample_actions_env<S, PAR>(c, st, e, rng, as, tick_base + (uint64_t)tick);
             // shuffled order: the tick's shuffle draws follow its action draws in the stream
@@ -826,7 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
-        if (kRec) drec.so = (uint32_t)tick * slab_rec;
+        if (kRec) drec = record_slab(a.record, slab_rec, tick, 0u);
         if (active) {
             uint32_t act[NW], R[NW];
             if constexpr (RNG::kNumpy) { // numpy parity: base.py:326-330, then np.random.shuffle (base.py:372-374) from the env's own words
@@ -1143,7 +1150,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * slab_a; dr.so = t32 * (4u * slab_a); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
-        if (kRec) drec.so = (uint32_t)tick * slab_rec;
+        if (kRec) drec = record_slab(a.record, slab_rec, tick, 0u);
         uint32_t act, R;
         if constexpr (RNG::kNumpy) { // numpy parity: base.py:326-330, then np.random.shuffle (base.py:372-374), from the env's own words
             uint32_t a2[2] = {0u, 0u}, R2[2];
@@ -1325,7 +1332,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
             const uint32_t t32 = (uint32_t)tick;
             da.so = t32 * (2u * slab_d); dr.so = t32 * (8u * slab_d); dd.so = t32 * slab_d; dt.so = t32 * slab_d; dobs.so = t32 * slab_o;
         }
-        if (kRec || kRec16) drec.so = (uint32_t)tick * (kRecBytes * slab_d);
+        if (kRec || kRec16) drec = record_slab(a.record, kRecBytes * slab_d, tick, (uint32_t)bl * kRecBytes);
         uint32_t a0, a1;
         if constexpr (RNG::kNumpy) { // base.py:326-330 with numpy's own words
             a0 = rng.bounded(6u);
