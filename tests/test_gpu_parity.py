@@ -522,7 +522,7 @@ def test_two_rank_bench_line_equals_one_process_over_the_same_env_ids(pkg):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     Bshard, K, W, T = 4096, 3, 1, 64
-    flags = ["--steps", str(K), "--warmup", str(W), "--ticks", str(T), "--config", "cfg3", "--no-cpu-baseline", "--no-secondary", "--repeats", "0"]
+    flags = ["--steps", str(K), "--warmup", str(W), "--ticks", str(T), "--config", "cfg3", "--no-cpu-baseline", "--no-secondary", "--repeats", "0", "--settle-ms", "0"]
     env = dict(os.environ, SUSNET_BENCH_BACKEND="gloo", SUSNET_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(bench.launch_command(2, port, ["--gpus", "2", "--batch", str(Bshard)] + flags), env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]

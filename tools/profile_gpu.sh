@@ -8,8 +8,8 @@ CONFIGS="${*:-cfg2 cfg3 cfg4 tag5}"
 for CFG in $CONFIGS; do
   OUT=gpurun_out/prof_${PROF_TAG:-cur}/$CFG
   rm -rf "$OUT" && mkdir -p "$OUT"
-  BENCH="python3 bench.py --config $CFG --no-cpu-baseline --no-secondary --steps 20 --warmup 5 --repeats 0"
-  if [ "$CFG" = cfg2 ]; then FULL="python3 bench.py --config cfg2 --no-cpu-baseline --steps 20 --warmup 5 --repeats 0"; else FULL="$BENCH"; fi
+  BENCH="python3 bench.py --config $CFG --no-cpu-baseline --no-secondary --steps 20 --warmup 5 --repeats 0 --settle-ms 150"
+  if [ "$CFG" = cfg2 ]; then FULL="python3 bench.py --config cfg2 --no-cpu-baseline --steps 20 --warmup 5 --repeats 0 --settle-ms 150"; else FULL="$BENCH"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $FULL > $OUT/stats.log 2>&1 || exit 1
   for C in WRITE_SIZE FETCH_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- $BENCH > $OUT/pmc_$C.log 2>&1 || exit 1
