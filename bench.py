@@ -562,11 +562,28 @@ def main():
                 dtc = time.perf_counter() - t0
                 entry["collect_into_replay_ring"] = {"value": n_added / dtc, "unit": "transitions/s", "ticks": 256, "ticks_per_append": 64, "epsilon": 0.1,
                                                      "us_per_tick": dtc * 1e6 / 256,
-                                                     "note": "DeviceReplayBuffer.collect: susnet_qnet_policy_step (network, epsilon-greedy argmax, random crew, step, "
-                                                             "replay feed: one kernel per tick) + susnet_ring_append per 64 ticks; the reference's six ring tensors, "
+                                                     "note": "DeviceReplayBuffer.collect: susnet_qnet_policy_rollout (network, epsilon-greedy argmax, random crew, step, "
+                                                             "replay feed: one launch per 64-tick block) + susnet_ring_append per block; the reference's six ring tensors, "
                                                              "trajectory_size 1"}
+                # the same tick looped inside ONE launch per 64-tick block (susnet_qnet_policy_rollout: the network image is loaded and
+                # the launch paid once per block; what collect() above uses)
+                if envc.supports_qnet_policy_step(polc.fused_imposter):
+                    feed = envc.alloc_feed(64)
+                    for _ in range(2):
+                        envc.policy_rollout_into(feed, 64, polc.fused_imposter, epsilon=0.1, mask_dead=True)
+                    b0e, b1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    b0e.record(torch.cuda.current_stream(device))
+                    for _ in range(4):
+                        envc.policy_rollout_into(feed, 64, polc.fused_imposter, epsilon=0.1, mask_dead=True)
+                    b1e.record(torch.cuda.current_stream(device))
+                    torch.cuda.synchronize(device)
+                    us_tick = b0e.elapsed_time(b1e) * 1e3 / (4 * 64)
+                    entry["block_in_one_launch"] = {"value": sp["batch"] / (us_tick * 1e-6), "unit": "env-steps/s", "us_per_tick": us_tick, "ticks_per_launch": 64,
+                                                    "launches_timed": 4, "epsilon": 0.1,
+                                                    "note": "susnet_qnet_policy_rollout: k_qnet_step looping over 64 ticks per launch, replay feed written"}
+                    del feed
                 del envc, polc, ring
-                entry["value"] = max(entry["eager"]["value"], entry["hip_graph_replay"]["value"])
+                entry["value"] = max(entry["eager"]["value"], entry["hip_graph_replay"]["value"])  # (one launch per tick: the step-API shape of the loop)
                 entry["kernel"] = "k_qnet_step (susnet_qnet_policy_step: float32 Q-network on the f32-input MFMA, argmax, crew draws and the env step: the whole tick in one launch)"
                 entry["torch_modules_hip_graph_replay"]["note"] = ("the same tick with the network as torch modules (hipBLASLt f32 GEMMs + PReLU kernels on "
                                                                    "the [B][88] observation): round 2's path, kept as the comparison")
@@ -587,7 +604,8 @@ def main():
             del ro
     if "other_configs" in line:  # the same numbers in a compact top-level key (the long entries above get truncated in driver records)
         line["others"] = {e["config"]: {"value": e["value"], "frac": (e.get("frac") if "frac" in e else e.get("roofline", {}).get("frac")),
-                                        **({"collect_transitions_per_s": e["collect_into_replay_ring"]["value"]} if "collect_into_replay_ring" in e else {})}
+                                        **({"collect_transitions_per_s": e["collect_into_replay_ring"]["value"]} if "collect_into_replay_ring" in e else {}),
+                                        **({"block_us_per_tick": e["block_in_one_launch"]["us_per_tick"]} if "block_in_one_launch" in e else {})}
                           for e in line["other_configs"]}
     if world > 1:
         dist.barrier()  # the timed region and its collectives are over on every rank before rank 0 spends host time below

@@ -167,14 +167,16 @@ typedef struct susnet_layout {
     uint32_t test_overrides;  /* SUSNET_OVERRIDE_* bits: which test hooks were found in the environment at susnet_create */
 } susnet_layout;
 
-/* Test hooks.  Three environment variables change how a handle launches its kernels (never what it computes); they are read
+/* Test hooks.  Four environment variables change how a handle launches its kernels (never what it computes); they are read
  * ONCE, in susnet_create, recorded in susnet_layout.test_overrides, and named in susnet_last_error() messages of that handle:
  *   SUSNET_FORCE_GENERIC=1      every configuration runs the generic (LDS-table) kernels, none of the compiled-in ones
  *   SUSNET_EPW=16|32|64         environments per wave of the fused rollout
- *   SUSNET_TRAJ_MAX_BYTES=n     default of susnet_set_launch_limit() */
+ *   SUSNET_TRAJ_MAX_BYTES=n     default of susnet_set_launch_limit()
+ *   SUSNET_RING_TILE=0|8|16|32  susnet_ring_append: environments of a wave's (ticks x envs) tile; 0 = 64 consecutive rows per wave */
 #define SUSNET_OVERRIDE_FORCE_GENERIC 1u
 #define SUSNET_OVERRIDE_EPW 2u
 #define SUSNET_OVERRIDE_TRAJ_MAX_BYTES 4u
+#define SUSNET_OVERRIDE_RING_TILE 8u
 
 typedef struct susnet_obs_spec {
     int32_t mode;                 /* SUSNET_OBS_* */
@@ -395,6 +397,26 @@ int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_
  * uses the two calls. */
 int susnet_qnet_policy_step(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
                             const float *packed, float *q_out, const susnet_policy_opts *opts /* or NULL */, const susnet_step_io *io, void *stream);
+
+/* The policy tick (susnet_qnet_policy_step) repeated n_ticks times inside ONE launch: the acting loop of the trainer over a block of
+ * ticks with fixed weights (train.py:345-399 between two optimizer steps) -- the network image is loaded once, a launch is paid once,
+ * and what replay_buffer.add needs of every tick lands in slot t of [T][B] arrays, ready for susnet_ring_append.  Every pointer is
+ * optional.  Served where susnet_qnet_policy_step is (the two compiled-in games, PHILOX handles, a random crew); the handle must
+ * auto-reset.  Advances the handle by n_ticks steps. */
+typedef struct susnet_feed_io {
+    uint8_t *actions;    /* out [T][B][A] u8: the actions taken */
+    float *rewards;      /* out [T][B][A] f32 */
+    uint8_t *done;       /* out [T][B] */
+    uint8_t *truncated;  /* out [T][B] */
+    uint8_t *obs;        /* out [T][B][obs_raw_size] u8: the state after each tick (after the auto-reset where the episode ended); 16-byte aligned
+                          * slots (B * obs_raw_size a multiple of 16) */
+    uint8_t *term_obs;   /* out [T][B][obs_raw_size] u8, written only where an episode ended: its terminal state */
+    uint16_t *roles;     /* out [T][B]: imposter bitmask of the episode that acted */
+    float *q;            /* out [T][B][n_actions_imposter] f32: the imposters' Q rows, or NULL */
+} susnet_feed_io;
+int susnet_qnet_policy_rollout(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                               const float *packed, const susnet_policy_opts *opts, const susnet_feed_io *feed, int32_t n_ticks, void *stream);
+
 int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void *stream);
 int susnet_observe(susnet_env *env, const susnet_obs_spec *obs, void *stream);
 int susnet_obs_size(const susnet_env *env, const susnet_obs_spec *obs, int32_t *size_out, int32_t *size2_out);

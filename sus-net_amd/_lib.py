@@ -31,7 +31,7 @@ LIFETIME_NAMES = ["episodes", "crew_won", "imposter_won", "truncated", "imp_kill
 # every symbol include/susnet.h declares
 EXPORTS = [
     "susnet_abi_version", "susnet_last_error", "susnet_create", "susnet_destroy", "susnet_get_layout",
-    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_policy_actions", "susnet_qnet_packed_floats", "susnet_qnet_pack", "susnet_qnet_forward", "susnet_step", "susnet_policy_step", "susnet_qnet_policy_step",
+    "susnet_bind_state", "susnet_bind_tape", "susnet_seed", "susnet_tick", "susnet_reset", "susnet_sample_actions", "susnet_policy_actions", "susnet_qnet_packed_floats", "susnet_qnet_pack", "susnet_qnet_forward", "susnet_step", "susnet_policy_step", "susnet_qnet_policy_step", "susnet_qnet_policy_rollout",
     "susnet_rollout", "susnet_record_layout", "susnet_record_layout_of", "susnet_set_launch_limit", "susnet_observe", "susnet_obs_size", "susnet_featurize", "susnet_export_state", "susnet_import_state",
     "susnet_reduce_lifetime", "susnet_device_tick", "susnet_poll_errors", "susnet_ring_append", "susnet_scent",
 ]
@@ -90,6 +90,11 @@ class RingIO(C.Structure):
         ("ring_actions", C.c_void_p), ("ring_rewards", C.c_void_p), ("ring_dones", C.c_void_p), ("ring_imposters", C.c_void_p),
         ("record", C.c_void_p), ("record_format", C.c_int32),
     ]
+
+
+class FeedIO(C.Structure):
+    _fields_ = [("actions", C.c_void_p), ("rewards", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p), ("obs", C.c_void_p),
+                ("term_obs", C.c_void_p), ("roles", C.c_void_p), ("q", C.c_void_p)]
 
 
 class PolicyOpts(C.Structure):
@@ -169,6 +174,9 @@ def lib():
     L.susnet_policy_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(PolicyOpts), P(StepIO), C.c_void_p]
     L.susnet_qnet_policy_step.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, P(PolicyOpts), P(StepIO),
                                           C.c_void_p]
+    L.susnet_qnet_policy_rollout.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, C.c_void_p, P(PolicyOpts), P(FeedIO), C.c_int32,
+                                             C.c_void_p]
+    L.susnet_record_layout_of.argtypes = [C.c_void_p, C.c_int32, P(RecordLayout)]
     L.susnet_policy_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(PolicyOpts), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.susnet_qnet_packed_floats.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32]
     L.susnet_qnet_pack.argtypes = [C.c_void_p, P(C.c_int32), C.c_int32, P(C.c_int32), C.c_int32, P(C.c_void_p), P(C.c_void_p), C.c_void_p, C.c_void_p]

@@ -457,6 +457,7 @@ struct susnet_env {
     uint64_t ticks = 0; // steps taken (index of the production action stream)
     // test hooks, read ONCE at susnet_create (include/susnet.h SUSNET_OVERRIDE_*)
     bool force_generic = false;
+    int ring_tile = 8; // susnet_ring_append: environments of a wave's (ticks x envs) tile (8 / 16 / 32; 0: consecutive rows per wave)
     uint64_t launch_limit = (1ull << 31) - 1u, launch_limit_default = (1ull << 31) - 1u;
     int spec = 0; // pick_spec(): which compiled-in kernel family serves the handle (0 = generic)
     susnet_layout layout;
@@ -477,6 +478,7 @@ static int fail(const susnet_env *env, int code, const std::string &msg) {
         if (env->layout.test_overrides & SUSNET_OVERRIDE_FORCE_GENERIC) m += " SUSNET_FORCE_GENERIC";
         if (env->layout.test_overrides & SUSNET_OVERRIDE_EPW) m += " SUSNET_EPW";
         if (env->layout.test_overrides & SUSNET_OVERRIDE_TRAJ_MAX_BYTES) m += " SUSNET_TRAJ_MAX_BYTES";
+        if (env->layout.test_overrides & SUSNET_OVERRIDE_RING_TILE) m += " SUSNET_RING_TILE";
         m += "]";
     }
     return fail(code, m);
@@ -544,6 +546,10 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     }
     if (const char *ev = getenv("SUSNET_FORCE_GENERIC"))
         if (ev[0] == '1') { e->force_generic = true; overrides |= SUSNET_OVERRIDE_FORCE_GENERIC; }
+    if (const char *ev = getenv("SUSNET_RING_TILE")) {
+        const int v = atoi(ev);
+        if (v == 0 || v == 8 || v == 16 || v == 32) { e->ring_tile = v; overrides |= SUSNET_OVERRIDE_RING_TILE; }
+    }
     if (const char *ev = getenv("SUSNET_TRAJ_MAX_BYTES")) {
         const long long v = atoll(ev);
         if (v > 0 && (uint64_t)v < e->launch_limit) { e->launch_limit = e->launch_limit_default = (uint64_t)v; overrides |= SUSNET_OVERRIDE_TRAJ_MAX_BYTES; }
@@ -994,7 +1000,7 @@ struct QnetFuse {
     int n_out;
 };
 template <class ROW, class S>
-static int qnet_step_launch(susnet_env *env, const QnetFuse &f, const StepArgs &a, const ObsArgs &o, size_t step_lds, hipStream_t st) {
+static int qnet_step_launch(susnet_env *env, const QnetFuse &f, const StepArgs &a, const ObsArgs &o, size_t step_lds, hipStream_t st, int n_ticks, const TickStrides &ts) {
     using Q = QNet<ROW>;
     // [table image of the step, shared by the four waves][network image][one region per wave: the rest of a k_step workgroup's LDS]
     const size_t rest = step_lds - (size_t)kTableWords * 4;
@@ -1002,13 +1008,15 @@ static int qnet_step_launch(susnet_env *env, const QnetFuse &f, const StepArgs &
     if (sh > 160 * 1024) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: observation too large for the LDS left beside the network image");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet_step<ROW, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); // (per device: see qnet_launch)
     const unsigned blocks = (unsigned)((env->c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
-    hipLaunchKernelGGL((k_qnet_step<ROW, S>), dim3(blocks), dim3(Q::kThreads), sh, st, env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest);
+    QStepArgs ka{env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest, n_ticks, ts};
+    hipLaunchKernelGGL((k_qnet_step<ROW, S>), dim3(blocks), dim3(Q::kThreads), sh, st, ka);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }
 
+// n_ticks > 1 (fuse only: susnet_qnet_policy_rollout): the one-kernel tick repeated inside ONE launch, outputs tick-strided (ts)
 static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_imp, const float *q_crew, void *stream, const QnetFuse *fuse = nullptr,
-                     const susnet_policy_opts *opts = nullptr) {
+                     const susnet_policy_opts *opts = nullptr, int n_ticks = 1, const TickStrides *ts = nullptr) {
     if (int rc = check_bound(env)) return rc;
     if (!io || (!io->actions && !q_imp && !fuse)) return fail(SUSNET_E_INVALID, "null actions");
     StepArgs a;
@@ -1073,11 +1081,12 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
         }
         sh = (sh + 15) & ~(size_t)15;
         int rc;
-        if (spec == 3 && fuse->feat == FEAT_ONEHOT_ALIVE_CLOSEST) rc = qnet_step_launch<QRow3, SpecCfg3>(env, *fuse, a, o, sh, st);
-        else if (spec == 2 && fuse->feat == FEAT_ONEHOT) rc = qnet_step_launch<QRow1, SpecCfg2>(env, *fuse, a, o, sh, st);
+        const TickStrides none = {};
+        if (spec == 3 && fuse->feat == FEAT_ONEHOT_ALIVE_CLOSEST) rc = qnet_step_launch<QRow3, SpecCfg3>(env, *fuse, a, o, sh, st, n_ticks, ts ? *ts : none);
+        else if (spec == 2 && fuse->feat == FEAT_ONEHOT) rc = qnet_step_launch<QRow1, SpecCfg2>(env, *fuse, a, o, sh, st, n_ticks, ts ? *ts : none);
         else return fail(env, SUSNET_E_INVALID, "susnet_qnet_policy_step: served are the two compiled-in games (1v1 9x9 ITG, 1v2 14x14 with 4 jobs)");
         if (rc) return rc;
-        env->ticks += 1;
+        env->ticks += (uint64_t)n_ticks;
         return SUSNET_OK;
     }
     if (is_family(spec)) kFamily[spec - kFamilySpecBase].step(tape, g, blk, sh, st, env->c, env->s, a, o);
@@ -1116,6 +1125,40 @@ extern "C" int susnet_qnet_policy_step(susnet_env *env, const int32_t *component
         return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: the network's output width must be the imposters' action count");
     const QnetFuse f = {qnet_feat(env, components, n_components), packed, q_out, dims[5]};
     return step_impl(env, io, nullptr, nullptr, stream, &f, opts);
+}
+
+extern "C" int susnet_qnet_policy_rollout(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
+                                          const float *packed, const susnet_policy_opts *opts, const susnet_feed_io *feed, int32_t n_ticks, void *stream) {
+    if (int rc = check_bound(env)) return rc;
+    if (!feed || n_ticks < 1) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_rollout: feed is null / n_ticks < 1");
+    const int64_t n = susnet_qnet_packed_floats(env, components, n_components, dims, n_dims);
+    if (n < 0) return (int)n;
+    if (!packed || (reinterpret_cast<uintptr_t>(packed) & 15u)) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_rollout: packed (16-byte aligned)");
+    if (dims[5] != env->layout.n_actions_imposter)
+        return fail(SUSNET_E_INVALID, "susnet_qnet_policy_rollout: the network's output width must be the imposters' action count");
+    if (!env->c.auto_reset) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_rollout: the handle must auto-reset (episodes end inside the launch)");
+    const int64_t B = env->c.B, A = env->c.A, S = env->layout.obs_raw_size;
+    susnet_obs_spec obs;
+    std::memset(&obs, 0, sizeof(obs));
+    obs.mode = SUSNET_OBS_RAW;
+    obs.dtype = SUSNET_U8;
+    obs.out = feed->obs;
+    susnet_step_io io;
+    std::memset(&io, 0, sizeof(io));
+    io.actions = feed->actions;
+    io.actions_dtype = SUSNET_U8;
+    io.actions_layout = SUSNET_LAYOUT_BA;
+    io.rewards = feed->rewards;
+    io.rewards_dtype = SUSNET_F32;
+    io.rewards_layout = SUSNET_LAYOUT_BA;
+    io.done = feed->done;
+    io.truncated = feed->truncated;
+    io.obs = feed->obs ? &obs : nullptr;
+    io.term_obs = feed->term_obs;
+    io.roles = feed->roles;
+    const TickStrides ts = {B * A, B * A * 4, B, B, B * S, B * 2, B * (int64_t)dims[5] * 4};
+    const QnetFuse f = {qnet_feat(env, components, n_components), packed, feed->q, dims[5]};
+    return step_impl(env, &io, nullptr, nullptr, stream, &f, opts, n_ticks, &ts);
 }
 
 extern "C" int susnet_record_layout_of(const susnet_env *env, int32_t record_format, susnet_record_layout_t *out) {
@@ -1338,6 +1381,7 @@ struct RingArgs {
     int64_t B, n0, n1; // envs; first / one-past-last transition (n = tick * B + env) this launch writes
     int32_t A, S, n_imp;
     int32_t rows_per_wave; // 64, or fewer when 64 rows of 2 x trajectory_size x S bytes would not fit the LDS images
+    int32_t tile_log2e;    // k_ring_append_tile: log2 of the tile's environments (3: 8 ticks x 8 envs)
     // the trajectory as PACKED RECORDS (io.record; whole records only: the 1v1 kernels), wave-uniform: record size (0 = separate
     // tensors) and field offsets; rec_packed: actions and flags share one byte (SUSNET_RECORD_COMPACT)
     int32_t rec_bytes, rec_obs, rec_act, rec_rew, rec_done, rec_trunc, rec_packed;
@@ -1546,6 +1590,241 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
         }
     }
 }
+// The same rows from a TILE per wave: TT consecutive ticks x TE consecutive environments (TT * TE = 64; lane = dt * TE + db).  A row needs
+// the Tw + 1 states around its tick (replay_memory.py:108-113, 122-127) and in the kernel above every lane fetches all of them itself:
+// each state of the trajectory is read by Tw + 1 waves.  Here the wave fetches the (TT + Tw) x TE states its tile touches ONCE into an
+// LDS image (one state per lane + Tw * TE states ahead of the tile + the terminal states where an episode ended) and every lane then
+// assembles its row from that image: (TT + Tw) / TT reads per state instead of Tw + 1.  The rows of one tick are TE consecutive ring
+// positions, so the wave writes TT contiguous runs per tensor; run bases live in a small LDS table and the store loop walks all runs as
+// one flattened index space (run = index / groups-per-run by a multiply), 16 bytes per lane and step as above.
+struct RingRun {
+    int64_t pos;      // ring position of the run's first row
+    int32_t first, n; // first lane-row of the run in the images (dt * TE + lo); rows (0: nothing to write; < 0: -n rows, the ring wraps inside)
+};
+__device__ __forceinline__ void ring_copy_state(uint8_t *d0, uint8_t *d1, const uint8_t *src, int S) {
+    int c = 0;
+    for (; c + 16 <= S; c += 16) {
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) __builtin_memcpy(&v[q], src + c + 4 * q, 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (d0) __builtin_memcpy(d0 + c + 4 * q, &v[q], 4);
+            if (d1) __builtin_memcpy(d1 + c + 4 * q, &v[q], 4);
+        }
+    }
+    for (; c + 4 <= S; c += 4) {
+        uint32_t v;
+        __builtin_memcpy(&v, src + c, 4);
+        if (d0) __builtin_memcpy(d0 + c, &v, 4);
+        if (d1) __builtin_memcpy(d1 + c, &v, 4);
+    }
+    for (; c < S; c++) {
+        const uint8_t v = src[c];
+        if (d0) d0[c] = v;
+        if (d1) d1[c] = v;
+    }
+}
+__global__ __launch_bounds__(64) void k_ring_append_tile(RingArgs r) {
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A, NI = r.n_imp;
+    const int le = r.tile_log2e, TE = 1 << le, TT = 64 >> le;
+    const int64_t tiles_b = (r.B + TE - 1) >> le;
+    const int64_t tile_t = (int64_t)blockIdx.x / tiles_b, tile_b = (int64_t)blockIdx.x - tile_t * tiles_b;
+    const int64_t t_first = r.n0 / r.B; // first tick with a row to write
+    const int64_t t0 = t_first + tile_t * TT, b0 = tile_b << le;
+    const int dt = lane >> le, db = lane & (TE - 1);
+    const int64_t t = t0 + dt, b = b0 + db;
+    const bool live = t < r.io.n_ticks && b < r.B; // the lane's (tick, env) exists (its row is written only if t * B + b >= n0)
+    const int TS = Tw * S;
+    // LDS: [source states (TT + Tw) x TE][their episode-end flags][states image 64 x TS][next_states image][rewards][actions][done][imposters][runs]
+    const int n_src = (TT + Tw) * TE;
+    uint8_t *src_img = reinterpret_cast<uint8_t *>(smem);
+    uint8_t *flg_img = src_img + ((n_src * S + 15) & ~15);
+    uint8_t *st_img = flg_img + ((n_src + 15) & ~15);
+    const int img = (64 * TS + 15) & ~15;
+    uint8_t *nx_img = st_img + img;
+    float *rew_img = reinterpret_cast<float *>(nx_img + img);
+    uint8_t *act_img = reinterpret_cast<uint8_t *>(rew_img + 64 * A);
+    uint8_t *done_img = act_img + ((64 * A + 15) & ~15);
+    int16_t *imp_img = reinterpret_cast<int16_t *>(done_img + 64);
+    RingRun *runs = reinterpret_cast<RingRun *>(reinterpret_cast<uint8_t *>(imp_img) + ((64 * NI * 2 + 15) & ~15));
+    uint8_t *my_st = st_img + (size_t)lane * TS, *my_nx = nx_img + (size_t)lane * TS;
+
+    // ---- phase A: every global load of the tile, then the LDS stores
+    uint32_t dn = 0, tr = 0;
+    if (live) { dn = ring_done(r, t, b); tr = ring_trunc(r, t, b); }
+    const bool ended = (dn | tr) != 0u;
+    // the Tw ticks ahead of the tile: lane = du * TE + db' for du < Tw (Tw * TE <= 64: checked on the host)
+    const int du = lane >> le;
+    const int64_t u_pre = t0 - Tw + du;
+    const bool pre = du < Tw && b < r.B;
+    uint32_t pre_flag = 0;
+    if (pre && u_pre >= 0) pre_flag = ring_done(r, u_pre, b) | ring_trunc(r, u_pre, b);
+    const uint8_t *sp[3] = {live ? ring_state(r, t, b) : nullptr, pre ? ring_state(r, u_pre, b) : nullptr,
+                            live && ended ? r.io.term_obs + ((size_t)t * r.B + b) * S : nullptr};
+    uint8_t *own_slot = src_img + (size_t)((dt + Tw) * TE + db) * S, *pre_slot = src_img + (size_t)(du * TE + db) * S, *last = my_nx + (size_t)(Tw - 1) * S;
+    for (int c0 = 0; c0 < S; c0 += 4 * kRingChunk) {
+        uint32_t v[3][kRingChunk];
+        uint8_t tail[3][3];
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            if (sp[g] == nullptr) continue;
+            const uint8_t *src = sp[g] + c0;
+#pragma unroll
+            for (int q = 0; q < kRingChunk; q++)
+                if (c0 + 4 * q + 4 <= S) __builtin_memcpy(&v[g][q], src + 4 * q, 4);
+            if (S - c0 < 4 * kRingChunk) {
+                const int f0 = (S - c0) & ~3;
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    if (f0 + q < S - c0) tail[g][q] = src[f0 + q];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            if (sp[g] == nullptr) continue;
+            // own state -> its source slot, and the row's last next-state unless the episode ended (then the terminal state is)
+            uint8_t *d0 = g == 0 ? own_slot + c0 : g == 1 ? pre_slot + c0 : last + c0;
+            uint8_t *d1 = g == 0 && !ended ? last + c0 : nullptr;
+#pragma unroll
+            for (int q = 0; q < kRingChunk; q++)
+                if (c0 + 4 * q + 4 <= S) {
+                    __builtin_memcpy(d0 + 4 * q, &v[g][q], 4);
+                    if (d1) __builtin_memcpy(d1 + 4 * q, &v[g][q], 4);
+                }
+            if (S - c0 < 4 * kRingChunk) {
+                const int f0 = (S - c0) & ~3;
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    if (f0 + q < S - c0) {
+                        d0[f0 + q] = tail[g][q];
+                        if (d1) d1[f0 + q] = tail[g][q];
+                    }
+            }
+        }
+    }
+    if (live) {
+        const uint32_t role_bits = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << NI) - 1u);
+        for (int i0 = 0; i0 < A; i0 += 8) {
+            uint8_t av[8];
+            float rv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (i0 + q < A) {
+                    av[q] = (uint8_t)ring_action(r, t, b, i0 + q);
+                    rv[q] = ring_reward(r, t, b, i0 + q);
+                }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (i0 + q < A) {
+                    act_img[lane * A + i0 + q] = av[q];
+                    rew_img[lane * A + i0 + q] = rv[q];
+                }
+        }
+        done_img[lane] = dn ? 1 : 0; // replay_memory.py:131: done, not truncation
+        uint32_t m = role_bits;
+        for (int k = 0; k < NI; k++) { // ascending agent indices
+            const int i = __ffs((int)m) - 1;
+            imp_img[lane * NI + k] = (int16_t)(i < 0 ? 0 : i);
+            m &= m - 1u;
+        }
+    }
+    flg_img[(dt + Tw) * TE + db] = ended ? 1 : 0;
+    if (du < Tw) flg_img[du * TE + db] = pre_flag ? 1 : 0;
+    if (lane < TT) { // the runs: tick t0 + lane, rows [lo, hi) of the tile's TE environments
+        const int64_t tt = t0 + lane;
+        RingRun run = {0, 0, 0};
+        if (tt < r.io.n_ticks) {
+            const int64_t nb = tt * r.B + b0; // transition index of the run's first environment
+            const int lo = nb >= r.n0 ? 0 : (r.n0 - nb >= TE ? TE : (int)(r.n0 - nb));
+            const int hi = r.B - b0 >= TE ? TE : (int)(r.B - b0);
+            if (hi > lo) {
+                run.pos = (r.io.idx + nb + lo) % r.io.max_size;
+                run.first = lane * TE + lo;
+                run.n = run.pos + (hi - lo) <= r.io.max_size ? hi - lo : -(hi - lo);
+            }
+        }
+        runs[lane] = run;
+    }
+    wave_lds_fence();
+
+    // ---- phase B: the row's window from the source image (states[k] and, shifted by one, next_states[k - 1])
+    if (live) {
+        int64_t e = -(1ll << 62); // most recent episode boundary before tick t within the window's reach
+        for (int k = Tw; k >= 1; k--)
+            if (flg_img[(dt + Tw - k) * TE + db] != 0 && t - k >= 0) e = t - k;
+        for (int k = 0; k < Tw; k++) {
+            int64_t u = t - Tw + k;
+            if (u < e) u = e;
+            const uint8_t *src = src_img + (size_t)((int)(u - t0 + Tw) * TE + db) * S;
+            ring_copy_state(my_st + (size_t)k * S, k > 0 ? my_nx + (size_t)(k - 1) * S : nullptr, src, S);
+        }
+    }
+    wave_lds_fence();
+
+    // ---- phase C: TT contiguous runs per tensor
+    const uint32_t run_elems = (uint32_t)(TE * TS); // floats of a full run
+    bool fast = true;                              // every run: no wrap inside, 16-byte aligned start, whole groups of four floats
+#pragma unroll 1
+    for (int q = 0; q < TT; q++) {
+        const RingRun run = runs[q];
+        if (run.n < 0 || ((((size_t)run.pos * TS) | (size_t)((run.first & (TE - 1)) * TS) | (size_t)(run.n > 0 ? run.n * TS : 0)) & 3u) != 0) fast = false;
+    }
+    if (__builtin_expect(fast, 1)) {
+        const uint32_t gpr = run_elems >> 2; // float4 groups of a full run (a shorter run: the groups past its end are skipped)
+        const uint32_t magic = 0xffffffffu / gpr + 1u;
+        const uint32_t total = gpr * (uint32_t)TT;
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(st_img), *n4 = reinterpret_cast<const uint32_t *>(nx_img);
+        for (uint32_t g = lane; g < total; g += 64) {
+            const uint32_t q = __umulhi(g, magic), w = g - q * gpr;
+            const RingRun run = runs[q];
+            if ((int)(4 * w) >= run.n * TS) continue;
+            const uint32_t at = (uint32_t)run.first * (uint32_t)TS + 4 * w; // byte offset into the images (a multiple of 4: checked above)
+            const uint32_t a = s4[at >> 2], c = n4[at >> 2];
+            const float4 fa = make_float4((float)(a & 0xffu), (float)((a >> 8) & 0xffu), (float)((a >> 16) & 0xffu), (float)(a >> 24));
+            const float4 fc = make_float4((float)(c & 0xffu), (float)((c >> 8) & 0xffu), (float)((c >> 16) & 0xffu), (float)(c >> 24));
+            const size_t o = (size_t)run.pos * TS + 4 * w;
+            *reinterpret_cast<float4 *>(r.io.states + o) = fa;
+            *reinterpret_cast<float4 *>(r.io.next_states + o) = fc;
+        }
+    } else { // a run that wraps round the ring's end or starts off a 16-byte boundary: element by element
+        for (int q = 0; q < TT; q++) {
+            const RingRun run = runs[q];
+            const int n = run.n < 0 ? -run.n : run.n;
+            for (int g = lane; g < n * TS; g += 64) {
+                const int row = g / TS, k = g - row * TS;
+                int64_t p = run.pos + row;
+                if (p >= r.io.max_size) p -= r.io.max_size;
+                r.io.states[(size_t)p * TS + k] = (float)st_img[(size_t)run.first * TS + g];
+                r.io.next_states[(size_t)p * TS + k] = (float)nx_img[(size_t)run.first * TS + g];
+            }
+        }
+    }
+    // the small tensors: lane-row l of the images is row l - run.first of run l / TE
+    {
+        const RingRun run = runs[dt];
+        const int n = run.n < 0 ? -run.n : run.n;
+        const int row = lane - run.first;
+        if (row >= 0 && row < n) {
+            int64_t p = run.pos + row;
+            if (p >= r.io.max_size) p -= r.io.max_size;
+            r.io.ring_dones[p] = done_img[lane];
+            for (int k = 0; k < NI; k++) r.io.ring_imposters[p * NI + k] = imp_img[lane * NI + k];
+        }
+        const uint32_t magic_a = 0xffffffffu / (uint32_t)A + 1u;
+        for (uint32_t g = lane; g < 64u * (uint32_t)A; g += 64) { // consecutive lanes: consecutive elements of a run
+            const uint32_t l = __umulhi(g, magic_a), i = g - l * (uint32_t)A;
+            const RingRun rl = runs[l >> le];
+            const int nl = rl.n < 0 ? -rl.n : rl.n, rw = (int)l - rl.first;
+            if (rw < 0 || rw >= nl) continue;
+            int64_t p = rl.pos + rw;
+            if (p >= r.io.max_size) p -= r.io.max_size;
+            r.io.ring_actions[p * A + i] = (int64_t)act_img[g];
+            r.io.ring_rewards[p * A + i] = rew_img[g];
+        }
+    }
+}
 // the carried window of every env after the launch: the window before the tick that follows the last one
 __global__ __launch_bounds__(64) void k_ring_window(RingArgs r) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -1635,13 +1914,29 @@ extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, voi
         return 2 * ((R * (size_t)io->trajectory_size * (size_t)r.S + 15) & ~(size_t)15) + R * r.A * 4 + ((R * r.A + 15) & ~(size_t)15) + 64 +
                R * r.n_imp * 2 + 16;
     };
-    r.rows_per_wave = 64;
-    while (r.rows_per_wave > 8 && images((size_t)r.rows_per_wave) > 64 * 1024) r.rows_per_wave /= 2;
-    const size_t sh = images((size_t)r.rows_per_wave);
-    if (sh > 64 * 1024) return fail(SUSNET_E_INVALID, "susnet_ring_append: trajectory_size x state size too large (8 rows of the window exceed 64 KiB)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t waves = (r.n1 - r.n0 + r.rows_per_wave - 1) / r.rows_per_wave;
-    hipLaunchKernelGGL(k_ring_append, dim3((unsigned)waves), dim3(64), sh, st, r);
+    // a (ticks x envs) tile per wave where the window is short enough for the tile's lanes to fetch the Tw ticks ahead of it and the
+    // images fit; else 64 (32 / 16 / 8) consecutive rows per wave
+    r.rows_per_wave = 64;
+    r.tile_log2e = 0;
+    const int te = env->ring_tile;
+    const size_t Tw = (size_t)io->trajectory_size;
+    const size_t tile_lds = te ? ((((size_t)(64 / te) + Tw) * te * r.S + 15) & ~(size_t)15) + ((((size_t)(64 / te) + Tw) * te + 15) & ~(size_t)15) +
+                                     2 * ((64 * Tw * r.S + 15) & ~(size_t)15) + 64 * (size_t)r.A * 4 + ((64 * (size_t)r.A + 15) & ~(size_t)15) + 64 +
+                                     ((64 * (size_t)r.n_imp * 2 + 15) & ~(size_t)15) + (64 / te) * sizeof(RingRun)
+                                : 0;
+    if (te && Tw * te <= 64 && tile_lds <= 32 * 1024 && r.A >= 2) {
+        r.tile_log2e = te == 8 ? 3 : te == 16 ? 4 : 5;
+        const int64_t t_first = r.n0 / r.B, tiles_t = (io->n_ticks - t_first + 64 / te - 1) / (64 / te), tiles_b = (r.B + te - 1) / te;
+        if (tiles_t * tiles_b > 0x7fffffffll) return fail(SUSNET_E_INVALID, "susnet_ring_append: too many tiles for one launch");
+        hipLaunchKernelGGL(k_ring_append_tile, dim3((unsigned)(tiles_t * tiles_b)), dim3(64), tile_lds, st, r);
+    } else {
+        while (r.rows_per_wave > 8 && images((size_t)r.rows_per_wave) > 64 * 1024) r.rows_per_wave /= 2;
+        const size_t sh = images((size_t)r.rows_per_wave);
+        if (sh > 64 * 1024) return fail(SUSNET_E_INVALID, "susnet_ring_append: trajectory_size x state size too large (8 rows of the window exceed 64 KiB)");
+        const int64_t waves = (r.n1 - r.n0 + r.rows_per_wave - 1) / r.rows_per_wave;
+        hipLaunchKernelGGL(k_ring_append, dim3((unsigned)waves), dim3(64), sh, st, r);
+    }
     hipLaunchKernelGGL(k_ring_window, dim3((unsigned)((r.B + 63) / 64)), dim3(64), 0, st, r);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;

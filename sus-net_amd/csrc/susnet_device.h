@@ -1320,7 +1320,8 @@ __device__ __forceinline__ uint32_t step_env(const Consts &c, const Tables &T, S
 // at episode end, one flush per launch.
 // wave-uniform copy of a 64-bit value every lane holds identically
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    // (the builtin returns int: widen through uint32_t, or a low word with bit 31 set smears into the high one)
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
 struct LifeAcc {

@@ -162,9 +162,10 @@ __device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG 
 // one-kernel policy tick (susnet_qnet.h k_qnet_step).  smem: the table image at LDS address 0 (every wave of the workgroup writes the
 // same words into it); rest: the wave's own LDS region (lds_bytes() of the host minus the table image).  pre_imp >= 0: the imposters'
 // greedy action, already chosen by the caller (the crew then draws from the action stream).
+// obs_tick: which [B][F] slot of the observation output this step writes (o.tick_stride elements apart: the multi-tick policy kernel)
 template <class RNG, class S>
 __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const StepArgs &a, const ObsArgs &o, uint32_t *smem, uint32_t *rest, int tid, int64_t b0,
-                                          int pre_imp) {
+                                          int pre_imp, int64_t obs_tick = 0) {
     const int64_t b = b0 + tid;
     const bool active = b < c.B;
     typename StoreFor<S>::type st;
@@ -346,12 +347,12 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
                 }
                 row.build(fx, fy, fal);
             }
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(o.out) + b0 * Row::F, 0, nrows * Row::F * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(o.out) + obs_tick * o.tick_stride + b0 * Row::F, 0, nrows * Row::F * 4, 0x00020000);
             flat_store_wave(row, T.stage, tid, nrows, r, 0u);
             return;
         }
     }
-    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, 0);
+    write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, obs_tick);
 }
 
 template <class RNG, class S>

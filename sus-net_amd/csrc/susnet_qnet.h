@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
                                               int64_t b0, int lane) {
     using Q = QNet<ROW>;
     constexpr int T = 2, R = Q::kGather;
-    const int m = lane & 31, h = lane >> 5;
+    const int h = lane >> 5;
     const float slope1 = pk[Q::oSlope + 0], slope2 = pk[Q::oSlope + 1], slope3 = pk[Q::oSlope + 2], slope4 = pk[Q::oSlope + 3];
     constexpr int kLast = Q::kBlocks - 1;
     const WeightStream ws = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pk + Q::oW2), 0, Q::kBlocks * 4096, 0x00020000), (uint32_t)lane * 16u, lane};
@@ -234,23 +234,39 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
     f32x16 a5[Q::NO / 32][T];
     dense<kB5, Q::H4 / 32, Q::NO / 32, T, kLast>(ws, w, w1 + Q::oB5, a4, a5); // dqn.py:328: no activation after the last Linear
 
+    // The Q rows go out through a raw buffer over this wave's rows: a row past the batch or an entry past n_out gets an offset the
+    // hardware's range check drops -- NO divergent branch anywhere in this function.  (Every vector register is spoken for here and the
+    // compiler parks values in accumulator registers around the matrix section; a parking move it places inside a divergent region runs
+    // under that region's narrowed EXEC and loses the value in the other lanes -- seen with the row index across `if (b < B)`.)
     uint32_t best[T];
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e)); // (the epilogue's lane-derived values are recomputed here, not carried across the matrix section)
+    const int me = lane_e & 31, he = lane_e >> 5;
+    const int64_t rows_left = c.B - b0;
+    const uint32_t n_rows = rows_left < 64 ? (uint32_t)rows_left : 64u;
+    if (q_out != nullptr) { // (wave-uniform)
+        // (base and size forced into scalar registers: a descriptor the compiler takes for lane-dependent is served by a loop over lanes)
+        float *qb = reinterpret_cast<float *>(uniform64(reinterpret_cast<uint64_t>(q_out + b0 * n_out)));
+        const int qbytes = __builtin_amdgcn_readfirstlane((int)(n_rows * (uint32_t)n_out * 4u));
+        const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(qb, 0, qbytes, 0x00020000);
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-        const int64_t b = b0 + 32 * t + m;
-        if (q_out != nullptr && b < c.B) {
+        for (int t = 0; t < T; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int n = 8 * (i >> 2) + 4 * h + (i & 3);
-                if (n < n_out) q_out[b * n_out + n] = a5[0][t][i];
+                const int n = 8 * (i >> 2) + 4 * he + (i & 3);
+                const uint32_t off = n < n_out ? ((uint32_t)(32 * t + me) * (uint32_t)n_out + (uint32_t)n) * 4u : 0x80000000u;
+                const float qv = a5[0][t][i]; // (a copy: __builtin_bit_cast applied to the vector element itself reads element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, qv), qr, off, 0, 0);
             }
-        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) {
         // argmax over the row: this lane's entries in ascending n (first maximum), then against the other half's (lane ^ 32)
         float hv = -__builtin_inff();
         uint32_t hn = 0xffffu;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int n = 8 * (i >> 2) + 4 * h + (i & 3);
+            const int n = 8 * (i >> 2) + 4 * he + (i & 3);
             const float v = a5[0][t][i];
             if (n < n_out && (hn == 0xffffu || v > hv)) { hv = v; hn = (uint32_t)n; }
         }
@@ -259,14 +275,14 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
         const bool theirs = pn != 0xffffu && (hn == 0xffffu || pv > hv || (pv == hv && pn < hn));
         best[t] = theirs ? pn : hn;
     }
-    return lane < 32 ? best[0] : best[1]; // lane L = (m = L % 32, half L / 32): tile L / 32 holds environment b0 + L
+    return lane_e < 32 ? best[0] : best[1]; // lane L = (m = L % 32, half L / 32): tile L / 32 holds environment b0 + L
 }
 
 template <class ROW>
 __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk, float *q_out, int n_out) {
     using Q = QNet<ROW>;
     extern __shared__ float w1[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * Q::kEnvsPerWave;
     // the state words of this lane's two environments are requested first: they arrive while the LDS image is being filled
     uint32_t aw[2][ROW::A];
@@ -274,7 +290,10 @@ __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk
     for (int t = 0; t < 2; t++) {
         const int64_t b = b0 + 32 * t + (lane & 31);
 #pragma unroll
-        for (int i = 0; i < ROW::A; i++) aw[t][i] = b < c.B ? (uint32_t)s.agent[(size_t)i * c.Bp + b] : 0u;
+        for (int i = 0; i < ROW::A; i++) { // (no branch around the load -- see qnet_wave's epilogue; a wave past the batch reads row 0)
+            const uint32_t wv = (uint32_t)s.agent[(size_t)i * c.Bp + (b < c.B ? b : 0)];
+            aw[t][i] = b < c.B ? wv : 0u;
+        }
     }
     { // the LDS image: every load in flight before the first write (one memory round trip, not kFill of them)
         constexpr int kFill = (Q::kLdsFloats / 4 + Q::kThreads - 1) / Q::kThreads;
@@ -305,23 +324,47 @@ __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk
 // Q-network as above, the argmax taken where the Q row lives, then the wave steps its own 64 environments (k_step's body, susnet_kernels.h
 // step_wave: the crew's draws from the action stream, the step, the in-step reset, the fused observation) -- no Q rows, no actions and no
 // second launch in between.  Dynamic LDS: the network image, then one step region of step_lds_bytes per wave.  q_out may be NULL.
+// n_ticks > 1 (susnet_qnet_policy_rollout): the kernel stays resident for a block of ticks -- the network image is copied to LDS once, a
+// launch is paid once -- and the outputs of tick k go to slot k of [T][B] arrays (ts: bytes between consecutive ticks of each output).
+// A wave only ever reads what it wrote itself (its own 64 environments): the stores of tick k are made visible to its loads of tick k + 1
+// by a release / acquire fence pair at agent scope (the vector L1 is not coherent with earlier stores on its own).
+struct TickStrides {
+    int64_t actions, rewards, done, trunc, term_obs, roles, q; // bytes
+};
+// All the arguments as ONE by-value struct, so the kernel can re-read them from the kernel-argument segment inside the tick loop (scalar
+// loads through a pointer the optimiser cannot see through) instead of carrying ~100 scalar registers across the Q-network, where every
+// vector register is already spoken for.
+struct QStepArgs {
+    Consts c;
+    State s;
+    const float *pk;
+    float *q_out;
+    int n_out;
+    StepArgs a;
+    ObsArgs o;
+    int step_lds_bytes, n_ticks;
+    TickStrides ts;
+};
+typedef __attribute__((address_space(4))) const char *KernargPtr;
+template <class T>
+__device__ __forceinline__ T kernarg_read(KernargPtr base, size_t off) {
+    T v; // (the typed pointer carries T's alignment: the copy becomes scalar loads, not byte-aligned vector loads)
+    __builtin_memcpy(&v, (const __attribute__((address_space(4))) T *)(base + off), sizeof(T));
+    return v;
+}
+#define SUSNET_KARG(base, field) kernarg_read<decltype(QStepArgs::field)>(base, offsetof(QStepArgs, field))
+
 template <class ROW, class S>
-__global__ __launch_bounds__(256) void k_qnet_step(Consts c, State s, const float *pk, float *q_out, int n_out, StepArgs a, ObsArgs o, int step_lds_bytes) {
+__global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
     using Q = QNet<ROW>;
     // dynamic LDS: [the step's table image, at address 0: its readers use absolute addresses][the network image][4 wave regions]
     extern __shared__ uint32_t dyn[];
     float *w1 = reinterpret_cast<float *>(dyn + kTableWords);
     static_assert((kTableWords * 4) % 16 == 0, "the network image is copied in 16-byte pieces");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * Q::kEnvsPerWave;
-    uint32_t aw[2][ROW::A];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int64_t b = b0 + 32 * t + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < ROW::A; i++) aw[t][i] = b < c.B ? (uint32_t)s.agent[(size_t)i * c.Bp + b] : 0u;
-    }
+    const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t b00 = ((int64_t)blockIdx.x * 4 + wave0) * Q::kEnvsPerWave;
     {
+        const float *pk = ka.pk;
         constexpr int kFill = (Q::kLdsFloats / 4 + Q::kThreads - 1) / Q::kThreads;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(pk);
         f32x4 *dst = reinterpret_cast<f32x4 *>(w1);
@@ -338,13 +381,69 @@ __global__ __launch_bounds__(256) void k_qnet_step(Consts c, State s, const floa
         }
     }
     __syncthreads();
-    if (b0 >= c.B) return; // (after the only barrier; the step below synchronises inside the wave only)
+    if (b00 >= ka.c.B) return; // (after the only barrier; the step below synchronises inside the wave only)
     bool unit = true;
 #pragma unroll
-    for (int l = 0; l < 4; l++) unit = unit && pk[Q::oSlope + l] >= 0.0f && pk[Q::oSlope + l] <= 1.0f;
-    const uint32_t a_imp = unit ? qnet_wave<ROW, true>(c, aw, pk, w1, q_out, n_out, b0, lane) : qnet_wave<ROW, false>(c, aw, pk, w1, q_out, n_out, b0, lane);
-    uint32_t *rest = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
-    step_wave<PhiloxRng, S>(c, s, a, o, dyn, rest, lane, b0, (int)a_imp);
+    for (int l = 0; l < 4; l++) unit = unit && ka.pk[Q::oSlope + l] >= 0.0f && ka.pk[Q::oSlope + l] <= 1.0f;
+    const int n_ticks = ka.n_ticks;
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < n_ticks; k++) {
+        if (k > 0) { // what this wave stored at tick k - 1 (its environments' state) is what it loads now
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        // (the optimiser would otherwise hoist every lane-dependent invariant of the step -- table-fill addresses, LDS offsets, ~150
+        // vector registers of them -- out of the tick loop and keep them across the Q-network; an opaque copy of the lane id per use
+        // site makes them per-tick values again)
+        uint32_t a_imp;
+        {
+            int lane = lane0;
+            int64_t b0 = b00;
+            KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp), "+v"(lane), "+s"(b0));
+            const Consts &c = ka.c; // (the tables: read in place)
+            const auto *agent = SUSNET_KARG(kp, s.agent);
+            const float *pk = SUSNET_KARG(kp, pk);
+            float *q_out = SUSNET_KARG(kp, q_out);
+            const int n_out = SUSNET_KARG(kp, n_out);
+            const int64_t qstride = SUSNET_KARG(kp, ts.q);
+            uint32_t aw[2][ROW::A];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int64_t b = b0 + 32 * t + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < ROW::A; i++) { // (rows are padded to Bp: no branch around the load -- see qnet_wave's epilogue)
+                    const uint32_t wv = (uint32_t)agent[(size_t)i * c.Bp + b];
+                    aw[t][i] = b < c.B ? wv : 0u;
+                }
+            }
+            float *qk = q_out ? reinterpret_cast<float *>(reinterpret_cast<char *>(q_out) + (int64_t)k * qstride) : nullptr;
+            a_imp = unit ? qnet_wave<ROW, true>(c, aw, pk, w1, qk, n_out, b0, lane) : qnet_wave<ROW, false>(c, aw, pk, w1, qk, n_out, b0, lane);
+        }
+        {
+            int lane = lane0, wave = wave0;
+            int64_t b0 = b00;
+            KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp), "+v"(lane), "+s"(wave), "+s"(b0));
+            const Consts &c = ka.c;
+            const State s = SUSNET_KARG(kp, s);
+            StepArgs ak = SUSNET_KARG(kp, a);
+            const ObsArgs &o = ka.o; // (a component list indexed at run time: read in place)
+            const TickStrides ts = SUSNET_KARG(kp, ts);
+            const int step_lds_bytes = SUSNET_KARG(kp, step_lds_bytes);
+            uint32_t *rest = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
+            auto shift = [&](auto *p, int64_t bytes) __attribute__((always_inline)) { return p ? reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + (int64_t)k * bytes) : p; };
+            ak.actions = ak.actions ? static_cast<const void *>(static_cast<const char *>(ak.actions) + (int64_t)k * ts.actions) : nullptr;
+            ak.rewards.ptr = ak.rewards.ptr ? static_cast<void *>(static_cast<char *>(ak.rewards.ptr) + (int64_t)k * ts.rewards) : nullptr;
+            ak.done = shift(ak.done, ts.done);
+            ak.trunc = shift(ak.trunc, ts.trunc);
+            ak.term_obs = shift(ak.term_obs, ts.term_obs);
+            ak.roles = shift(ak.roles, ts.roles);
+            ak.tick = ak.tick + (uint64_t)k;
+            step_wave<PhiloxRng, S>(c, s, ak, o, dyn, rest, lane, b0, (int)a_imp, (int64_t)k);
+        }
+    }
 }
+#undef SUSNET_KARG
 
 } // namespace susnet

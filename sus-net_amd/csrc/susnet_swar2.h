@@ -164,7 +164,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     }
 
     // ---- KILL (base.py:490-515), imposters in turn order --------------------------------------------------------------------
-    uint32_t kc80 = 0, pend80 = 0;
+    uint32_t pend80 = 0;
     uint32_t idx4 = w.ridx; // reward-table byte index per agent: the episode's base + what this step adds (see step_swar)
     bool changed = check_win; // something the win rules read moved this step (the same in both lanes of a pair)
     {
@@ -221,8 +221,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
             w.crew80 &= ~v80;
             w.ridx += v80 >> 3;      // the victim's rewards come from the "dead" rows from now on (base.py:562)
             const uint32_t hot = hit ? (second_first ? w.ihot[s1] : w.ihot[s0]) : 0u;
-            kc80 |= hot;             // base.py:514-515 (the victim's slot ends as dead_penalty)
-            idx4 += (v80 >> 3) + (hot >> 5); // RC_KILL * 4 for the killer
+            idx4 += (v80 >> 3) + (hot >> 5); // RC_KILL * 4 for the killer; base.py:514-515: the victim's slot ends as dead_penalty
             pend80 |= v80 & ge80;    // killed before its own turn: it never acts
         }
     }

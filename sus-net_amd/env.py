@@ -654,7 +654,7 @@ class BatchedFourRoomEnv:
 
     def policy_tick_into(self, feed: Dict[str, torch.Tensor], t: int, net_imposter: "PackedQNet" = None, net_crew: "PackedQNet" = None,
                          q_imposter: Optional[torch.Tensor] = None, q_crew: Optional[torch.Tensor] = None, epsilon: float = 0.0,
-                         mask_dead: bool = True) -> None:
+                         mask_dead: bool = True, q_out: Optional[torch.Tensor] = None) -> None:
         """ONE tick of the trainer's acting loop (train.py:345-399: act on the current state, step, keep what ``replay_buffer.add``
         needs) written into slot ``t`` of ``feed``: the actions taken, rewards, done / truncated, the raw uint8 state after the step (after
         the auto-reset where the episode ended), the true terminal state there, and the acting episode's roles.  The teams' Q rows come
@@ -689,8 +689,11 @@ class BatchedFourRoomEnv:
         opts = self._policy_opts(epsilon, mask_dead)
         with self._on_device():
             if net_imposter is not None and net_crew is None and q_crew is None and self.supports_qnet_policy_step(net_imposter):
+                if q_out is not None:  # (the one-kernel tick can also emit the Q rows it acted on)
+                    assert q_out.dtype == torch.float32 and tuple(q_out.shape) == (self.batch, net_imposter.dims[-1]) and q_out.is_contiguous()
                 L.check(self.lib.susnet_qnet_policy_step(self._h, net_imposter.components, len(net_imposter.components), net_imposter.cdims,
-                                                         len(net_imposter.dims), net_imposter.packed.data_ptr(), None, opts, C.byref(io), self._stream()))
+                                                         len(net_imposter.dims), net_imposter.packed.data_ptr(), q_out.data_ptr() if q_out is not None else None,
+                                                         opts, C.byref(io), self._stream()))
             else:
                 if q_imposter is None:
                     q_imposter = self.qnet_forward(net_imposter)
@@ -700,6 +703,26 @@ class BatchedFourRoomEnv:
                                                     C.byref(io), self._stream()))
             if bounce is not None:
                 slot.copy_(bounce)
+
+    def policy_rollout_into(self, feed: Dict[str, torch.Tensor], n_ticks: int, net_imposter: "PackedQNet", epsilon: float = 0.0, mask_dead: bool = True,
+                            q_out: Optional[torch.Tensor] = None) -> None:
+        """``n_ticks`` policy ticks (slots 0 .. n_ticks - 1 of ``feed``) in ONE launch (``susnet_qnet_policy_rollout``): what ``policy_tick_into``
+        does per tick, with the network image loaded and the launch paid once -- the acting loop between two optimizer steps.  Needs
+        ``supports_qnet_policy_step(net_imposter)`` (a compiled-in game, the production stream, a random crew)."""
+        assert self.auto_reset and self.supports_qnet_policy_step(net_imposter) and 1 <= n_ticks <= feed["n_ticks"]
+        assert feed["obs"][0].data_ptr() % 16 == 0 and (self.batch * self.flattened_state_size) % 16 == 0, \
+            "the fused raw observation is written in 16-byte pieces: batch x flattened_state_size must be a multiple of 16"
+        io = L.FeedIO()
+        io.actions, io.rewards = feed["actions"].data_ptr(), feed["rewards"].data_ptr()
+        io.done, io.truncated = feed["done"].data_ptr(), feed["truncated"].data_ptr()
+        io.obs, io.term_obs, io.roles = feed["obs"].data_ptr(), feed["term_obs"].data_ptr(), feed["roles"].data_ptr()
+        if q_out is not None:
+            assert q_out.dtype == torch.float32 and tuple(q_out.shape) == (n_ticks, self.batch, net_imposter.dims[-1]) and q_out.is_contiguous()
+            io.q = q_out.data_ptr()
+        with self._on_device():
+            L.check(self.lib.susnet_qnet_policy_rollout(self._h, net_imposter.components, len(net_imposter.components), net_imposter.cdims,
+                                                        len(net_imposter.dims), net_imposter.packed.data_ptr(), self._policy_opts(epsilon, mask_dead),
+                                                        C.byref(io), int(n_ticks), self._stream()))
 
     def step4(self, agent_actions):
         """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""

@@ -144,14 +144,16 @@ class DeviceReplayBuffer:
         return io
 
     @torch.no_grad()
-    def collect(self, env, policy, num_steps: int, epsilon: float = 0.0, mask_dead: bool = True, ticks_per_append: int = 64) -> int:
+    def collect(self, env, policy, num_steps: int, epsilon: float = 0.0, mask_dead: bool = True, ticks_per_append: int = 64,
+                one_launch_per_block: bool = True) -> int:
         """The trainer's collection loop (train.py:345-399) for B environments in lockstep, on the device: per tick the teams act by
         their Q-networks on the current state -- epsilon-greedy, dead agents get index 0 (train.py:351-381) --, the env steps, and the
         transition ``(window, actions, rewards, next window, done, imposters)`` goes to the ring with ``ReplayBuffer.add``'s semantics
         (replay_memory.py:50-73; windows as train.py:318-322, 388-389, 441-445).  ``policy``: a ``PolicyRollout`` over ``env`` whose
         models are reference MLPs the Q-network kernel serves (``policy.fused_imposter``; the crew by ``policy.fused_crew``, or random
         when it has no model).  Per tick ONE kernel where the env serves the whole tick (``susnet_qnet_policy_step``), else the network
-        launch(es) + ``susnet_policy_step``; every ``ticks_per_append`` ticks ONE ``susnet_ring_append``.  The sequence window carries
+        launch(es) + ``susnet_policy_step``; every ``ticks_per_append`` ticks ONE ``susnet_ring_append``.  ``one_launch_per_block``: the block's
+        ticks in ONE launch where the env serves it (``susnet_qnet_policy_rollout``: the weights are fixed within a block anyway).  The sequence window carries
         over between calls (``reset_collection`` after an ``env.reset()``).  Row order = tick-major, env-minor; with ``batch=1``,
         ``rng='numpy'`` and two networks the ring equals the reference's for the same numpy seed and weights
         (tests/golden/collect_*.npz).  Returns the number of transitions added."""
@@ -172,12 +174,18 @@ class DeviceReplayBuffer:
         if feed is None or feed["n_ticks"] != n_block or feed["actions"].shape[1] != B:
             feed = self._collect_feed = env.alloc_feed(n_block)
         io = self._ring_io(env, feed, self._collect_window)
+        # one launch per BLOCK where the env serves the whole tick in one kernel and the block's observation slots are 16-byte aligned
+        fused_block = (one_launch_per_block and policy.fused_crew is None and policy.crew_model is None and env.supports_qnet_policy_step(policy.fused_imposter)
+                       and (B * self.state_size) % 16 == 0)
         done_ticks = 0
         while done_ticks < num_steps:
             n = min(n_block, num_steps - done_ticks)
             policy.refresh_weights(force=False)  # (the optimizer may have stepped since the last block)
-            for t in range(n):
-                env.policy_tick_into(feed, t, net_imposter=policy.fused_imposter, net_crew=policy.fused_crew, epsilon=epsilon, mask_dead=mask_dead)
+            if fused_block:  # the whole block in ONE launch (susnet_qnet_policy_rollout)
+                env.policy_rollout_into(feed, n, policy.fused_imposter, epsilon=epsilon, mask_dead=mask_dead)
+            else:
+                for t in range(n):
+                    env.policy_tick_into(feed, t, net_imposter=policy.fused_imposter, net_crew=policy.fused_crew, epsilon=epsilon, mask_dead=mask_dead)
             io.n_ticks, io.idx = n, self.idx
             with torch.cuda.device(env.device):
                 L.check(env.lib.susnet_ring_append(env._h, C.byref(io), env._stream()))

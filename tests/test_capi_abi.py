@@ -24,7 +24,8 @@ def test_header_is_plain_c_and_matches_ctypes(pkg, tmp_path):
     prog = tmp_path / "sizes.c"
     structs = {"susnet_config": L.Config, "susnet_layout": L.Layout, "susnet_obs_spec": L.ObsSpec,
                "susnet_step_io": L.StepIO, "susnet_rollout_io": L.RolloutIO, "susnet_state_view": L.StateView,
-               "susnet_record_layout_t": L.RecordLayout, "susnet_ring_io": L.RingIO, "susnet_policy_opts": L.PolicyOpts}
+               "susnet_record_layout_t": L.RecordLayout, "susnet_ring_io": L.RingIO, "susnet_policy_opts": L.PolicyOpts,
+               "susnet_feed_io": L.FeedIO}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "susnet.h"', "int main(void){"]
     for name, ct in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')

@@ -1497,14 +1497,17 @@ def _replay_feeds():
     return [(n, f) for n in replay_names() for f in ("tensors",) + (("records", "compact") if n.startswith("replay_itg_1v1") else ())]
 
 
+@pytest.mark.parametrize("tile", [None, "0"], ids=["tile-kernel", "row-kernel"])
 @pytest.mark.parametrize("name,feed", _replay_feeds())
-def test_native_replay_ring_matches_reference_populate(pkg, name, feed):
+def test_native_replay_ring_matches_reference_populate(pkg, name, feed, tile, monkeypatch):
     """susnet_ring_append fed by the fused rollout against the REFERENCE's own `ReplayBuffer.populate` tensors
     (tests/golden/generate_replay.py: unmodified src/replay_memory.py on the unmodified env after np.random.seed): one env,
     numpy's words as the tape, several launches (the window is carried across them; one fixture wraps the ring)."""
     g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
     meta = g["meta"]
     T, max_size, num_steps = meta["trajectory_size"], meta["max_size"], meta["num_steps"]
+    if tile is not None:
+        monkeypatch.setenv("SUSNET_RING_TILE", tile)  # (read at susnet_create)
     env = env_from_meta(pkg, meta, 1, rng="numpy", tape_words=1 << 16, auto_reset=True, check_errors=False)
     env._reseed([meta["seed"]])
     buf = pkg.DeviceReplayBuffer(max_size, meta["state_size"], T, meta["n_agents"], meta["n_imposters"], device=env.device)
@@ -1605,7 +1608,8 @@ def test_policy_driven_collection_matches_the_reference_trainer_loop(pkg, name):
     np.testing.assert_array_equal(np_(buf.imposters[:n]), g["imposters"], err_msg="imposters")
 
 
-def test_one_kernel_collection_matches_the_step_by_step_policy_loop(pkg):
+@pytest.mark.parametrize("one_launch", [True, False], ids=["block-in-one-launch", "launch-per-tick"])
+def test_one_kernel_collection_matches_the_step_by_step_policy_loop(pkg, one_launch):
     """Production stream, random crew, epsilon-greedy: `collect` (ONE kernel per tick writing the replay feed) against a twin env driven
     tick by tick through `PolicyRollout.tick` with the window / ring bookkeeping done in torch (`add_batch`): same transitions, same
     ring -- episode ends, terminal next-states and truncations included."""
@@ -1620,7 +1624,7 @@ def test_one_kernel_collection_matches_the_step_by_step_policy_loop(pkg):
     pol = pkg.PolicyRollout(env, model, None, components=comps, epsilon=0.25, mask_dead=True)
     assert pol.one_kernel_tick
     env.reset()
-    assert buf.collect(env, pol, n_ticks, epsilon=0.25, mask_dead=True, ticks_per_append=32) == B * n_ticks
+    assert buf.collect(env, pol, n_ticks, epsilon=0.25, mask_dead=True, ticks_per_append=32, one_launch_per_block=one_launch) == B * n_ticks
     # the twin: the tested tick (susnet_qnet_policy_step through PolicyRollout) + torch bookkeeping with the reference's window rules
     tp = pkg.PolicyRollout(twin, model, None, components=comps, epsilon=0.25, mask_dead=True)
     raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
@@ -1657,12 +1661,52 @@ def test_one_kernel_collection_matches_the_step_by_step_policy_loop(pkg):
     np.testing.assert_array_equal(term[:, 3 * A:3 * A + 8], prev[:, 3 * A:3 * A + 8], err_msg="job cells stay within an episode")
 
 
-@pytest.mark.parametrize("game,T", [("base_1v2", 3), ("tagging_1v4", 14), ("base_2v6", 29)])
-def test_native_replay_ring_batched_matches_a_host_rebuild(pkg, game, T):
+@pytest.mark.parametrize("name,comps,B", [("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], 16 * 61), ("itg_1v1_nowalls", ["onehot_pos"], 16 * 37)])
+def test_policy_block_in_one_launch_equals_one_launch_per_tick(pkg, oracle_mod, name, comps, B):
+    """susnet_qnet_policy_rollout (the policy tick looped INSIDE the kernel, the wave re-reading the state it stored) against
+    susnet_qnet_policy_step called once per tick on a twin: every feed array of every tick, the Q rows, and the state afterwards.
+    B is not a multiple of the 256 environments of a workgroup, and the run crosses episode ends."""
+    n = 40
+    mk = lambda: make_pair(pkg, oracle_mod, name, B, 5, auto_reset=True, check_errors=False, max_time_steps=12, obs=pkg.ObsConfig("flat", comps))[0]
+    env, twin = mk(), mk()
+    model = pkg.policy.reference_imposter_mlp(env, comps, seed=9)
+    pol, tp = (pkg.PolicyRollout(e, model, None, components=comps, epsilon=0.2, mask_dead=True) for e in (env, twin))
+    if not env.supports_qnet_policy_step(pol.fused_imposter):
+        pytest.skip("no one-kernel tick for this game")
+    env.reset(), twin.reset()
+    nq = pol.fused_imposter.dims[-1]
+    fa, fb = env.alloc_feed(n), twin.alloc_feed(n)
+    qa = torch.zeros(n, B, nq, device=env.device)
+    qb = torch.zeros(n, B, nq, device=env.device)
+    env.policy_rollout_into(fa, n, pol.fused_imposter, epsilon=0.2, mask_dead=True, q_out=qa)
+    for k in range(n):
+        twin.policy_tick_into(fb, k, tp.fused_imposter, epsilon=0.2, mask_dead=True, q_out=qb[k])
+    torch.cuda.synchronize()
+    for key in ("actions", "rewards", "done", "truncated", "obs", "term_obs", "roles"):
+        a, b = fa[key][:n].contiguous(), fb[key][:n].contiguous()
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), key
+    assert torch.equal(qa.view(torch.int32), qb.view(torch.int32)), "Q rows"
+    assert int((fa["done"][:n] | fa["truncated"][:n]).sum()) > B // 8, "the block must cross episode ends"
+    raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
+    assert torch.equal(env.observe(raw8), twin.observe(raw8)) and torch.equal(env.episode_index(), twin.episode_index())
+    # and a second block continues where the first stopped (tick counter, episode counters)
+    env.policy_rollout_into(fa, 7, pol.fused_imposter, epsilon=0.2, mask_dead=True)
+    for k in range(7):
+        twin.policy_tick_into(fb, k, tp.fused_imposter, epsilon=0.2, mask_dead=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fa["actions"][:7], fb["actions"][:7]) and torch.equal(fa["obs"][:7], fb["obs"][:7])
+
+
+@pytest.mark.parametrize("game,T,tile", [("base_1v2", 3, None), ("base_1v2", 3, "0"), ("base_1v2", 3, "16"), ("base_1v2", 2, "32"), ("base_2v6", 8, None),
+                                         ("tagging_1v4", 14, None), ("base_2v6", 29, None)])
+def test_native_replay_ring_batched_matches_a_host_rebuild(pkg, game, T, tile, monkeypatch):
     """Many envs, odd launch lengths, a ring smaller than the run: every row the ring holds equals what replaying the
     trajectory on the host with ReplayBuffer.populate's rules gives (window roll, first state repeated after a reset, true
     terminal next state, `done` only), at position (rows added so far) % max_size.  The long windows (14 x 41 bytes, 29 x 36
-    bytes per row) do not fit 64 rows into the kernel's LDS images: a wave then takes 32 / 16 rows (RingArgs::rows_per_wave)."""
+    bytes per row) do not fit 64 rows into the kernel's LDS images: a wave then takes 32 / 16 rows (RingArgs::rows_per_wave).  Windows of
+    up to 8 states go through the tile kernel (a wave = 8 ticks x 8 envs, or 4 x 16 / 2 x 32 / the row kernel under SUSNET_RING_TILE)."""
+    if tile is not None:
+        monkeypatch.setenv("SUSNET_RING_TILE", tile)  # (read at susnet_create)
     B, max_size = 300, 4000
     mk = {"base_1v2": lambda: pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False),
           "tagging_1v4": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 5, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False),
