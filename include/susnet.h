@@ -172,7 +172,7 @@ typedef struct susnet_layout {
  *   SUSNET_FORCE_GENERIC=1      every configuration runs the generic (LDS-table) kernels, none of the compiled-in ones
  *   SUSNET_EPW=16|32|64         environments per wave of the fused rollout
  *   SUSNET_TRAJ_MAX_BYTES=n     default of susnet_set_launch_limit()
- *   SUSNET_RING_TILE=0|8|16|32  susnet_ring_append: environments of a wave's (ticks x envs) tile; 0 = 64 consecutive rows per wave */
+ *   SUSNET_RING_TILE=0|8|16|32  susnet_ring_append: environments of a wave's (ticks x envs) tile; 0 (default) = 64 consecutive rows per wave */
 #define SUSNET_OVERRIDE_FORCE_GENERIC 1u
 #define SUSNET_OVERRIDE_EPW 2u
 #define SUSNET_OVERRIDE_TRAJ_MAX_BYTES 4u

@@ -457,7 +457,7 @@ struct susnet_env {
     uint64_t ticks = 0; // steps taken (index of the production action stream)
     // test hooks, read ONCE at susnet_create (include/susnet.h SUSNET_OVERRIDE_*)
     bool force_generic = false;
-    int ring_tile = 8; // susnet_ring_append: environments of a wave's (ticks x envs) tile (8 / 16 / 32; 0: consecutive rows per wave)
+    int ring_tile = 0;   // susnet_ring_append: environments of a wave's (ticks x envs) tile (8 / 16 / 32; 0: consecutive rows per wave)
     uint64_t launch_limit = (1ull << 31) - 1u, launch_limit_default = (1ull << 31) - 1u;
     int spec = 0; // pick_spec(): which compiled-in kernel family serves the handle (0 = generic)
     susnet_layout layout;
@@ -1382,6 +1382,8 @@ struct RingArgs {
     int32_t A, S, n_imp;
     int32_t rows_per_wave; // 64, or fewer when 64 rows of 2 x trajectory_size x S bytes would not fit the LDS images
     int32_t tile_log2e;    // k_ring_append_tile: log2 of the tile's environments (3: 8 ticks x 8 envs)
+    int32_t n0_b;            // n0 = n0_t * B + n0_b; pos_n0 = ring position of transition n0
+    int64_t n0_t, pos_n0;
     // the trajectory as PACKED RECORDS (io.record; whole records only: the 1v1 kernels), wave-uniform: record size (0 = separate
     // tensors) and field offsets; rec_packed: actions and flags share one byte (SUSNET_RECORD_COMPACT)
     int32_t rec_bytes, rec_obs, rec_act, rec_rew, rec_done, rec_trunc, rec_packed;
@@ -1411,22 +1413,22 @@ __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t 
     if (r.rec_bytes) return ring_rec(r, u, b) + r.rec_obs;
     return r.io.obs + ((size_t)u * r.B + b) * r.S;
 }
-// One wave per 64 consecutive transitions (32 / 16 / 8 for long windows: RingArgs::rows_per_wave).  Lane r gathers what its row needs into flat images in LDS, laid out exactly as the
-// wave's 64 rows lie in each ring tensor (row-major; `states` and `next_states`: Tw * S bytes per row, the Tw - 1 shared states
-// written to both; actions, rewards, done, imposters likewise), and the wave then writes every tensor as ONE linear range:
-// 16 bytes per lane and step, no index arithmetic.  Two things made the first version slow (3.1-3.5 TB/s, 82 % of the wave cycles
-// waiting): every element index was divided by Tw * S to find its row, and each lane stored its row's small tensors between its
-// loads -- stores the loads behind them had to wait for (may-alias), one memory round trip per element.  Now a lane only LOADS in
-// the gather phase (flags first, unrolled without an early exit; then rows, actions, rewards, roles) and all global stores happen
-// after it.
+// One wave per 64 consecutive transitions (32 / 16 / 8 for long windows: RingArgs::rows_per_wave).
+// Lane r gathers what its row needs into flat images in LDS, laid out exactly as the wave's 64 rows lie in each ring tensor (row-major;
+// `states` and `next_states`: Tw * S bytes per row, the Tw - 1 shared states written to both; actions, rewards, done, imposters
+// likewise), and the wave then writes every tensor as ONE linear range: 16 bytes per lane and step, no index arithmetic.  (One image of
+// Tw + 1 states per row, read at offsets 0 and S, needs a quarter less LDS but its reads are unaligned dwords: measured 2.1 / 3.4 TB/s
+// against 3.0 / 4.2 on the 1v1 and 1v2 shapes.)
+// Two things made the first version slow (3.1-3.5 TB/s, 82 % of the wave cycles waiting): every element index was divided by Tw * S to
+// find its row, and each lane stored its row's small tensors between its loads -- stores the loads behind them had to wait for
+// (may-alias), one memory round trip per element.  Now a lane only LOADS in the gather phase (flags first, unrolled without an early
+// exit; then rows, actions, rewards, roles) and all global stores happen after it.
 constexpr int kRingFlagsUnroll = 8;
 constexpr int kRingGroup = 3, kRingChunk = 8; // source states per load group; dwords of a state per load group
 __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A, NI = r.n_imp;
     const int R = r.rows_per_wave;
-    const int64_t n_first = r.n0 + (int64_t)blockIdx.x * R, n = n_first + lane;
-    const int rows = (int)((r.n1 - n_first) < R ? (r.n1 - n_first) : R);
     const int TS = Tw * S;
     const int img = (R * TS + 15) & ~15; // bytes of one state image (padded: the vector loops read up to 3 bytes past the last row)
     uint8_t *st_img = reinterpret_cast<uint8_t *>(smem), *nx_img = st_img + img;
@@ -1434,8 +1436,14 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
     uint8_t *act_img = reinterpret_cast<uint8_t *>(rew_img + R * A); // [R][A] (+ pad)
     uint8_t *done_img = act_img + ((R * A + 15) & ~15);              // [R]
     int16_t *imp_img = reinterpret_cast<int16_t *>(done_img + 64);   // [R][NI]
+    // (tick, env) of the lane's transition n = n0 + rel + lane without a 64-bit division per lane: the host supplies n0's, the rest is
+    // 32-bit (rel + B < 2^32: checked there)
+    const uint32_t rel = (uint32_t)blockIdx.x * (uint32_t)R;
+    const int64_t n_first = r.n0 + (int64_t)rel;
+    const int rows = (int)((r.n1 - n_first) < R ? (r.n1 - n_first) : R);
     if (lane < rows) {
-        const int64_t t = n / r.B, b = n % r.B;
+        const uint32_t x = rel + (uint32_t)r.n0_b + (uint32_t)lane, tq = x / (uint32_t)r.B;
+        const int64_t t = r.n0_t + (int64_t)tq, b = (int64_t)(x - tq * (uint32_t)r.B);
         // most recent episode boundary before tick t within the window's reach (the episode's first state is obs[e]); all flag
         // loads are independent of each other
         int64_t e = -(1ll << 62);
@@ -1538,7 +1546,8 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
     }
     wave_lds_fence();
     // ring position of row 0 of this wave; rows are consecutive positions modulo max_size
-    const int64_t pos0 = (r.io.idx + n_first) % r.io.max_size;
+    int64_t pos0 = r.pos_n0 + (int64_t)rel; // (pos_n0 = (idx + n0) % max_size from the host; rel < max_size)
+    if (pos0 >= r.io.max_size) pos0 -= r.io.max_size;
     const int total = rows * TS;
     if (__builtin_expect(pos0 + rows <= r.io.max_size, 1)) { // no wrap inside the wave: every output is ONE contiguous range
         float *out_s = r.io.states + (size_t)pos0 * TS, *out_n = r.io.next_states + (size_t)pos0 * TS;
@@ -1907,6 +1916,10 @@ extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, voi
     const int64_t total = (int64_t)io->n_ticks * r.B;
     r.n0 = total > io->max_size ? total - io->max_size : 0; // (earlier rows would be overwritten by later ones of this same launch)
     r.n1 = total;
+    r.n0_t = r.n0 / r.B;
+    r.n0_b = (int32_t)(r.n0 % r.B);
+    r.pos_n0 = (io->idx + r.n0) % io->max_size;
+    if (r.n1 - r.n0 + r.B + 64 >= (1ll << 32)) return fail(SUSNET_E_INVALID, "susnet_ring_append: more than 2^32 rows in one launch");
     // the row images of k_ring_append: states, next_states (bytes), rewards (f32), actions (bytes), done, imposters (i16); a wave
     // takes 64 rows, or 32 / 16 / 8 when the window is long (trajectory_size x S bytes per row, twice): the reference's
     // ReplayBuffer accepts any trajectory_size (replay_memory.py:33-44)

@@ -1497,7 +1497,7 @@ def _replay_feeds():
     return [(n, f) for n in replay_names() for f in ("tensors",) + (("records", "compact") if n.startswith("replay_itg_1v1") else ())]
 
 
-@pytest.mark.parametrize("tile", [None, "0"], ids=["tile-kernel", "row-kernel"])
+@pytest.mark.parametrize("tile", [None, "8"], ids=["row-kernel", "tile-kernel"])
 @pytest.mark.parametrize("name,feed", _replay_feeds())
 def test_native_replay_ring_matches_reference_populate(pkg, name, feed, tile, monkeypatch):
     """susnet_ring_append fed by the fused rollout against the REFERENCE's own `ReplayBuffer.populate` tensors
@@ -1697,16 +1697,17 @@ def test_policy_block_in_one_launch_equals_one_launch_per_tick(pkg, oracle_mod, 
     assert torch.equal(fa["actions"][:7], fb["actions"][:7]) and torch.equal(fa["obs"][:7], fb["obs"][:7])
 
 
-@pytest.mark.parametrize("game,T,tile", [("base_1v2", 3, None), ("base_1v2", 3, "0"), ("base_1v2", 3, "16"), ("base_1v2", 2, "32"), ("base_2v6", 8, None),
+@pytest.mark.parametrize("game,T,tile", [("base_1v2", 3, None), ("base_1v2", 3, "tile=8"),
+                                         ("base_1v2", 3, "tile=16"), ("base_1v2", 2, "tile=32"), ("base_2v6", 8, "tile=8"), ("base_2v6", 8, None),
                                          ("tagging_1v4", 14, None), ("base_2v6", 29, None)])
 def test_native_replay_ring_batched_matches_a_host_rebuild(pkg, game, T, tile, monkeypatch):
     """Many envs, odd launch lengths, a ring smaller than the run: every row the ring holds equals what replaying the
     trajectory on the host with ReplayBuffer.populate's rules gives (window roll, first state repeated after a reset, true
     terminal next state, `done` only), at position (rows added so far) % max_size.  The long windows (14 x 41 bytes, 29 x 36
-    bytes per row) do not fit 64 rows into the kernel's LDS images: a wave then takes 32 / 16 rows (RingArgs::rows_per_wave).  Windows of
-    up to 8 states go through the tile kernel (a wave = 8 ticks x 8 envs, or 4 x 16 / 2 x 32 / the row kernel under SUSNET_RING_TILE)."""
+    bytes per row) do not fit 64 rows into the kernel's LDS images: a wave then takes 32 / 16 rows (RingArgs::rows_per_wave).  Behind the
+    SUSNET_RING_TILE test hook: the (ticks x envs) tile kernel for windows of up to 8 states (8 x 8, 4 x 16, 2 x 32)."""
     if tile is not None:
-        monkeypatch.setenv("SUSNET_RING_TILE", tile)  # (read at susnet_create)
+        monkeypatch.setenv("SUSNET_RING_TILE", tile.split("=")[1])  # (read at susnet_create)
     B, max_size = 300, 4000
     mk = {"base_1v2": lambda: pkg.BatchedFourRoomEnv(1, 2, 4, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False),
           "tagging_1v4": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 5, batch=B, auto_reset=True, seed=31, max_time_steps=25, check_errors=False),
