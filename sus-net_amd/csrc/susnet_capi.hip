@@ -1388,30 +1388,36 @@ struct RingArgs {
     // tensors) and field offsets; rec_packed: actions and flags share one byte (SUSNET_RECORD_COMPACT)
     int32_t rec_bytes, rec_obs, rec_act, rec_rew, rec_done, rec_trunc, rec_packed;
 };
-// the trajectory's fields at (tick u, env b), from the separate tensors or from the records (a wave-uniform choice)
+// the trajectory's fields at (tick u, env b), from the separate tensors or from the records -- a compile-time choice (REC): as a run-time
+// one every access carried a uniform branch and both address forms, and the append of the small 1v1 rows ran at 81 us instead of 56
 __device__ __forceinline__ const uint8_t *ring_rec(const RingArgs &r, int64_t u, int64_t b) { return r.io.record + ((size_t)u * r.B + b) * (size_t)r.rec_bytes; }
+template <bool REC>
 __device__ __forceinline__ uint32_t ring_done(const RingArgs &r, int64_t u, int64_t b) {
-    if (r.rec_bytes) return r.rec_packed ? (ring_rec(r, u, b)[r.rec_done] >> 6) & 1u : (uint32_t)ring_rec(r, u, b)[r.rec_done];
-    return r.io.done[u * r.B + b];
+    if constexpr (REC) return r.rec_packed ? (ring_rec(r, u, b)[r.rec_done] >> 6) & 1u : (uint32_t)ring_rec(r, u, b)[r.rec_done];
+    else return r.io.done[u * r.B + b];
 }
+template <bool REC>
 __device__ __forceinline__ uint32_t ring_trunc(const RingArgs &r, int64_t u, int64_t b) {
-    if (r.rec_bytes) return r.rec_packed ? (uint32_t)(ring_rec(r, u, b)[r.rec_trunc] >> 7) : (uint32_t)ring_rec(r, u, b)[r.rec_trunc];
-    return r.io.truncated[u * r.B + b];
+    if constexpr (REC) return r.rec_packed ? (uint32_t)(ring_rec(r, u, b)[r.rec_trunc] >> 7) : (uint32_t)ring_rec(r, u, b)[r.rec_trunc];
+    else return r.io.truncated[u * r.B + b];
 }
+template <bool REC>
 __device__ __forceinline__ uint32_t ring_action(const RingArgs &r, int64_t t, int64_t b, int i) {
-    if (r.rec_bytes) return r.rec_packed ? (ring_rec(r, t, b)[r.rec_act] >> (3 * i)) & 7u : (uint32_t)ring_rec(r, t, b)[r.rec_act + i];
-    return r.io.actions[((size_t)t * r.B + b) * r.A + i];
+    if constexpr (REC) return r.rec_packed ? (ring_rec(r, t, b)[r.rec_act] >> (3 * i)) & 7u : (uint32_t)ring_rec(r, t, b)[r.rec_act + i];
+    else return r.io.actions[((size_t)t * r.B + b) * r.A + i];
 }
+template <bool REC>
 __device__ __forceinline__ float ring_reward(const RingArgs &r, int64_t t, int64_t b, int i) {
-    if (r.rec_bytes) return reinterpret_cast<const float *>(ring_rec(r, t, b) + r.rec_rew)[i];
-    return r.io.rewards[((size_t)t * r.B + b) * r.A + i];
+    if constexpr (REC) return reinterpret_cast<const float *>(ring_rec(r, t, b) + r.rec_rew)[i];
+    else return r.io.rewards[((size_t)t * r.B + b) * r.A + i];
 }
 // the flattened state an env's window holds at virtual tick u (= the state after tick u; u < 0: the carried-in window)
+template <bool REC>
 __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t u, int64_t b) {
     const int Tw = r.io.trajectory_size;
     if (u < 0) return r.io.window + ((size_t)b * Tw + (size_t)(Tw + u < 0 ? 0 : Tw + u)) * r.S; // window[Tw - 1] = state before tick 0
-    if (r.rec_bytes) return ring_rec(r, u, b) + r.rec_obs;
-    return r.io.obs + ((size_t)u * r.B + b) * r.S;
+    if constexpr (REC) return ring_rec(r, u, b) + r.rec_obs;
+    else return r.io.obs + ((size_t)u * r.B + b) * r.S;
 }
 // One wave per 64 consecutive transitions (32 / 16 / 8 for long windows: RingArgs::rows_per_wave).
 // Lane r gathers what its row needs into flat images in LDS, laid out exactly as the wave's 64 rows lie in each ring tensor (row-major;
@@ -1425,6 +1431,7 @@ __device__ __forceinline__ const uint8_t *ring_state(const RingArgs &r, int64_t 
 // exit; then rows, actions, rewards, roles) and all global stores happen after it.
 constexpr int kRingFlagsUnroll = 8;
 constexpr int kRingGroup = 3, kRingChunk = 8; // source states per load group; dwords of a state per load group
+template <bool REC>
 __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A, NI = r.n_imp;
@@ -1453,17 +1460,17 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
             for (int k = 1; k <= kRingFlagsUnroll; k++) { // every lane loads (tick clamped): no per-lane branch, no wait between the loads
                 const int64_t u = t - k < 0 ? 0 : t - k;
                 const bool want = k <= Tw; // (wave-uniform)
-                fd[k - 1] = want ? ring_done(r, u, b) : 0u;
-                ft[k - 1] = want ? ring_trunc(r, u, b) : 0u;
+                fd[k - 1] = want ? ring_done<REC>(r, u, b) : 0u;
+                ft[k - 1] = want ? ring_trunc<REC>(r, u, b) : 0u;
             }
 #pragma unroll
             for (int k = kRingFlagsUnroll; k >= 1; k--)
                 if ((fd[k - 1] | ft[k - 1]) != 0u && t - k >= 0) e = t - k; // (descending k: the most recent boundary wins)
         } else {
             for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
-                if (ring_done(r, u, b) | ring_trunc(r, u, b)) { e = u; break; }
+                if (ring_done<REC>(r, u, b) | ring_trunc<REC>(r, u, b)) { e = u; break; }
         }
-        const uint32_t dn = ring_done(r, t, b), tr = ring_trunc(r, t, b);
+        const uint32_t dn = ring_done<REC>(r, t, b), tr = ring_trunc<REC>(r, t, b);
         const uint32_t role_bits = r.io.roles ? (uint32_t)r.io.roles[t * r.B + b] : ((1u << NI) - 1u);
         uint8_t *my_st = st_img + (size_t)lane * TS, *my_nx = nx_img + (size_t)lane * TS;
         // The row needs Tw + 1 source states (replay_memory.py:108-113, 122-127): the window's Tw states -> states[k], and shifted by one
@@ -1472,12 +1479,12 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
         // byte tail.  All loads of a group of kRingGroup states are issued before the first LDS store: one memory round trip per group,
         // not one per dword (the rolled load -> store loop this replaces made 18 dependent round trips per row and left the kernel
         // latency-bound at 3.7 TB/s).
-        const uint8_t *nxt = (dn | tr) ? r.io.term_obs + ((size_t)t * r.B + b) * S : ring_state(r, t, b);
+        const uint8_t *nxt = (dn | tr) ? r.io.term_obs + ((size_t)t * r.B + b) * S : ring_state<REC>(r, t, b);
         auto source = [&](int k) -> const uint8_t * {
             if (k >= Tw) return nxt;
             int64_t u = t - Tw + k;
             if (u < e) u = e;
-            return ring_state(r, u, b);
+            return ring_state<REC>(r, u, b);
         };
         for (int k0 = 0; k0 <= Tw; k0 += kRingGroup) {
             for (int c0 = 0; c0 < S; c0 += 4 * kRingChunk) {
@@ -1526,8 +1533,8 @@ __global__ __launch_bounds__(64) void k_ring_append(RingArgs r) {
 #pragma unroll
             for (int q = 0; q < 8; q++)
                 if (i0 + q < A) {
-                    av[q] = (uint8_t)ring_action(r, t, b, i0 + q);
-                    rv[q] = ring_reward(r, t, b, i0 + q);
+                    av[q] = (uint8_t)ring_action<REC>(r, t, b, i0 + q);
+                    rv[q] = ring_reward<REC>(r, t, b, i0 + q);
                 }
 #pragma unroll
             for (int q = 0; q < 8; q++)
@@ -1634,6 +1641,7 @@ __device__ __forceinline__ void ring_copy_state(uint8_t *d0, uint8_t *d1, const 
         if (d1) d1[c] = v;
     }
 }
+template <bool REC>
 __global__ __launch_bounds__(64) void k_ring_append_tile(RingArgs r) {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x, Tw = r.io.trajectory_size, S = r.S, A = r.A, NI = r.n_imp;
@@ -1662,15 +1670,15 @@ __global__ __launch_bounds__(64) void k_ring_append_tile(RingArgs r) {
 
     // ---- phase A: every global load of the tile, then the LDS stores
     uint32_t dn = 0, tr = 0;
-    if (live) { dn = ring_done(r, t, b); tr = ring_trunc(r, t, b); }
+    if (live) { dn = ring_done<REC>(r, t, b); tr = ring_trunc<REC>(r, t, b); }
     const bool ended = (dn | tr) != 0u;
     // the Tw ticks ahead of the tile: lane = du * TE + db' for du < Tw (Tw * TE <= 64: checked on the host)
     const int du = lane >> le;
     const int64_t u_pre = t0 - Tw + du;
     const bool pre = du < Tw && b < r.B;
     uint32_t pre_flag = 0;
-    if (pre && u_pre >= 0) pre_flag = ring_done(r, u_pre, b) | ring_trunc(r, u_pre, b);
-    const uint8_t *sp[3] = {live ? ring_state(r, t, b) : nullptr, pre ? ring_state(r, u_pre, b) : nullptr,
+    if (pre && u_pre >= 0) pre_flag = ring_done<REC>(r, u_pre, b) | ring_trunc<REC>(r, u_pre, b);
+    const uint8_t *sp[3] = {live ? ring_state<REC>(r, t, b) : nullptr, pre ? ring_state<REC>(r, u_pre, b) : nullptr,
                             live && ended ? r.io.term_obs + ((size_t)t * r.B + b) * S : nullptr};
     uint8_t *own_slot = src_img + (size_t)((dt + Tw) * TE + db) * S, *pre_slot = src_img + (size_t)(du * TE + db) * S, *last = my_nx + (size_t)(Tw - 1) * S;
     for (int c0 = 0; c0 < S; c0 += 4 * kRingChunk) {
@@ -1721,8 +1729,8 @@ __global__ __launch_bounds__(64) void k_ring_append_tile(RingArgs r) {
 #pragma unroll
             for (int q = 0; q < 8; q++)
                 if (i0 + q < A) {
-                    av[q] = (uint8_t)ring_action(r, t, b, i0 + q);
-                    rv[q] = ring_reward(r, t, b, i0 + q);
+                    av[q] = (uint8_t)ring_action<REC>(r, t, b, i0 + q);
+                    rv[q] = ring_reward<REC>(r, t, b, i0 + q);
                 }
 #pragma unroll
             for (int q = 0; q < 8; q++)
@@ -1835,6 +1843,7 @@ __global__ __launch_bounds__(64) void k_ring_append_tile(RingArgs r) {
     }
 }
 // the carried window of every env after the launch: the window before the tick that follows the last one
+template <bool REC>
 __global__ __launch_bounds__(64) void k_ring_window(RingArgs r) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= r.B) return;
@@ -1842,7 +1851,7 @@ __global__ __launch_bounds__(64) void k_ring_window(RingArgs r) {
     const int64_t t = r.io.n_ticks;
     int64_t e = -(1ll << 62);
     for (int64_t u = t - 1; u >= 0 && u > t - 1 - Tw; u--)
-        if (ring_done(r, u, b) | ring_trunc(r, u, b)) { e = u; break; }
+        if (ring_done<REC>(r, u, b) | ring_trunc<REC>(r, u, b)) { e = u; break; }
     // in place, slots ascending: slot k of the new window comes from obs, or (launches shorter than the window) from slot
     // k + t > k of the old one, which has not been overwritten yet
     // (a group's loads are all issued before its first store, as in k_ring_append: a slot read from the old window lies above every slot
@@ -1857,7 +1866,7 @@ __global__ __launch_bounds__(64) void k_ring_window(RingArgs r) {
                 if (k0 + g >= Tw) break;
                 int64_t u = t - Tw + k0 + g;
                 if (u < e) u = e;
-                const uint8_t *src = ring_state(r, u, b) + c0;
+                const uint8_t *src = ring_state<REC>(r, u, b) + c0;
 #pragma unroll
                 for (int q = 0; q < kRingChunk; q++)
                     if (c0 + 4 * q + 4 <= S) __builtin_memcpy(&v[g][q], src + 4 * q, 4);
@@ -1942,15 +1951,18 @@ extern "C" int susnet_ring_append(susnet_env *env, const susnet_ring_io *io, voi
         r.tile_log2e = te == 8 ? 3 : te == 16 ? 4 : 5;
         const int64_t t_first = r.n0 / r.B, tiles_t = (io->n_ticks - t_first + 64 / te - 1) / (64 / te), tiles_b = (r.B + te - 1) / te;
         if (tiles_t * tiles_b > 0x7fffffffll) return fail(SUSNET_E_INVALID, "susnet_ring_append: too many tiles for one launch");
-        hipLaunchKernelGGL(k_ring_append_tile, dim3((unsigned)(tiles_t * tiles_b)), dim3(64), tile_lds, st, r);
+        if (from_records) hipLaunchKernelGGL(k_ring_append_tile<true>, dim3((unsigned)(tiles_t * tiles_b)), dim3(64), tile_lds, st, r);
+        else hipLaunchKernelGGL(k_ring_append_tile<false>, dim3((unsigned)(tiles_t * tiles_b)), dim3(64), tile_lds, st, r);
     } else {
         while (r.rows_per_wave > 8 && images((size_t)r.rows_per_wave) > 64 * 1024) r.rows_per_wave /= 2;
         const size_t sh = images((size_t)r.rows_per_wave);
         if (sh > 64 * 1024) return fail(SUSNET_E_INVALID, "susnet_ring_append: trajectory_size x state size too large (8 rows of the window exceed 64 KiB)");
         const int64_t waves = (r.n1 - r.n0 + r.rows_per_wave - 1) / r.rows_per_wave;
-        hipLaunchKernelGGL(k_ring_append, dim3((unsigned)waves), dim3(64), sh, st, r);
+        if (from_records) hipLaunchKernelGGL(k_ring_append<true>, dim3((unsigned)waves), dim3(64), sh, st, r);
+        else hipLaunchKernelGGL(k_ring_append<false>, dim3((unsigned)waves), dim3(64), sh, st, r);
     }
-    hipLaunchKernelGGL(k_ring_window, dim3((unsigned)((r.B + 63) / 64)), dim3(64), 0, st, r);
+    if (from_records) hipLaunchKernelGGL(k_ring_window<true>, dim3((unsigned)((r.B + 63) / 64)), dim3(64), 0, st, r);
+    else hipLaunchKernelGGL(k_ring_window<false>, dim3((unsigned)((r.B + 63) / 64)), dim3(64), 0, st, r);
     HIP_TRY(hipGetLastError());
     return SUSNET_OK;
 }

@@ -5,6 +5,7 @@ and by tests/test_capi_abi.py:
   * store_data_hazards(): no vector write into the data registers of a > 64-bit store within two wait states (a gfx950
     hazard the compiler only guards when the store's scalar-offset field is a constant: see BufDst::st128);
   * scratch_instructions(): no scratch (private memory) traffic;
+  * parked_under_divergence(): in the kernels at the register limit (k_qnet*), no value parked in an accumulator register inside a divergent region;
   * collect(): per kernel the ELF notes (`llvm-readelf --notes`: vgpr / agpr / sgpr counts, spill counts, private segment,
     static LDS) and disassembly statistics (`llvm-objdump -d`: static instruction count; `v_readlane` / `v_writelane` = SGPR
     spills to vector lanes, `v_accvgpr_*` = VGPR spills to accumulation registers, `scratch_*` = memory);
@@ -114,7 +115,7 @@ def parse_disasm(obj: str, asm: str | None = None):
         op = ins.split()[0]
         cur["instructions"] += 1
         if len(body) > 1:  # "// 000000001234: AABBCCDD EEFF0011"
-            enc = body[1].split(":")[-1].split()
+            enc = [w for w in body[1].split(":")[-1].split() if re.fullmatch(r"[0-9A-Fa-f]{8}", w)]  # (a branch line ends in "<symbol+0x..>")
             cur["code_bytes"] += 4 * len(enc)
         if op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
             cur["v_readlane"] += op.startswith("v_readlane")
@@ -192,6 +193,85 @@ def store_data_hazards(asm, window=2):
     return bad
 
 
+EXEC_NARROWING = ("s_and_saveexec_b64", "s_andn2_saveexec_b64", "s_or_saveexec_b64", "s_xor_saveexec_b64")
+
+
+def parked_under_divergence(asm, kernels=("k_qnet",)):
+    """`v_accvgpr_write` that may execute under a narrowed EXEC, in the kernels that run at the register limit.
+
+    There the register allocator parks long-lived values in accumulator registers around the matrix section.  A parking move it places inside a
+    divergent region executes under that region's EXEC: the lanes outside keep whatever the accumulator held, and read it back as the value later
+    (measured: the row index of k_qnet_step's Q-row store, parked inside `if (b + 32 < B)`; the last, partial wave of a batch stored through a wild
+    pointer).  The Q-network code is written without divergent branches for that reason; this check keeps it so.
+    Method: the kernel's control-flow graph from the branch offsets; forward data flow of "EXEC may be narrowed" (set by s_*_saveexec_b64 and by
+    and / andn2 / xor into exec, cleared by `s_or_b64 exec, exec, ...` and `s_mov_b64 exec, ...`; union over predecessors).  An inner region's end
+    clears the flag although an outer one may still be open: the check can miss, not false-alarm on straight code.
+    Validated against: AMD clang 22.0.0git (ROCm 7.2.0)."""
+    bad = []
+    cur, ins = None, []
+
+    def finish():
+        if cur is None or not ins:
+            return
+        addr_to_idx = {a: i for i, (a, _, _) in enumerate(ins)}
+        n = len(ins)
+        succ = [[] for _ in range(n)]
+        for i, (a, size, text) in enumerate(ins):
+            op = text.split()[0]
+            nxt = a + size
+            if op in ("s_endpgm", "s_setpc_b64"):
+                continue
+            if op == "s_branch" or op.startswith("s_cbranch"):
+                off = int(text.split()[-1])
+                if off >= 0x8000:
+                    off -= 0x10000
+                t = addr_to_idx.get(nxt + 4 * off)
+                if t is not None:
+                    succ[i].append(t)
+                if op == "s_branch":
+                    continue
+            if i + 1 < n:
+                succ[i].append(i + 1)
+        state_in = [None] * n  # None: not reached yet
+        state_in[0] = False
+        work = [0]
+        while work:
+            i = work.pop()
+            st = state_in[i]
+            text = ins[i][2]
+            op = text.split()[0]
+            ops = text.split(None, 1)[1].replace(" ", "") if " " in text else ""
+            if op in EXEC_NARROWING or (op in ("s_and_b64", "s_andn2_b64", "s_xor_b64") and ops.startswith("exec,")):
+                st = True
+            elif op in ("s_or_b64", "s_mov_b64") and ops.startswith("exec,"):
+                st = False
+            for t in succ[i]:
+                new = st if state_in[t] is None else (state_in[t] or st)
+                if new != state_in[t]:
+                    state_in[t] = new
+                    work.append(t)
+        for i, (_, _, text) in enumerate(ins):
+            if state_in[i] and text.startswith("v_accvgpr_write_b32"):
+                bad.append((cur, text))
+
+    for ln in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", ln)
+        if m:
+            finish()
+            cur, ins = (m.group(1) if any(k in m.group(1) for k in kernels) else None), []
+            continue
+        if cur is None or "\t" not in ln or "//" not in ln:
+            continue
+        text, tail = ln.split("//", 1)
+        text = text.strip()
+        mm = re.match(r"\s*([0-9A-Fa-f]+):\s*(.*)$", tail)
+        if not text or not mm:
+            continue
+        ins.append((int(mm.group(1), 16), 4 * sum(1 for w in mm.group(2).split() if re.fullmatch(r"[0-9A-Fa-f]{8}", w)), text))  # (a branch line ends in "<symbol+0x..>")
+    finish()
+    return bad
+
+
 def scratch_instructions(asm):
     return [ln.strip() for ln in asm.splitlines() if re.search(r"\bscratch_", ln.split("//")[0])]
 
@@ -229,6 +309,9 @@ def _analyse(obj: str):
     hz = store_data_hazards(asm)
     if hz:
         problems.append(f"{os.path.basename(obj)}: {len(hz)} wide-store data hazards, e.g. {hz[:2]}")
+    pk = parked_under_divergence(asm)
+    if pk:
+        problems.append(f"{os.path.basename(obj)}: {len(pk)} accumulator-register parking moves inside divergent regions, e.g. {pk[:2]}")
     sc = scratch_instructions(asm)
     if sc:
         problems.append(f"{os.path.basename(obj)}: {len(sc)} scratch instructions, e.g. {sc[:2]}")

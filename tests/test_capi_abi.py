@@ -295,6 +295,23 @@ def test_store_data_hazard_checker_flags_the_measured_case(isa):
     assert isa.scratch_instructions("\tscratch_load_dword v1, off, s32\n\tv_mov_b32 v0, v1") == ["scratch_load_dword v1, off, s32"]
 
 
+def test_parking_move_checker_flags_the_measured_case(isa):
+    """The register allocator's parking move inside a divergent region (k_qnet_step, round 4: the row index of the Q-row store parked in an
+    accumulator register under `if (b + 32 < B)`): flagged inside the region, not after the region's end, and only in the named kernels."""
+    body = [
+        "\ts_and_saveexec_b64 s[12:13], s[4:5]                       // 000000001000: BE8C2104",
+        "\ts_cbranch_execz 2                                          // 000000001004: BF880002 <k+0x10>",
+        "\tglobal_load_ushort v5, v[0:1], off offset:64              // 000000001008: DC488040 057F0000",
+        "\tv_accvgpr_write_b32 a207, v11                             // 000000001010: D3D940CF 1800010B",
+        "\ts_or_b64 exec, exec, s[12:13]                             // 000000001018: 87FE0C7E",
+        "\tv_accvgpr_write_b32 a205, v10                             // 00000000101C: D3D940CD 1800010A",
+        "\ts_endpgm                                                   // 000000001024: BF810000",
+    ]
+    asm = "\n".join(["0000000000001000 <_ZN6susnet11k_qnet_stepINS_7FlatRowILi1ELi2ELi9EEEEEvNS_9QStepArgsE>:"] + body)
+    assert [b[1] for b in isa.parked_under_divergence(asm)] == ["v_accvgpr_write_b32 a207, v11"]
+    assert isa.parked_under_divergence(asm.replace("k_qnet_step", "k_rollout")) == []
+
+
 def test_build_rejects_a_library_that_fails_the_isa_checks(pkg, isa, tmp_path, monkeypatch):
     """build_hip.verify(): a library with a problem is moved aside and the build raises."""
     import shutil

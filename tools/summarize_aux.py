@@ -25,8 +25,9 @@ def main():
     out = {}
     for work in ("featurize", "ring"):
         base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}", work)
-        traces = glob.glob(os.path.join(base, "stats", "**", "*kernel_trace.csv"), recursive=True)
-        pmcs = glob.glob(os.path.join(base, "pmc_WRITE_SIZE", "**", "*counter_collection.csv"), recursive=True)
+        # (gpurun MERGES a call's files into the local gpurun_out/: earlier sessions' files of the same pass may still lie there -- newest only)
+        traces = sorted(glob.glob(os.path.join(base, "stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]
+        pmcs = sorted(glob.glob(os.path.join(base, "pmc_WRITE_SIZE", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
         if not traces:
             continue
         # the i-th dispatch of a kernel is the same launch in both runs (same script, same order): pair them, then group a kernel's

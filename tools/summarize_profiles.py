@@ -16,7 +16,7 @@ for cdir in sorted(glob.glob(f"{root}/*")):
     if not os.path.isdir(cdir):
         continue
     cfg = os.path.basename(cdir)
-    stats = glob.glob(f"{cdir}/stats/*/*kernel_stats.csv")
+    stats = sorted(glob.glob(f"{cdir}/stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1:]  # (newest: see the counter files below)
     if stats:
         shutil.copy(stats[0], f"profiles/{tag}_{cfg}_kernel_stats.csv")
     if not cfg.startswith(("cfg", "tag")):  # (featurize / ring / writepath_*: tools/profile_aux.sh, tools/profile_writepath.sh: kernel stats only here)
@@ -38,7 +38,8 @@ for cdir in sorted(glob.glob(f"{root}/*")):
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         dur = collections.defaultdict(list)
-        for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+        # (gpurun MERGES a call's files into the local gpurun_out/: an earlier session's files of the same pass may still lie there -- newest only)
+        for f in sorted(glob.glob(f"{d}/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"].split("(")[0][:80]
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -47,38 +48,37 @@ for cdir in sorted(glob.glob(f"{root}/*")):
         for k, cs in agg.items():
             if not any(x in k for x in ("rollout", "k_step", "k_sample", "k_featurize", "k_ring", "k_scent", "k_observe")):
                 continue
-            out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in cs.items()}
+            out[k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v), "sum": sum(v)} for c, v in cs.items()}
             # (every counter row of a dispatch repeats its timestamps: average over dispatches, not rows)
             out[k]["avg_duration_us"] = sum(dur[k]) / len(dur[k])
-            # (the profiled command runs 33 bench steps; a step split into consecutive launches shows as a multiple of 33)
-            n = len(dur[k])
-            out[k]["launches_per_bench_step"] = n // 33 if n % 33 == 0 and n >= 33 else 1
+            # bench steps in the pass = launches that run (nearly) a whole step: the settle loop makes their number vary from run to run, and
+            # under counter collection a long step can arrive as two dispatches (tag5: 482 + 30 ticks) -- the short ones are parts, not steps
+            n_rows = len(next(iter(cs.values())))
+            dd = dur[k][::max(1, len(dur[k]) // n_rows)][:n_rows]
+            out[k]["bench_steps"] = sum(1 for x in dd if x >= 0.5 * max(dd))
+            out[k]["launches_per_bench_step"] = n_rows / out[k]["bench_steps"]
         per[os.path.basename(d)] = out
     # derived per wave-tick figures of the fused rollout kernel (SQ_* cycle counters tick in quad-cycles)
     try:
         roll = lambda grp: next(v for k, v in per[grp].items() if "k_rollout" in k)
         s1, s2 = roll("pmc_sq1"), roll("pmc_sq2")
         waves = s1["SQ_WAVES"]["mean_per_launch"]
-        # the profiled command runs 33 bench steps of 512 ticks (5 warm-up + 20 timed + 8 event-pair launches); a step whose
-        # record array would pass 2 GiB is split into consecutive launches (tag5: two), so a launch holds fewer ticks
-        launches = s1["SQ_WAVES"]["launches"]
-        ticks = 512 * 33 / launches if launches % 33 == 0 else 512
-        wt = waves * ticks
-        wc = s1["SQ_WAVE_CYCLES"]["mean_per_launch"]
+        # every bench step is 512 ticks; totals over the pass divided by the steps in it (see bench_steps above)
+        wt = waves * 512 * s1["bench_steps"]
+        wc, wc2 = s1["SQ_WAVE_CYCLES"]["sum"], None
         per["derived_per_wave_tick"] = {
-            "waves": waves, "ticks_per_launch": ticks,
-            "valu": s1["SQ_INSTS_VALU"]["mean_per_launch"] / wt, "salu": s1["SQ_INSTS_SALU"]["mean_per_launch"] / wt,
-            "lds": s1["SQ_INSTS_LDS"]["mean_per_launch"] / wt, "vmem_wr": s1["SQ_INSTS_VMEM_WR"]["mean_per_launch"] / wt,
-            "branch": s1["SQ_INSTS_BRANCH"]["mean_per_launch"] / wt, "cycles": 4.0 * wc / wt,
-            "share_active_inst_any": s2["SQ_ACTIVE_INST_ANY"]["mean_per_launch"] / wc,
-            "share_wait_any": s2["SQ_WAIT_ANY"]["mean_per_launch"] / wc,
-            "share_wait_inst_any": s2["SQ_WAIT_INST_ANY"]["mean_per_launch"] / wc,
+            "waves": waves, "bench_steps_in_pass": s1["bench_steps"], "launches_per_bench_step": s1["launches_per_bench_step"],
+            "valu": s1["SQ_INSTS_VALU"]["sum"] / wt, "salu": s1["SQ_INSTS_SALU"]["sum"] / wt,
+            "lds": s1["SQ_INSTS_LDS"]["sum"] / wt, "vmem_wr": s1["SQ_INSTS_VMEM_WR"]["sum"] / wt,
+            "branch": s1["SQ_INSTS_BRANCH"]["sum"] / wt, "cycles": 4.0 * wc / wt,
+            # (second pass: shares of ITS wave cycles ~ the first pass's scaled by the steps of each)
+            "share_active_inst_any": s2["SQ_ACTIVE_INST_ANY"]["sum"] / s2["bench_steps"] / (wc / s1["bench_steps"]),
+            "share_wait_any": s2["SQ_WAIT_ANY"]["sum"] / s2["bench_steps"] / (wc / s1["bench_steps"]),
+            "share_wait_inst_any": s2["SQ_WAIT_INST_ANY"]["sum"] / s2["bench_steps"] / (wc / s1["bench_steps"]),
         }
-        w = roll("pmc_WRITE_SIZE")["WRITE_SIZE"]["mean_per_launch"]
-        f = roll("pmc_FETCH_SIZE")["FETCH_SIZE"]["mean_per_launch"]
-        per["traffic_bytes_per_launch"] = (w + 2.0 * f) * 1024.0
-        # (a bench step whose record array would pass 2 GiB runs as consecutive launches: tag5 takes two)
-        per["traffic_bytes_per_bench_step"] = per["traffic_bytes_per_launch"] * roll("pmc_WRITE_SIZE").get("launches_per_bench_step", 1)
+        rw, rf = roll("pmc_WRITE_SIZE"), roll("pmc_FETCH_SIZE")
+        per["traffic_bytes_per_bench_step"] = (rw["WRITE_SIZE"]["sum"] / rw["bench_steps"] + 2.0 * rf["FETCH_SIZE"]["sum"] / rf["bench_steps"]) * 1024.0
+        per["traffic_bytes_per_launch"] = per["traffic_bytes_per_bench_step"] / rw["launches_per_bench_step"]
     except (KeyError, StopIteration, ZeroDivisionError) as exc:
         per["derived_error"] = repr(exc)
     summary[cfg] = per
