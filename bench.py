@@ -254,6 +254,8 @@ def main():
                     "has been busy this long.  An MI355X that has been idle takes tens of milliseconds of sustained load to reach its steady clocks: 5 "
                     "warm-up launches of 0.1-0.3 ms each leave the timed region on the ramp (cfg3: 107 G with 5 warm-up launches, 118.5 G with 50 "
                     "or 400 -- same box, same binary).  Reported in the line as `settle_ms`; 0 = none")
+    ap.add_argument("--policy-block", type=int, default=64, help="cfg5: ticks per launch of the policy loop (susnet_qnet_policy_rollout: the network image and the "
+                    "launch are paid once per block; the loop runs with fixed networks, as run_game does).  0 = one launch per tick (susnet_qnet_policy_step)")
     ap.add_argument("--repeats", type=int, default=5, help="the K-launch timed region is run this many more times back to back (after the "
                     "headline measurement, which stays as it is): median / min / max of the repeats are reported in `repeats`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -318,7 +320,7 @@ def main():
             env.step(a)
         return 2 * n_ticks
 
-    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0, policy_fused=True, n_repeats=0):
+    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0, policy_fused=True, n_repeats=0, block_ticks=0):
         """W untimed + K timed bench steps of one configuration.  fused: a step is one launch of `ticks` ticks; step / policy:
         one tick (policy with graph_ticks > 0: the tick loop replayed as hipGraphs of graph_ticks ticks, K rounded up to whole graphs)."""
         oc = obs_config(obs_mode) if mode == "fused" else None
@@ -351,9 +353,9 @@ def main():
                         graph.replay()
                     return n // graph_ticks
             else:
-                def runner(n):
-                    pr.run(n)
-                    return n
+                def runner(n):  # (block_ticks > 0: that many ticks per launch where the env serves the whole tick as one kernel)
+                    pr.run(n, block_ticks=block_ticks)
+                    return n if block_ticks <= 0 else (n + block_ticks - 1) // block_ticks
         else:
             runner = (lambda n: run_fused(env, n, ticks, bufs)) if mode == "fused" else (lambda n: run_step(env, n))
         if args.settle_ms > 0:  # steady clocks first (see --settle-ms): untimed, not part of the W warm-up steps
@@ -420,9 +422,9 @@ def main():
             issued = 2.0 * B * sum(a * b for a, b in zip(pad[1:-1], pad[2:]))       # layers 2..5 at their padded widths: what the matrix core executes
             model_flops = 2.0 * B * sum(a * b for a, b in zip(net.dims[:-1], net.dims[1:]))  # the reference MLP's own multiply-adds, layer 1 included
             traffic, traffic_source = None, None
-            cpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_qnet_counters.json")
+            cpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_qnet_counters.json")
             if B == 65536 and os.path.exists(cpath):  # WRITE_SIZE + 2 x FETCH_SIZE of the same kernel on the same batch (tools/profile_cfg5.sh)
-                traffic, traffic_source = json.load(open(cpath)).get("traffic_bytes_per_launch"), "profiles/r03_qnet_counters.json"
+                traffic, traffic_source = json.load(open(cpath)).get("traffic_bytes_per_launch"), "profiles/r04_qnet_counters.json"
             alone = {"kernel": "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward), 50 launches outside the timed region", "avg_launch_us": us,
                      "achieved": issued / us / 1e6, "frac": issued / us / 1e6 / MFMA_F32_PEAK_TFLOPS, "model_tflops": model_flops / us / 1e6,
                      "traffic": traffic, "traffic_source": traffic_source}
@@ -430,7 +432,9 @@ def main():
             # the kernel of the TIMED region: with the one-kernel tick every launch there is k_qnet_step (network + argmax + crew draws + step:
             # the matrix core idles while the wave steps its environments); else the network kernel as timed alone
             tick_us = dev_ms * 1e3 / K if one else us
-            qnet = {"kernel": ("k_qnet_step<FlatRow<2,3,14>, Spec<3,4,..>> (susnet_qnet_policy_step: the whole tick, one launch per bench step)" if one
+            qnet = {"kernel": (("k_qnet_step<FlatRow<2,3,14>, Spec<3,4,..>> (susnet_qnet_policy_step: the whole tick, one launch per bench step)" if block_ticks <= 0 else
+                                f"k_qnet_step<FlatRow<2,3,14>, Spec<3,4,..>> (susnet_qnet_policy_rollout: the whole tick, {block_ticks} ticks = bench steps per launch; "
+                                "avg_launch_us is per TICK)") if one
                                else "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward)"),
                     "bound": "mfma", "avg_launch_us": tick_us, "unit": "TFLOP/s", "traffic": None if one else traffic,
                     "peak": MFMA_F32_PEAK_TFLOPS, "achieved": issued / tick_us / 1e6, "frac": issued / tick_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
@@ -451,7 +455,8 @@ def main():
     if spec.get("policy"):
         args.mode, args.obs = "policy", "flat"
     ticks_per_step = args.ticks if args.mode == "fused" else 1
-    res = measure(spec, B, args.mode, args.obs, K, W, args.ticks, args.packed, n_repeats=args.repeats if world == 1 else 0)
+    res = measure(spec, B, args.mode, args.obs, K, W, args.ticks, args.packed, n_repeats=args.repeats if world == 1 else 0,
+                  block_ticks=args.policy_block if args.mode == "policy" else 0)
     steps_per_launch = B * ticks_per_step          # env-steps one launch of the dominant kernel processes (this rank)
     total_steps = steps_per_launch * world * K
     value = total_steps / res["seconds"]
@@ -487,7 +492,10 @@ def main():
     if args.mode == "policy":  # the tick's dominant kernel is the Q-network: its roofline is the f32 matrix peak
         line["roofline"] = dict(res["qnet"])
         line["dtype"] = "f32"
-        line["config"]["policy_forward"] = "susnet_qnet_policy_step: the whole tick -- Q-network (float32, f32-input MFMA), argmax, crew draws, env step -- as one HIP kernel"
+        line["config"]["policy_forward"] = ("the whole tick -- Q-network (float32, f32-input MFMA), argmax, crew draws, env step -- as one HIP kernel; "
+                                            + (f"{args.policy_block} ticks per launch (susnet_qnet_policy_rollout)" if args.policy_block > 0 else
+                                               "one launch per tick (susnet_qnet_policy_step)"))
+        line["config"]["ticks_per_launch"] = max(1, args.policy_block)
     del res
     secondary = rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy"
     if secondary:

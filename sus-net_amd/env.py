@@ -724,6 +724,19 @@ class BatchedFourRoomEnv:
                                                         len(net_imposter.dims), net_imposter.packed.data_ptr(), self._policy_opts(epsilon, mask_dead),
                                                         C.byref(io), int(n_ticks), self._stream()))
 
+    def policy_block(self, n_ticks: int, net_imposter: "PackedQNet", epsilon: float = 0.0, mask_dead: bool = False) -> None:
+        """``n_ticks`` ticks of the acting loop in ONE launch with nothing kept but the state and the episode metrics: ``run_game``'s loop with
+        fixed networks (visualize.py:547-582), i.e. ``policy_rollout_into`` without a feed.  The fused observation (``env.obs``) is refreshed
+        once, after the block."""
+        assert self.auto_reset and self.supports_qnet_policy_step(net_imposter) and n_ticks >= 1
+        io = L.FeedIO()
+        with self._on_device():
+            L.check(self.lib.susnet_qnet_policy_rollout(self._h, net_imposter.components, len(net_imposter.components), net_imposter.cdims,
+                                                        len(net_imposter.dims), net_imposter.packed.data_ptr(), self._policy_opts(epsilon, mask_dead),
+                                                        C.byref(io), int(n_ticks), self._stream()))
+            if self._obs_spec is not None:
+                L.check(self.lib.susnet_observe(self._h, C.byref(self._obs_spec), self._stream()))
+
     def step4(self, agent_actions):
         """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""
         state, rew, done, trunc, info = self.step(agent_actions)

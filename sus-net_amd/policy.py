@@ -278,8 +278,19 @@ class PolicyRollout:
         return env.policy_actions(q_imp, q_crew, out=self._actions, epsilon=self.epsilon, mask_dead=self.mask_dead)
 
     @torch.no_grad()
-    def run(self, n_steps: int, record: bool = False) -> Dict[str, torch.Tensor]:
+    def run(self, n_steps: int, record: bool = False, block_ticks: int = 64) -> Dict[str, torch.Tensor]:
+        """``n_steps`` ticks of the acting loop with the networks as they are (``run_game``, visualize.py:547-582).  Where the env serves the
+        whole tick as one kernel and nothing is recorded, ``block_ticks`` ticks go into ONE launch (``susnet_qnet_policy_rollout``; 0: one
+        launch per tick)."""
         env = self.env
+        if self.one_kernel_tick and not record and block_ticks > 0 and env.auto_reset:
+            self.refresh_weights(force=False)
+            left = int(n_steps)
+            while left > 0:
+                n = min(left, int(block_ticks))
+                env.policy_block(n, self.fused_imposter, epsilon=self.epsilon, mask_dead=self.mask_dead)
+                left -= n
+            return {}
         out: Dict[str, List[torch.Tensor]] = {"actions": [], "rewards": [], "done": [], "truncated": []}
         for _ in range(n_steps):
             a, rew, done, trunc = self.tick()

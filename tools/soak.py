@@ -13,7 +13,9 @@ from oracle import oracle as om  # noqa: E402
 import test_gpu_parity as T  # noqa: E402
 
 om.build()
-for name in ("itg_1v1_nowalls", "base_1v2_j4_14", "tagging_1v4_j5", "base_2v6_j4_14"):
+NAMES = sys.argv[1:] or ["itg_1v1_nowalls", "base_1v2_j4_14", "tagging_1v4_j5", "base_2v6_j4_14",
+                         "tagging_2v6_j4_14", "itg_1v5_j3"]  # (the last two: byte-parallel FAMILY kernels -- run-time job count, roles drawn per episode)
+for name in NAMES:
     B, seed = 1536, 5
     spec = dict(T.CONFIGS[name])
     env, ob = T.make_pair(pkg, om, name, B, seed, auto_reset=True, check_errors=False)
