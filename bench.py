@@ -548,11 +548,14 @@ def main():
             sp = CONFIGS[name]
             if sp.get("policy"):
                 entry = {"config": name, "workload": sp["workload"], "unit": "env-steps/s"}
-                for label, gt, fused in (("eager", 0, True), ("hip_graph_replay", 8, True), ("torch_modules_hip_graph_replay", 8, False)):
-                    rp = measure(sp, sp["batch"], "policy", "flat", 64, 16, 1, graph_ticks=gt, policy_fused=fused)
+                # one launch per tick (eager, and replayed as hipGraphs of 8 ticks), the torch-module network as the comparison, and the
+                # loop as bench.py --config cfg5 times it: 64 ticks per launch (run_game's loop runs with fixed networks)
+                for label, gt, fused, blk in (("eager", 0, True, 0), ("hip_graph_replay", 8, True, 0), ("torch_modules_hip_graph_replay", 8, False, 0),
+                                              ("blocks_of_64_ticks", 0, True, 64)):
+                    rp = measure(sp, sp["batch"], "policy", "flat", 256 if blk else 64, 64 if blk else 16, 1, graph_ticks=gt, policy_fused=fused, block_ticks=blk)
                     entry[label] = {"value": sp["batch"] * rp["steps"] / rp["seconds"], "us_per_tick": rp["seconds"] * 1e6 / rp["steps"],
-                                    "ticks_timed": rp["steps"], **({"ticks_per_graph": gt} if gt else {})}
-                    if rp["qnet"] is not None:
+                                    "ticks_timed": rp["steps"], **({"ticks_per_graph": gt} if gt else {}), **({"ticks_per_launch": blk} if blk else {})}
+                    if rp["qnet"] is not None and (blk or "roofline" not in entry):
                         entry["roofline"] = rp["qnet"]
                     del rp
                 # the trainer's collection loop on the same env: the one-kernel tick writing the replay feed + one susnet_ring_append per
@@ -586,15 +589,16 @@ def main():
                     b1e.record(torch.cuda.current_stream(device))
                     torch.cuda.synchronize(device)
                     us_tick = b0e.elapsed_time(b1e) * 1e3 / (4 * 64)
-                    entry["block_in_one_launch"] = {"value": sp["batch"] / (us_tick * 1e-6), "unit": "env-steps/s", "us_per_tick": us_tick, "ticks_per_launch": 64,
+                    entry["block_with_replay_feed"] = {"value": sp["batch"] / (us_tick * 1e-6), "unit": "env-steps/s", "us_per_tick": us_tick, "ticks_per_launch": 64,
                                                     "launches_timed": 4, "epsilon": 0.1,
                                                     "note": "susnet_qnet_policy_rollout: k_qnet_step looping over 64 ticks per launch, replay feed written"}
                     del feed
                 del envc, polc, ring
                 # the loop as the trainer runs it between two optimizer steps (fixed weights): the block launch where the env serves it
-                best = max(("eager", "hip_graph_replay", "block_in_one_launch"), key=lambda k: entry.get(k, {}).get("value", 0.0))
+                best = max(("eager", "hip_graph_replay", "blocks_of_64_ticks"), key=lambda k: entry.get(k, {}).get("value", 0.0))
                 entry["value"], entry["value_from"] = entry[best]["value"], best
-                entry["kernel"] = "k_qnet_step (susnet_qnet_policy_step: float32 Q-network on the f32-input MFMA, argmax, crew draws and the env step: the whole tick in one launch)"
+                entry["kernel"] = ("k_qnet_step (float32 Q-network on the f32-input MFMA, argmax, crew draws and the env step as one kernel: one launch per tick -- "
+                                   "susnet_qnet_policy_step -- or 64 ticks per launch -- susnet_qnet_policy_rollout)")
                 entry["torch_modules_hip_graph_replay"]["note"] = ("the same tick with the network as torch modules (hipBLASLt f32 GEMMs + PReLU kernels on "
                                                                    "the [B][88] observation): round 2's path, kept as the comparison")
                 line["other_configs"].append(entry)
@@ -615,7 +619,7 @@ def main():
     if "other_configs" in line:  # the same numbers in a compact top-level key (the long entries above get truncated in driver records)
         line["others"] = {e["config"]: {"value": e["value"], "frac": (e.get("frac") if "frac" in e else e.get("roofline", {}).get("frac")),
                                         **({"collect_transitions_per_s": e["collect_into_replay_ring"]["value"]} if "collect_into_replay_ring" in e else {}),
-                                        **({"block_us_per_tick": e["block_in_one_launch"]["us_per_tick"]} if "block_in_one_launch" in e else {})}
+                                        **({"us_per_tick": e["blocks_of_64_ticks"]["us_per_tick"], "launch_per_tick_us": e["eager"]["us_per_tick"]} if "blocks_of_64_ticks" in e else {})}
                           for e in line["other_configs"]}
     if world > 1:
         dist.barrier()  # the timed region and its collectives are over on every rank before rank 0 spends host time below
