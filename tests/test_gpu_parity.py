@@ -767,6 +767,51 @@ def test_two_lanes_per_env_rollout_equals_the_one_lane_kernel(pkg, oracle_mod, m
         np.testing.assert_array_equal(f["obs"][s], ob.obs_raw_u8(), err_msg=f"raw obs tick {s}")
 
 
+@pytest.mark.parametrize("name,obs", [("itg_1v5_j3", "flat"), ("base_2v6_j4_14", "flat"), ("base_2v6_j4_14", "planes"), ("tagging_2v6_j4_14", "planes"),
+                                      ("tagging_1v4_j5", "planes")])
+def test_fused_rollout_with_float_observations_matches_oracle(pkg, oracle_mod, name, obs):
+    """The OUT_ANY instantiations of the byte-parallel rollouts (any observation mode fused in: the largest kernels of the library, the
+    8-agent ones past 256 registers with values parked in accumulator registers): a ragged last wave, many in-launch resets, the full
+    trajectory and the float observation of every tick against the oracle."""
+    B, T, seed = 64 * 9 + 23, 90, 13
+    short = name + "@20"  # (episodes of at most 20 steps: every environment resets several times inside the launch)
+    CONFIGS[short] = dict(CONFIGS[name], kw=dict(CONFIGS[name]["kw"], max_time_steps=20))
+    try:
+        env, ob = make_pair(pkg, oracle_mod, short, B, seed, auto_reset=True, check_errors=False)
+    finally:
+        del CONFIGS[short]
+    env.reset()
+    ob.reset()
+    comps = ["onehot_pos", "alive_crew", "coord_pos"]
+    cfg = pkg.ObsConfig("flat", comps) if obs == "flat" else pkg.ObsConfig("planes")
+    ended = 0
+    for n in (T, 7):  # (a second, short launch: starts mid-stream)
+        traj = env.rollout(n, obs=cfg)
+        torch.cuda.synchronize()
+        got = traj["obs"] if not isinstance(traj["obs"], (tuple, list)) else traj["obs"][0]
+        got2 = traj["obs"][1] if isinstance(traj["obs"], (tuple, list)) else traj.get("obs_non_spatial")
+        for s in range(n):
+            oa = ob.sample_actions()
+            np.testing.assert_array_equal(np_(traj["actions"])[s], oa, err_msg=f"{name} actions tick {s}")
+            orew, odone, otrunc, _ = ob.step(oa)
+            assert np.array_equal(np_(traj["rewards"])[s].astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} rewards tick {s}"
+            np.testing.assert_array_equal(np_(traj["done"])[s], odone.astype(bool))
+            np.testing.assert_array_equal(np_(traj["truncated"])[s], otrunc.astype(bool))
+            e = (odone | otrunc).astype(bool)
+            ended += int(e.sum())
+            ob.reset(mask=e)
+            if obs == "flat":
+                assert np_(got[s]).view(np.uint32).tolist() == ob.obs_flat(comps).view(np.uint32).tolist(), f"{name} flat obs tick {s}"
+            else:
+                wsp, wnon = ob.obs_planes()
+                np.testing.assert_array_equal(np_(got[s]), wsp, err_msg=f"{name} planes tick {s}")
+                if got2 is not None:
+                    np.testing.assert_array_equal(np_(got2[s]), wnon, err_msg=f"{name} non-spatial tick {s}")
+    assert ended > B // 4, "the launches must cross episode ends"
+    env._export(full=True)
+    compare_full_state(env, ob, f"{name} after the float-observation rollouts")
+
+
 # ------------------------------------------------------------------------------------------------
 # observations
 # ------------------------------------------------------------------------------------------------
