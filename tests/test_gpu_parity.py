@@ -1742,11 +1742,13 @@ def test_policy_block_in_one_launch_equals_one_launch_per_tick(pkg, oracle_mod, 
     assert torch.equal(fa["actions"][:7], fb["actions"][:7]) and torch.equal(fa["obs"][:7], fb["obs"][:7])
 
 
-def test_policy_rollout_run_in_blocks_equals_tick_by_tick(pkg, oracle_mod):
+@pytest.mark.parametrize("B", [16 * 53, 65536], ids=["848-envs", "bench-size"])
+def test_policy_rollout_run_in_blocks_equals_tick_by_tick(pkg, oracle_mod, B):
     """`PolicyRollout.run` with the ticks of a block in ONE launch (env.policy_block: susnet_qnet_policy_rollout without a feed) against one
-    launch per tick on a twin: the state, the refreshed fused observation, the step counter and the episode metrics afterwards."""
+    launch per tick on a twin: the state, the refreshed fused observation, the step counter and the episode metrics afterwards.  At the
+    bench's batch every SIMD holds a wave that re-reads, tick after tick, what it stored the tick before (wavefront-scope fences only)."""
     comps = ["onehot_pos", "alive_crew", "closest_crew"]
-    mk = lambda: make_pair(pkg, oracle_mod, "base_1v2_j4_14", 16 * 53, 9, auto_reset=True, check_errors=False, max_time_steps=15,
+    mk = lambda: make_pair(pkg, oracle_mod, "base_1v2_j4_14", B, 9, auto_reset=True, check_errors=False, max_time_steps=15,
                            obs=pkg.ObsConfig("flat", comps))[0]
     env, twin = mk(), mk()
     model = pkg.policy.reference_imposter_mlp(env, comps, seed=4)
@@ -1759,7 +1761,7 @@ def test_policy_rollout_run_in_blocks_equals_tick_by_tick(pkg, oracle_mod):
     raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
     assert torch.equal(env.observe(raw8), twin.observe(raw8)) and torch.equal(env.obs, twin.obs)
     assert int(env.tick) == int(twin.tick) == 45 and torch.equal(env.episode_index(), twin.episode_index())
-    assert np.array_equal(np_(env.lifetime_totals()), np_(twin.lifetime_totals())) and int(env.lifetime_totals()[0]) > 16 * 53
+    assert np.array_equal(np_(env.lifetime_totals()), np_(twin.lifetime_totals())) and int(env.lifetime_totals()[0]) > B
 
 
 @pytest.mark.parametrize("game,T,tile", [("base_1v2", 3, None), ("base_1v2", 3, "tile=8"),
