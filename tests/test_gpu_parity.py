@@ -812,6 +812,56 @@ def test_fused_rollout_with_float_observations_matches_oracle(pkg, oracle_mod, n
     compare_full_state(env, ob, f"{name} after the float-observation rollouts")
 
 
+@pytest.mark.parametrize("cls", ["base", "itg", "tagging"])
+@pytest.mark.parametrize("A", [3, 4, 5, 6, 7, 8])
+def test_family_sweep_matches_oracle(pkg, oracle_mod, cls, A):
+    """The byte-parallel FAMILY instantiations (susnet_family.h: 3..8 agents x {FourRoomEnv, ImposterTrainingGround, tagging} x action order x
+    1..2 imposters, job count and role shuffle at run time), each through BOTH trajectory layouts -- packed records and separate tensors with
+    the raw observation -- against the oracle: job counts 0 / 3 / 8, fixed and shuffled roles, a ragged last wave, 12-step episodes."""
+    B, T, n_cases = 64 * 2 + 3, 36, 0
+    raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
+    for n_imp in ((1,) if cls == "itg" else (1, 2)):
+        if A - n_imp <= (0 if cls == "itg" else n_imp):  # (base.py:243-249: more crew members than imposters)
+            continue
+        for J in (0, 3, 8):
+            for order_random in ((False,) if cls == "itg" else (True, False)):
+                for shuffle in (False, True):
+                    kw = dict(n_crew=A - n_imp, n_jobs=J, max_time_steps=12, shuffle_imposter_index=shuffle)
+                    if cls == "itg":
+                        kw.update(kill_reward=-3, sabotage_reward=1, end_of_game_reward=5, time_step_reward=-1)
+                    else:
+                        kw.update(n_imposters=n_imp, is_action_order_random=order_random)
+                    if cls == "tagging":
+                        kw.update(tag_reset_interval=5)
+                    name = f"sweep {cls} {n_imp}v{A - n_imp} j{J} order{int(order_random)} shuffle{int(shuffle)}"
+                    CONFIGS[name] = dict(cls=cls, kw=kw, n=9)
+                    try:
+                        for packed in (True, False):
+                            env, ob = make_pair(pkg, oracle_mod, name, B, 40 + J, auto_reset=True, check_errors=False)
+                            if packed and env.record_layout() is None:
+                                continue
+                            env.reset()
+                            ob.reset()
+                            traj = env.rollout(T, obs=raw8, packed=packed)
+                            torch.cuda.synchronize()
+                            acts, rews, dones, truncs, obs = (np_(traj[k]) for k in ("actions", "rewards", "done", "truncated", "obs"))
+                            for s_ in range(T):
+                                oa = ob.sample_actions()
+                                assert np.array_equal(acts[s_], oa), f"{name} packed={packed} actions tick {s_}"
+                                orew, odone, otrunc, _ = ob.step(oa)
+                                assert np.array_equal(rews[s_].astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} packed={packed} rewards tick {s_}"
+                                assert np.array_equal(dones[s_], odone.astype(bool)) and np.array_equal(truncs[s_], otrunc.astype(bool)), f"{name} flags tick {s_}"
+                                ob.reset(mask=(odone | otrunc).astype(bool))
+                                assert np.array_equal(obs[s_], ob.obs_raw_u8()), f"{name} packed={packed} raw obs tick {s_}"
+                            env._export(full=True)
+                            compare_full_state(env, ob, f"{name} packed={packed}")
+                            n_cases += 1
+                            del env, ob, traj
+                    finally:
+                        del CONFIGS[name]
+    assert n_cases >= 12
+
+
 # ------------------------------------------------------------------------------------------------
 # observations
 # ------------------------------------------------------------------------------------------------
