@@ -853,6 +853,16 @@ def test_family_sweep_matches_oracle(pkg, oracle_mod, cls, A):
                                 assert np.array_equal(dones[s_], odone.astype(bool)) and np.array_equal(truncs[s_], otrunc.astype(bool)), f"{name} flags tick {s_}"
                                 ob.reset(mask=(odone | otrunc).astype(bool))
                                 assert np.array_equal(obs[s_], ob.obs_raw_u8()), f"{name} packed={packed} raw obs tick {s_}"
+                            if not packed:  # ... then the drop-in API on the same handle (k_sample_philox + k_step of the same instantiation)
+                                for s_ in range(8):
+                                    a = env.sample_actions().clone()
+                                    oa = ob.sample_actions()
+                                    assert np.array_equal(np_(a), oa), f"{name} api actions step {s_}"
+                                    _, rew, done, trunc, _ = env.step(a)
+                                    orew, odone, otrunc, _ = ob.step(oa)
+                                    assert np.array_equal(np_(rew).astype(np.float64).view(np.uint64), orew.view(np.uint64)), f"{name} api rewards step {s_}"
+                                    assert np.array_equal(np_(done), odone.astype(bool)) and np.array_equal(np_(trunc), otrunc.astype(bool))
+                                    ob.reset(mask=(odone | otrunc).astype(bool))
                             env._export(full=True)
                             compare_full_state(env, ob, f"{name} packed={packed}")
                             n_cases += 1
