@@ -409,7 +409,7 @@ typedef struct susnet_feed_io {
     uint8_t *done;       /* out [T][B] */
     uint8_t *truncated;  /* out [T][B] */
     uint8_t *obs;        /* out [T][B][obs_raw_size] u8: the state after each tick (after the auto-reset where the episode ended); 16-byte aligned
-                          * slots (B * obs_raw_size a multiple of 16) */
+                          * slots (n_ticks > 1: B * obs_raw_size a multiple of 16, else SUSNET_E_INVALID) */
     uint8_t *term_obs;   /* out [T][B][obs_raw_size] u8, written only where an episode ended: its terminal state */
     uint16_t *roles;     /* out [T][B]: imposter bitmask of the episode that acted */
     float *q;            /* out [T][B][n_actions_imposter] f32: the imposters' Q rows, or NULL */

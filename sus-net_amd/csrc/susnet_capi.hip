@@ -1138,6 +1138,10 @@ extern "C" int susnet_qnet_policy_rollout(susnet_env *env, const int32_t *compon
         return fail(SUSNET_E_INVALID, "susnet_qnet_policy_rollout: the network's output width must be the imposters' action count");
     if (!env->c.auto_reset) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_rollout: the handle must auto-reset (episodes end inside the launch)");
     const int64_t B = env->c.B, A = env->c.A, S = env->layout.obs_raw_size;
+    // (the raw observation is stored in 16-byte pieces: every tick's slot must start on a 16-byte boundary)
+    if (feed->obs && n_ticks > 1 && (B * S) % 16 != 0)
+        return fail(env, SUSNET_E_INVALID, "susnet_qnet_policy_rollout: feed->obs holds one [B][obs_raw_size] slot per tick, each 16-byte aligned: batch x "
+                                           "obs_raw_size must be a multiple of 16 (or pass obs = NULL / one tick per call)");
     susnet_obs_spec obs;
     std::memset(&obs, 0, sizeof(obs));
     obs.mode = SUSNET_OBS_RAW;

@@ -1802,6 +1802,27 @@ def test_policy_block_in_one_launch_equals_one_launch_per_tick(pkg, oracle_mod, 
     assert torch.equal(fa["actions"][:7], fb["actions"][:7]) and torch.equal(fa["obs"][:7], fb["obs"][:7])
 
 
+def test_policy_block_rejects_unaligned_observation_slots(pkg, oracle_mod):
+    """susnet_qnet_policy_rollout writes the raw observation of every tick in 16-byte pieces: a batch whose slots would not start on
+    16-byte boundaries is refused with SUSNET_E_INVALID (one tick per call and a feed without `obs` stay available)."""
+    import ctypes as C
+
+    comps = ["onehot_pos", "alive_crew", "closest_crew"]
+    env = make_pair(pkg, oracle_mod, "base_1v2_j4_14", 5, 3, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))[0]
+    env.reset()
+    pol = pkg.PolicyRollout(env, pkg.policy.reference_imposter_mlp(env, comps, seed=1), None, components=comps)
+    L = pkg._lib if hasattr(pkg, "_lib") else __import__("importlib").import_module("sus-net_amd._lib")
+    net, feed = pol.fused_imposter, env.alloc_feed(4)
+    io = L.FeedIO()
+    io.obs = feed["obs"].data_ptr()
+    args = (env._h, net.components, len(net.components), net.cdims, len(net.dims), net.packed.data_ptr(), env._policy_opts(0.0, False), C.byref(io))
+    assert env.lib.susnet_qnet_policy_rollout(*args, 4, env._stream()) == L.E_INVALID and b"16" in env.lib.susnet_last_error()
+    assert env.lib.susnet_qnet_policy_rollout(*args, 1, env._stream()) == 0  # one tick: slot 0 only
+    env.policy_block(3, net)  # no feed at all
+    torch.cuda.synchronize()
+    assert int(env.tick) == 4
+
+
 @pytest.mark.parametrize("B", [16 * 53, 65536], ids=["848-envs", "bench-size"])
 def test_policy_rollout_run_in_blocks_equals_tick_by_tick(pkg, oracle_mod, B):
     """`PolicyRollout.run` with the ticks of a block in ONE launch (env.policy_block: susnet_qnet_policy_rollout without a feed) against one
