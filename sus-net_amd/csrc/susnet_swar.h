@@ -559,6 +559,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     for (int it = 0; it < NI; it++)
 #pragma unroll
         for (int q = 0; q < NW; q++) vk80[it][q] = gek80[it][q] = 0;
+#ifndef SUSNET_EXP_SKIP_KILL // diagnostic builds only (tools/build_variant.sh, profiles/r04_step_sections.md): a section's share of the tick -- WRONG results
     {
         const uint64_t cur0 = rng.cur; // the step's (aligned) event cursor: a landed kill takes word cur0 + kills landed before it
         uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot, in ALL four bytes: kill flag (0x80 / 0), rank | 0x80, cell
@@ -630,6 +631,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             }
         }
     }
+#endif
     // final positions: a victim that had not acted yet stays where it was
 #pragma unroll
     for (int q = 0; q < NW; q++) w.xy[q] = sel_bytes(ff_from80(pend80[q]), w.xy[q], newt[q]);
@@ -645,6 +647,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     uint32_t fc80[NW], sc80[NW];
 #pragma unroll
     for (int q = 0; q < NW; q++) fc80[q] = sc80[q] = 0;
+#ifndef SUSNET_EXP_SKIP_JOBS
     if constexpr (JM::kOn) {
         // With the cell -> job map (fused rollouts): jobat = 0x80 | j under every agent that stands on a job.  An actor standing on
         // a job is rare (a percent or two per environment), so all that follows the flag test sits behind a ballot; the job count
@@ -794,11 +797,13 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 #pragma unroll
         for (int q = 0; q < NW; q++) idx4[q] += (fc80[q] >> 4) + (sc80[q] >> 5) + (sc80[q] >> 4); // RC_FIX 2, RC_SAB 3, times 4
     }
+#endif
 
     WSTAMP(2);
     // ---- tag actions (tagging.py:103-110) and the vote (tagging.py:180-207) ------------------------------------------------------
     float team = 0.0f; // team reward: vote outcome, then the win reward (tagging.py:196, 209-213)
     bool voted_out = false; // the vote ejected somebody this step
+#ifndef SUSNET_EXP_SKIP_TAG
     if (W::kTag) {
         const uint32_t hi = NW > 1 ? NW - 1 : 0;
         uint32_t tgt[NW], vt80[NW];
@@ -887,6 +892,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             w.timer = due ? 0u : w.timer;
         }
     }
+#endif
 
     WSTAMP(3);
     // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
@@ -928,7 +934,13 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     // ---- rewards: assignments -> _merge_rewards (base.py:553-563) -> zero fill (389-390), one lookup per agent in the
     // host-evaluated table [win][index < n_imposters][dead][assignment code]; byte = 4 * table index.  idx4 started from the episode's
     // base (dead / index < n_imposters: Swar::ridx) and collected this step's assignment codes and outcome where they arose
+#ifdef SUSNET_EXP_SKIP_REWARDS
+#pragma unroll
+    for (int i = 0; i < A; i++) rr[i] = __uint_as_float(idx4[i / 4] ^ kc80[i / 4]);
+    if (false) {
+#else
     if (!W::kTag) {
+#endif
 #pragma unroll
 #ifdef SUSNET_EXP_NO_REWARD_LDS
         for (int i = 0; i < A; i++) rr[i] = (float)((idx4[i / 4] >> (8 * (i & 3))) & 0xffu);
