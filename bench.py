@@ -48,6 +48,11 @@ CONFIGS = {
     "cfg2": dict(workload="cfg2: ImposterTrainingGround 1v1, 9x9 no walls, 0 jobs (notebook rewards), batch 65536/GPU",
                  cls="itg", kw=dict(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
                                     time_step_reward=0, include_walls=False), n=9, A=2, J=0, batch=65536),
+    # the reference's own 1v1 experiments run on its four-room WALL map (include_walls=True is the constructor default, base.py:119;
+    # notebooks/experiment_1v1.ipynb envs['Wall']): cfg2 with the walls in
+    "cfg2w": dict(workload="cfg2w: ImposterTrainingGround 1v1, 9x9 four-room wall map, 0 jobs (notebook rewards), batch 65536/GPU",
+                  cls="itg", kw=dict(n_crew=1, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0,
+                                     time_step_reward=0, include_walls=True), n=9, A=2, J=0, batch=65536),
     "cfg3": dict(workload="cfg3: FourRoomEnv 1v2, 14x14 walled, 4 jobs, batch 65536/GPU",
                  cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536),
     "cfg4": dict(workload="cfg4: FourRoomEnv 2v6, 14x14 walled, 4 jobs, batch 32768/GPU",
@@ -120,7 +125,7 @@ def profiled_traffic(config, obs, packed, batch, ticks, bytes_per_step=None):
         return None, None
 
 
-KERNEL_NAMES = {"cfg2": "k_rollout_duel<PhiloxRng, OUT>", "cfg3": "k_rollout_swar<Spec<3,4,..>, OUT, PhiloxRng>",
+KERNEL_NAMES = {"cfg2": "k_rollout_duel<PhiloxRng, OUT, false>", "cfg2w": "k_rollout_duel<PhiloxRng, OUT, true>", "cfg3": "k_rollout_swar<Spec<3,4,..>, OUT, PhiloxRng>",
                 "cfg4": "k_rollout_swar2<Spec<8,4,..>, OUT, PhiloxRng>", "tag5": "k_rollout_swar<Spec<5,5,2,..>, OUT, PhiloxRng>"}
 
 
@@ -542,7 +547,7 @@ def main():
             del r3
         # the other BASELINE configurations, each measured like the headline (5 warm-up + 20 timed launches of 512 ticks)
         line["other_configs"] = []
-        for name in ("cfg3", "cfg4", "tag5", "cfg5"):
+        for name in ("cfg2w", "cfg3", "cfg4", "tag5", "cfg5"):
             if name == args.config:
                 continue
             sp = CONFIGS[name]

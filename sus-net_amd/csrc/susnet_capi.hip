@@ -615,7 +615,8 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
     }
     c.seed = cfg->seed; c.env_id_base = cfg->env_id_base;
     { // 1v1 ImposterTrainingGround on a grid without walls, every reachable reward an integer in [-127, 127]: susnet_duel.h
-        bool ok = e->float_exact && A == 2 && J == 0 && cfg->variant == SUSNET_VARIANT_ITG && !c.shuffle_imp && c.n_valid == N * N;
+        bool ok = e->float_exact && A == 2 && J == 0 && cfg->variant == SUSNET_VARIANT_ITG && !c.shuffle_imp;
+        const bool walls = c.n_valid != N * N; // a wall map: the same kernels with the bounds test replaced by the cells' blocked-move bits (DuelWallTable)
         c.duel_lut[0] = c.duel_lut[1] = 0;
         for (int idx = 0; idx < 8 && ok; idx++) {
             const int hit = idx & 1, dead0 = (idx >> 1) & 1, dead1 = (idx >> 2) & 1;
@@ -626,7 +627,8 @@ extern "C" int susnet_create(const susnet_config *cfg, susnet_env **out) {
                 else c.duel_lut[a] |= (uint64_t)(uint8_t)(int8_t)(int)r[a] << (8 * idx);
             }
         }
-        c.duel_fast = ok ? 1 : 0;
+        c.duel_fast = ok && !walls ? 1 : 0;
+        c.duel_walls = ok && walls ? 1 : 0;
     }
 
     // state blob layout (every array 256-byte aligned; row stride Bp)
@@ -799,6 +801,7 @@ static size_t lds_bytes(const susnet_env *env, const ObsArgs &o, bool may_reset,
     size_t core = (size_t)lds_core_words(c.A, c.J, spec == 0, swar, (swar && rollout) ? c.N : 0) * 4;
     size_t perm = (may_reset && env->cfg.rng_mode == SUSNET_RNG_TAPE) ? (size_t)c.n_valid * kBlock : 0;
     size_t stage = (size_t)(o.words1 + o.words2) * 4;
+    if (spec == 2 && rollout && c.duel_walls) core += (size_t)kDuelWallWords * 4; // the cells' blocked-move bits (susnet_duel.h DuelWallTable)
     return core + (perm > stage ? perm : stage);
 }
 
@@ -1170,7 +1173,7 @@ extern "C" int susnet_record_layout_of(const susnet_env *env, int32_t record_for
     if (!env || !out) return fail(SUSNET_E_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
     if (record_format != SUSNET_RECORD_COMPACT) return fail(SUSNET_E_INVALID, "susnet_record_layout_of: unknown record format");
-    if (env->spec != 2 || !env->c.duel_fast) return SUSNET_OK; // record_bytes = 0: only the 1v1 no-walls kernel has the compact record
+    if (env->spec != 2 || !(env->c.duel_fast || env->c.duel_walls)) return SUSNET_OK; // record_bytes = 0: only the 1v1 kernels have the compact record
     out->record_bytes = 16;
     out->off_rewards = 0;
     out->off_obs = 8;
@@ -1279,7 +1282,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
     const uint64_t AB = (uint64_t)env->c.A * (uint64_t)env->c.B;
     // the compiled-in float32 FlatFeaturizer layouts (susnet_flat.h): `onehot_pos` on the 1v1 9x9 game without walls, `onehot_pos +
     // alive_crew + closest_crew` on the 1v2 14x14 game, next to the full trajectory, on the production stream
-    const bool flat1 = spec == 2 && env->c.duel_fast && env->c.N == 9 && o.ncomp == 1 && o.comp[0] == SUSNET_F_ONEHOT_POS;
+    const bool flat1 = spec == 2 && (env->c.duel_fast || env->c.duel_walls) && env->c.N == 9 && o.ncomp == 1 && o.comp[0] == SUSNET_F_ONEHOT_POS;
     const bool flat3 = spec == 3 && env->c.N == 14 && o.ncomp == 3 && o.comp[0] == SUSNET_F_ONEHOT_POS && o.comp[1] == SUSNET_F_ALIVE_CREW &&
                        o.comp[2] == SUSNET_F_CLOSEST_CREW;
     const bool traj_flat = all_traj && !tape && o.mode == SUSNET_OBS_FLAT && o.dtype == SUSNET_F32 && (flat1 || flat3) && !a.term_obs && !a.roles;
@@ -1297,7 +1300,7 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
                     : (traj_noobs && fit >= 1)              ? OUT_TRAJ
                     : (traj_flat && fit >= 1)               ? OUT_TRAJ_FLAT
                                                             : OUT_ANY;
-    const bool rec_term = a.record && a.term_obs && !a.roles && spec == 2 && env->c.duel_fast; // whole records of the 1v1 kernel + the terminal states
+    const bool rec_term = a.record && a.term_obs && !a.roles && spec == 2 && (env->c.duel_fast || env->c.duel_walls); // whole records of the 1v1 kernel + the terminal states
     if ((a.term_obs || a.roles) && !rec_term && !(all_traj && o.mode == SUSNET_OBS_RAW && o.dtype == SUSNET_U8))
         return fail(env, SUSNET_E_INVALID, "susnet_rollout: term_obs / roles go with the full trajectory and the raw uint8 observation (term_obs also "
                                            "with the records of the 1v1 no-walls kernel)");

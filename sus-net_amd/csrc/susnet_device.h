@@ -74,7 +74,7 @@ struct Consts {
     uint64_t seed, env_id_base;
     // 1v1 no-walls fast path (susnet_duel.h): reward bytes over {kill landed, imposter dead, crew dead} per agent
     uint64_t duel_lut[2];
-    int32_t duel_fast, duel_pad;
+    int32_t duel_fast, duel_walls; // which flavour of the duel kernels serves the handle's fused rollouts: no walls / a wall map (at most one is set)
 };
 enum : int { RW_KILL = 0, RW_FIX = 1, RW_SAB = 2, RW_TSR = 3, RW_END = 4, RW_DEAD = 5, RW_VOTE = 6 };
 template <class RT> __device__ __forceinline__ RT rw(const Consts &c, int k);

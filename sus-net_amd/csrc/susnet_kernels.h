@@ -163,7 +163,8 @@ __device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG 
 // same words into it); rest: the wave's own LDS region (lds_bytes() of the host minus the table image).  pre_imp >= 0: the imposters'
 // greedy action, already chosen by the caller (the crew then draws from the action stream).
 // obs_tick: which [B][F] slot of the observation output this step writes (o.tick_stride elements apart: the multi-tick policy kernel)
-template <class RNG, class S>
+// TABLES = false: the caller has filled the table image already (the multi-tick policy kernel: once per launch, before its barrier)
+template <class RNG, class S, bool TABLES = true>
 __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const StepArgs &a, const ObsArgs &o, uint32_t *smem, uint32_t *rest, int tid, int64_t b0,
                                           int pre_imp, int64_t obs_tick = 0) {
     const int64_t b = b0 + tid;
@@ -174,7 +175,7 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
     // between them (state rows are padded to Bp, so lanes past B read their own padding; their action index is clamped),
     // and only then are the tables written to LDS -- one memory round trip instead of one per table, per agent, per field.
     TableLoad<true> tl;
-    tl.issue(c, o.comp, tid);
+    if constexpr (TABLES) tl.issue(c, o.comp, tid);
     Env e = {};
     load_env<S>(c, s, st, b, e);
     const bool policy = a.q_imp != nullptr || pre_imp >= 0; // (wave-uniform) susnet_policy_step: Q rows instead of actions
@@ -197,8 +198,10 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
     // identical in every env -- read here, advanced below by the same lane
     uint64_t tick_word = a.tick;
     if (c.dev_tick) tick_word = s.tickw[b];
-    tl.commit(smem, tid, true);
-    wave_lds_fence();
+    if constexpr (TABLES) {
+        tl.commit(smem, tid, true);
+        wave_lds_fence();
+    }
     if (active) {
         const int A = S::A(c);
         bool done = false, trunc = false;
@@ -235,7 +238,7 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
         constexpr bool kDuelSpec = !S::kGeneric && S::kA == 2 && S::kJ == 0 && S::kVar == SUSNET_VARIANT_ITG && S::kStaticRoles && S::kFixedOrder;
         bool stepped = false;
         if constexpr (kDuelSpec) {
-            if (c.duel_fast) { // no walls, byte-sized rewards: the register-arithmetic step (susnet_duel.h)
+            if (c.duel_fast) { // no walls, byte-sized rewards: the register-arithmetic step (susnet_duel.h; a wall map steps through the tables here)
                 stepped = true;
                 const int32_t a0 = (int32_t)st.act(0), a1 = (int32_t)st.act(1);
                 if (a0 >= 8 || a1 >= 8) bits |= SUSNET_ERRBIT_ASSERT;            // base.py:360-362
@@ -589,8 +592,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Consts c, State s, RolloutAr
                 pt = pt ? pt + c.B : pt;
             }
         }
-        if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        if (OUT == OUT_TRAJ_RAW8 && !kDirect) write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+        if (OUT == OUT_ANY || (OUT == OUT_TRAJ_RAW8 && !kDirect)) {
+            int tid_o = tid; // (an opaque copy: see k_rollout_swar)
+            asm volatile("" : "+v"(tid_o));
+            if (OUT == OUT_ANY) write_obs<S>(c, o, T, st, tid_o, e, active, b0, nrows, tick);
+            else write_obs_raw8<S>(c, o, T, st, tid_o, e, active, b0, nrows, tick);
+        }
         if (kDirect) {
             if (active) {
                 uint8_t row[(kRawF > 0 ? kRawF : 1) + 4];
@@ -733,9 +740,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     }
     constexpr bool kFlat = OUT == OUT_TRAJ_FLAT; // (cooperative feature stores: every lane stays)
     constexpr bool kTraj = OUT == OUT_TRAJ_RAW8 || OUT == OUT_TRAJ || kFlat;
-    // the family's raw row has a run-time length: it goes through the cooperative LDS writer (every lane stays)
-    constexpr bool kCoopRaw = OUT == OUT_TRAJ_RAW8 && S::kRawF < 0;
-    if (((kTraj && !kFlat && !kCoopRaw) || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
+    // the family's raw row has a run-time length (the job count): still written straight from registers, by the one case of a wave-uniform
+    // switch over the job count that applies (round 4 sent it through the cooperative LDS writer: 37 G where the packed record reached 70)
+    constexpr bool kFamRaw = OUT == OUT_TRAJ_RAW8 && S::kRawF < 0;
+    if (((kTraj && !kFlat) || OUT == OUT_NONE || OUT == OUT_RECORD) && !active) return; // no cooperative work past this point in these modes
     W w;
     to_swar<S>(c, st, e, w);
     uint64_t tick_base = a.tick_base;
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     BufDst dr = make_buf_dst(a.rewards, nt * (uint64_t)AB * 4u, (uint32_t)(bb * A) * 4u);
     BufDst dd = make_buf_dst(a.done, nt * (uint64_t)c.B, (uint32_t)bb);
     BufDst dt = make_buf_dst(a.trunc, nt * (uint64_t)c.B, (uint32_t)bb);
-    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)(bb * kRawF));
+    BufDst dobs = make_buf_dst(o.out, nt * (uint64_t)o.tick_stride, (uint32_t)bb * (uint32_t)(kRawF > 0 ? kRawF : o.F));
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
     // OUT_TRAJ_FLAT: the wave's float32 feature rows [B][F], written cooperatively (susnet_flat.h); base = the wave's first row
     using FlatRowT = typename FlatFor<S>::Row;
@@ -824,7 +832,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         stage_a(0, true);
         stage_b();
     }
-    // the next episode of my environment, drawn ahead (production stream; see draw_episode)
+    // the next episode of my environment, drawn ahead (production stream; see draw_episode).  Not in OUT_ANY: the drawn-ahead episode is a
+    // second copy of the whole byte-parallel state (47 registers with 8 agents and 2 imposters), and next to the general observation
+    // writer that pushed the 5..8-agent kernels past 256 vector registers, i.e. into accumulator-register copies inside code that runs
+    // under divergent EXEC by design (isa_checks.parked_under_divergence).  There a finishing lane draws its episode on the spot -- the
+    // same RESET-stream words, so the same episode.
+    constexpr bool kAhead = !RNG::kNumpy && OUT != OUT_ANY;
     W wn = w;
     typename StoreFor<S>::type stn = st;
     uint32_t impn = 0;
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             KSTAMP(2);
             const bool fin = done || trunc;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(fin) != 0ull, 0)) {
-                if constexpr (!RNG::kNumpy) {
+                if constexpr (kAhead) {
                     // a finishing lane without a drawn episode: draw now -- for every lane that has none (see draw_episode)
                     if (__builtin_amdgcn_ballot_w64(fin && !have_next) != 0ull) {
                         if (!have_next) {
@@ -911,6 +924,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                     if constexpr (RNG::kNumpy) {
                         reset_env<S>(c, T, st, tid, e, rng);
                         to_swar<S>(c, st, e, w);
+                    } else if constexpr (!kAhead) { // base.py:251-324 on the RESET stream, drawn on the spot (see kAhead)
+                        Env en;
+                        draw_episode<S>(c, T, tid, rng, e.ep, st, en);
+                        to_swar<S>(c, st, en, w);
+                        e.imp = en.imp;
+                        e.alive = (1u << A) - 1u;
+                        e.jd = e.used = e.timer = e.t = 0u;
+                        e.ep += 1u;
                     } else { // base.py:251-324, drawn ahead: take it
                         st = stn;
                         w = wn;
@@ -934,6 +955,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 uint32_t row[(kRawF + 3) / 4];
                 raw_row_swar<S>(w, row, (uint32_t)c.tag_interval);
                 store_packed_bytes<kRawF>(dobs, row);
+            }
+            if constexpr (kFamRaw) { // flatten_state with the handle's job count: one case runs (scalar compares)
+                const int Jn = S::J(c);
+                static_for<0, 9>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int JJ = decltype(jc)::value;
+                    if (Jn == JJ) {
+                        uint32_t row[RawRowOf<S, JJ>::kDwords];
+                        raw_row_swar_n<S, JJ>(w, row, (uint32_t)c.tag_interval);
+                        store_packed_bytes<RawRowOf<S, JJ>::F>(dobs, row);
+                    }
+                });
             }
             if constexpr (kFlat) { // the feature row of the state after the step (and after an in-launch reset)
                 uint32_t fx[A], fy[A], fal[A];
@@ -1016,12 +1048,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
         }
         if (OUT == OUT_ANY) { // any observation mode: through the cooperative writer, on the bitmask / packed-store form
             if (active) from_swar<S>(c, w, st, e);
-            write_obs<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
+            // (an opaque copy of the lane id: the writer's lane-dependent addresses -- row pointers, the copy-out's piece offsets -- are
+            // invariant over the tick loop, and hoisted out of it they are held across the whole step: with them the 5..8-agent kernels
+            // needed up to 304 vector registers)
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            write_obs<S>(c, o, T, st, tid_o, e, active, b0, nrows, tick);
         }
-        if constexpr (kCoopRaw) { // the family's raw uint8 rows (run-time length): the wave's rows built in LDS, copied out in 16-byte pieces
-            if (active) from_swar<S>(c, w, st, e);
-            write_obs_raw8<S>(c, o, T, st, tid, e, active, b0, nrows, tick);
-        }
+
         if constexpr (kFlat) flat_store_wave(frow, T.stage, tid, nrows, dflat.r, dflat.vo + (uint32_t)tick * (slab_o * 4u));
     };
 #pragma clang loop unroll(disable)
@@ -1270,7 +1304,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
 
 // Fused random rollout of the 1v1 no-walls game (susnet_duel.h): the headline kernel.  Same contract as k_rollout for the
 // modes OUT_NONE / OUT_TRAJ / OUT_TRAJ_RAW8; RNG = the production stream or caller-supplied words (numpy parity).
-template <class RNG, int OUT>
+// WALLS: the wall-map flavour of the step (susnet_duel.h DuelWallTable; Consts::duel_walls)
+template <class RNG, int OUT, bool WALLS = false>
 __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, RolloutArgs a, ObsArgs o) {
     using S = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>;
     extern __shared__ uint32_t smem[];
@@ -1282,6 +1317,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     const bool active = tid < c.epw && b < c.B;
     typename StoreFor<S>::type st;
     Tables T = setup_lds<S>(c, smem, tid, st);
+    if constexpr (WALLS) { // the cells' blocked-move bits sit right behind the table image; what the reset / the feature rows stage moves up
+        DuelWallTable::build(c.N, tid);
+        wave_lds_publish();
+        T.stage += kDuelWallWords;
+        T.perm += 4u * kDuelWallWords;
+    }
     Env e = {};
     // OUT_TRAJ_FLAT stores the feature rows cooperatively, so every lane stays: a lane without an environment (ragged last
     // wave, fewer than 64 environments per wave) mirrors environment 0 and its stores are dropped by the buffer range check
@@ -1296,6 +1337,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
     as.init();
     Duel d;
     to_duel(st, e, d);
+    if constexpr (WALLS) DuelWallTable::lookup(d);
     DuelConsts k = make_duel_consts(c);
     // the low halves of the two reward tables are v_perm's second source every tick and an instruction takes one scalar operand: as
     // scalars they are copied to a vector register tick after tick (the compiler re-materialises rather than keep them); pinned here
@@ -1361,7 +1403,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
         if (kTraj) da.st16(0u, a0 | (a1 << 8));
         float r0, r1;
         uint32_t done, trunc, hit;
-        duel_step<RNG::kNumpy>(k, d, e, rng.cur, a0, a1, r0, r1, done, trunc, &hit);
+        duel_step<RNG::kNumpy, WALLS>(k, d, e, rng.cur, a0, a1, r0, r1, done, trunc, &hit);
         if (kTraj) {
             dr.st64(0u, __float_as_uint(r0), __float_as_uint(r1));
             dd.st8(0u, done);
@@ -1403,6 +1445,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_duel(Consts c, State s, Roll
                     e.ep += 1u;
                     have_next = false;
                 }
+                if constexpr (WALLS) DuelWallTable::lookup(d); // the spawn cells' bits (rare path: the wait sits in here)
                 // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed.
                 // The next step will align the event cursor: done right here unless this was the launch's last tick (then the
                 // stored cursor is the one the last step left)
@@ -1463,20 +1506,25 @@ template <int A_> using SpecA = Spec<A_, -1, -1, -1>;
 // ---------------------------------------------------------------------------------------------------
 // tape: the handle draws from caller-supplied words (numpy parity) instead of the production stream; offered for the
 // populate()-shaped trajectory (OUT_TRAJ_RAW8) and for the packed record (OUT_RECORD) -- the modes bench.py times
+template <bool WALLS>
+inline void launch_duel(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
+    if (out == OUT_TRAJ_FLAT) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_FLAT, WALLS>), g, blk, sh, st, c, s, a, o);
+    else if (tape && out == OUT_RECORD16) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD16, WALLS>), g, blk, sh, st, c, s, a, o);
+    else if (out == OUT_RECORD16) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD16, WALLS>), g, blk, sh, st, c, s, a, o);
+    else if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD, WALLS>), g, blk, sh, st, c, s, a, o);
+    else if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8, WALLS>), g, blk, sh, st, c, s, a, o);
+    else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD, WALLS>), g, blk, sh, st, c, s, a, o);
+    else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_NONE, WALLS>), g, blk, sh, st, c, s, a, o);
+    else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ, WALLS>), g, blk, sh, st, c, s, a, o);
+    else hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_RAW8, WALLS>), g, blk, sh, st, c, s, a, o);
+}
 template <class SPEC>
 void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t st, const Consts &c, const State &s, const RolloutArgs &a, const ObsArgs &o) {
     constexpr bool kDuelSpec = !SPEC::kGeneric && SPEC::kA == 2 && SPEC::kJ == 0 && SPEC::kVar == SUSNET_VARIANT_ITG && SPEC::kStaticRoles && SPEC::kFixedOrder;
     if constexpr (kDuelSpec) {
-        if (c.duel_fast && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD || out == OUT_TRAJ_FLAT || out == OUT_RECORD16)) { // susnet_duel.h
-            if (out == OUT_TRAJ_FLAT) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_FLAT>), g, blk, sh, st, c, s, a, o);
-            else if (tape && out == OUT_RECORD16) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD16>), g, blk, sh, st, c, s, a, o);
-            else if (out == OUT_RECORD16) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD16>), g, blk, sh, st, c, s, a, o);
-            else if (tape && out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
-            else if (tape) hipLaunchKernelGGL((k_rollout_duel<TapeRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
-            else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
-            else if (out == OUT_NONE) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_NONE>), g, blk, sh, st, c, s, a, o);
-            else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
-            else hipLaunchKernelGGL((k_rollout_duel<PhiloxRng, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
+        if ((c.duel_fast || c.duel_walls) && (out == OUT_NONE || out == OUT_TRAJ || out == OUT_TRAJ_RAW8 || out == OUT_RECORD || out == OUT_TRAJ_FLAT || out == OUT_RECORD16)) { // susnet_duel.h
+            if (c.duel_walls) launch_duel<true>(tape, out, g, blk, sh, st, c, s, a, o);
+            else launch_duel<false>(tape, out, g, blk, sh, st, c, s, a, o);
             return;
         }
     }

@@ -386,6 +386,13 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
             if (k < Q::kLdsFloats / 4) dst[k] = tmp[i];
         }
     }
+    // the step's table image (launch-constant): written ONCE, by the first wave, and published to the other three by the barrier -- no
+    // wave writes LDS words another one reads after this point
+    if (wave0 == 0) {
+        TableLoad<true> tl;
+        tl.issue(ka.c, ka.o.comp, lane0);
+        tl.commit(dyn, lane0, true);
+    }
     __syncthreads();
     if (b00 >= ka.c.B) return; // (after the only barrier; the step below synchronises inside the wave only)
     bool unit = true;
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
             ak.term_obs = shift(ak.term_obs, ts.term_obs);
             ak.roles = shift(ak.roles, ts.roles);
             ak.tick = ak.tick + (uint64_t)k;
-            step_wave<PhiloxRng, S>(c, s, ak, o, dyn, rest, lane, b0, (int)a_imp, (int64_t)k);
+            step_wave<PhiloxRng, S, false>(c, s, ak, o, dyn, rest, lane, b0, (int)a_imp, (int64_t)k);
         }
     }
 }

@@ -976,10 +976,17 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
 }
 
 // flatten_state (base.py:234-235) of the byte-parallel state as packed dwords: positions, alive, job cells, job status
-template <class S>
-__device__ __forceinline__ void raw_row_swar(const Swar<S> &w, uint32_t (&row)[(S::kRawF + 3) / 4], uint32_t tag_interval = 0u) {
+// (JJ: the job count the row is built for -- the compiled-in one, or, for the family, the case of a wave-uniform switch)
+template <class S, int JJ>
+struct RawRowOf {
+    static constexpr int A = S::kA, F = 3 * A + ((JJ > 0 || S::kVar == SUSNET_VARIANT_TAGGING) ? 3 * JJ : 0) + (S::kVar == SUSNET_VARIANT_TAGGING ? 2 * A + 1 : 0);
+    static constexpr int kDwords = (F + 3) / 4;
+};
+template <class S, int JJ>
+__device__ __forceinline__ void raw_row_swar_n(const Swar<S> &w, uint32_t (&row)[RawRowOf<S, JJ>::kDwords], uint32_t tag_interval = 0u) {
     using W = Swar<S>;
-    constexpr int A = W::A, J = W::J, F = S::kRawF;
+    constexpr int A = W::A, J = JJ, F = RawRowOf<S, JJ>::F;
+    static_assert(J <= W::JMAX, "job slots");
     uint8_t b[(F + 3) / 4 * 4];
     // assembled bytewise from a handful of words; the compiler folds the static byte moves into v_perm / shifts
     uint32_t pos[2 * W::NW];
@@ -1012,6 +1019,11 @@ __device__ __forceinline__ void raw_row_swar(const Swar<S> &w, uint32_t (&row)[(
 #pragma unroll
     for (int d = 0; d < (F + 3) / 4; d++)
         row[d] = (uint32_t)b[4 * d] | ((uint32_t)b[4 * d + 1] << 8) | ((uint32_t)b[4 * d + 2] << 16) | ((uint32_t)b[4 * d + 3] << 24);
+}
+template <class S>
+__device__ __forceinline__ void raw_row_swar(const Swar<S> &w, uint32_t (&row)[(S::kRawF + 3) / 4], uint32_t tag_interval = 0u) {
+    static_assert(S::kJ >= 0 && RawRowOf<S, S::kJ>::F == S::kRawF, "compiled-in job count");
+    raw_row_swar_n<S, S::kJ>(w, row, tag_interval);
 }
 
 } // namespace susnet

@@ -454,6 +454,7 @@ class BatchedFourRoomEnv:
             if mask is not None:
                 m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
             L.check(self.lib.susnet_reset(self._h, m.data_ptr() if m is not None else None, self._obs_ptr(), self._stream()))
+            self.reset_generation = getattr(self, "reset_generation", 0) + 1  # (DeviceReplayBuffer.collect drops its carried window when this moves)
             if self.export_state:
                 self._export(full=True)
             if self.check_errors:
@@ -736,6 +737,11 @@ class BatchedFourRoomEnv:
                                                         C.byref(io), int(n_ticks), self._stream()))
             if self._obs_spec is not None:
                 L.check(self.lib.susnet_observe(self._h, C.byref(self._obs_spec), self._stream()))
+            # once per block: what step() / policy_step() do per tick for a handle built with these flags
+            if self.export_state:
+                self._export(full=False)
+            if self.check_errors:
+                self.poll_errors()
 
     def step4(self, agent_actions):
         """North-star surface ``(obs, rewards, dones, info)``; dones = done | truncated."""

@@ -193,72 +193,69 @@ def store_data_hazards(asm, window=2):
     return bad
 
 
-EXEC_NARROWING = ("s_and_saveexec_b64", "s_andn2_saveexec_b64", "s_or_saveexec_b64", "s_xor_saveexec_b64")
+# ---- accumulator registers and divergence: a value-level check ---------------------------------------------------------------------
+# At the register limit the allocator keeps values in accumulator registers (`v_accvgpr_write_b32 aN, vM` ... `v_accvgpr_read_b32 vK, aN`).
+# Such a copy only moves the lanes of the CURRENT EXEC.  A write under a narrowed EXEC whose value is read back under a wider one hands the
+# lanes in between whatever the accumulator held before (round 4: k_qnet_step's last, partial wave stored Q rows through a wild pointer --
+# the row index had been parked inside `if (b + 32 < B)` and was read after the region's end; profiles/r04_parking_fault.md).
+#
+# parked_under_divergence() proves, for every accumulator value of a kernel, that EXEC at each of its reads is a subset of EXEC at the
+# write that produced it -- or reports the (write, read) pair.  Method:
+#   1. EXEC versions.  Every instruction that writes EXEC defines a version; version 0 is the kernel's entry mask; `parent[v]` is a
+#      version known to be a SUPERSET of v.  Narrowing forms (s_and / s_andn2 / s_*_saveexec with exec as an operand, the `else` xor) give
+#      a child of the current version.  Widening forms (`s_or_b64 exec, exec, sX`, `s_mov_b64 exec, sX`, `s_or_saveexec_b64`) give the version
+#      sX is KNOWN to hold lanes of -- scalar registers are tracked symbolically through s_mov / s_xor / s_andn2 / s_or and through their
+#      spills to vector lanes (v_writelane / v_readlane) -- or, when sX is unknown, a fresh version only known to lie inside version 0.
+#      Where control flow joins with different versions a phi version below their common ancestor is made.  (Assumed of the compiler: a
+#      restore from a register that holds lanes of version u brings back exactly u -- structured control flow lowering does.)
+#   2. Reaching definitions of the accumulator registers over the control-flow graph.  A definition carries the version it was made
+#      under and an `exposed` flag, set as soon as it flows through an EXEC write (or a join) whose new version is not provably inside
+#      its own.  MFMA reads and writes all lanes whatever EXEC is: its accumulator operands count as read / written under version 0.
+#   3. A read is reported when a reaching definition is exposed, or was made under a version that is not an ancestor of the read's.
+# Validated against: AMD clang 22.0.0git (ROCm 7.2.0).
+_SREG = re.compile(r"^s(\d+)$")
+_SRANGE = re.compile(r"^s\[(\d+):(\d+)\]$")
+_AREG = re.compile(r"^a(\d+)$")
+_ARANGE = re.compile(r"^a\[(\d+):(\d+)\]$")
+_VCC = {"vcc": (106, 107), "vcc_lo": (106,), "vcc_hi": (107,)}
+_NO_SDST = ("s_cmp", "s_bitcmp", "s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_endpgm", "s_barrier", "s_sleep", "s_setprio", "s_setreg", "s_store",
+            "s_buffer_store", "s_dcache", "s_icache", "s_sethalt", "s_trap", "s_setpc", "s_sendmsg", "s_setkill", "s_inst_prefetch", "s_clause", "s_set_gpr",
+            "s_ttrace", "s_decperflevel", "s_incperflevel", "s_cmpk", "s_setvskip", "s_code_end")
 
 
-def parked_under_divergence(asm, kernels=("k_qnet",)):
-    """`v_accvgpr_write` that may execute under a narrowed EXEC, in the kernels that run at the register limit.
+def _sregs(operand):
+    m = _SREG.match(operand)
+    if m:
+        return (int(m.group(1)),)
+    m = _SRANGE.match(operand)
+    if m:
+        return tuple(range(int(m.group(1)), int(m.group(2)) + 1))
+    return _VCC.get(operand, ())
 
-    There the register allocator parks long-lived values in accumulator registers around the matrix section.  A parking move it places inside a
-    divergent region executes under that region's EXEC: the lanes outside keep whatever the accumulator held, and read it back as the value later
-    (measured: the row index of k_qnet_step's Q-row store, parked inside `if (b + 32 < B)`; the last, partial wave of a batch stored through a wild
-    pointer).  The Q-network code is written without divergent branches for that reason; this check keeps it so.
-    Method: the kernel's control-flow graph from the branch offsets; forward data flow of "EXEC may be narrowed" (set by s_*_saveexec_b64 and by
-    and / andn2 / xor into exec, cleared by `s_or_b64 exec, exec, ...` and `s_mov_b64 exec, ...`; union over predecessors).  An inner region's end
-    clears the flag although an outer one may still be open: the check can miss, not false-alarm on straight code.
-    Validated against: AMD clang 22.0.0git (ROCm 7.2.0)."""
-    bad = []
-    cur, ins = None, []
 
-    def finish():
-        if cur is None or not ins:
-            return
-        addr_to_idx = {a: i for i, (a, _, _) in enumerate(ins)}
-        n = len(ins)
-        succ = [[] for _ in range(n)]
-        for i, (a, size, text) in enumerate(ins):
-            op = text.split()[0]
-            nxt = a + size
-            if op in ("s_endpgm", "s_setpc_b64"):
-                continue
-            if op == "s_branch" or op.startswith("s_cbranch"):
-                off = int(text.split()[-1])
-                if off >= 0x8000:
-                    off -= 0x10000
-                t = addr_to_idx.get(nxt + 4 * off)
-                if t is not None:
-                    succ[i].append(t)
-                if op == "s_branch":
-                    continue
-            if i + 1 < n:
-                succ[i].append(i + 1)
-        state_in = [None] * n  # None: not reached yet
-        state_in[0] = False
-        work = [0]
-        while work:
-            i = work.pop()
-            st = state_in[i]
-            text = ins[i][2]
-            op = text.split()[0]
-            ops = text.split(None, 1)[1].replace(" ", "") if " " in text else ""
-            if op in EXEC_NARROWING or (op in ("s_and_b64", "s_andn2_b64", "s_xor_b64") and ops.startswith("exec,")):
-                st = True
-            elif op in ("s_or_b64", "s_mov_b64") and ops.startswith("exec,"):
-                st = False
-            for t in succ[i]:
-                new = st if state_in[t] is None else (state_in[t] or st)
-                if new != state_in[t]:
-                    state_in[t] = new
-                    work.append(t)
-        for i, (_, _, text) in enumerate(ins):
-            if state_in[i] and text.startswith("v_accvgpr_write_b32"):
-                bad.append((cur, text))
+def _aregs(operand):
+    m = _AREG.match(operand)
+    if m:
+        return (int(m.group(1)),)
+    m = _ARANGE.match(operand)
+    if m:
+        return tuple(range(int(m.group(1)), int(m.group(2)) + 1))
+    return ()
+
+
+def _parse_kernels(asm, want):
+    """-> [(mangled name, [(address, size, op, [operands])])] for the kernels `want(name, body_text)` selects."""
+    out, cur, ins, raw = [], None, [], []
+
+    def flush():
+        if cur is not None and ins and want(cur, raw):
+            out.append((cur, list(ins)))
 
     for ln in asm.splitlines():
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", ln)
         if m:
-            finish()
-            cur, ins = (m.group(1) if any(k in m.group(1) for k in kernels) else None), []
+            flush()
+            cur, ins, raw = m.group(1), [], []
             continue
         if cur is None or "\t" not in ln or "//" not in ln:
             continue
@@ -267,8 +264,370 @@ def parked_under_divergence(asm, kernels=("k_qnet",)):
         mm = re.match(r"\s*([0-9A-Fa-f]+):\s*(.*)$", tail)
         if not text or not mm:
             continue
-        ins.append((int(mm.group(1), 16), 4 * sum(1 for w in mm.group(2).split() if re.fullmatch(r"[0-9A-Fa-f]{8}", w)), text))  # (a branch line ends in "<symbol+0x..>")
-    finish()
+        parts = text.split(None, 1)
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        # (modifiers ride on the last operand: "v153 offset:39520", "off offset:64")
+        ops = [o.split()[0] if o and " " in o and not o.startswith(("s[", "v[", "a[")) else o for o in ops]
+        size = 4 * sum(1 for w in mm.group(2).split() if re.fullmatch(r"[0-9A-Fa-f]{8}", w))  # (a branch line ends in "<symbol+0x..>")
+        ins.append((int(mm.group(1), 16), size, parts[0], ops))
+        raw.append(parts[0])
+    flush()
+    return out
+
+
+class _ExecVersions:
+    """parent[] forest of EXEC versions (see above); ids are tied to instruction sites so that the data flow converges."""
+
+    def __init__(self):
+        self.parent = {0: None}
+        self.ids = {}
+        self.changed = False
+
+    def depth_path(self, v):
+        path = []
+        while v is not None:
+            path.append(v)
+            v = self.parent[v]
+        return path
+
+    def anc_or_eq(self, a, v):
+        while v is not None:
+            if v == a:
+                return True
+            v = self.parent[v]
+        return False
+
+    def lca(self, a, b):
+        pa = set(self.depth_path(a))
+        while b not in pa:
+            b = self.parent[b]
+        return b
+
+    def make(self, key, parent):
+        """the version of site `key`, below `parent` (a second visit with another parent moves it below their common ancestor)"""
+        v = self.ids.get(key)
+        if v is None:
+            v = self.ids[key] = len(self.parent)
+            self.parent[v] = parent
+            self.changed = True
+        elif self.parent[v] != parent:
+            p = self.lca(self.parent[v], parent)
+            if p == v or self.anc_or_eq(v, p):  # (degenerate: would make v its own ancestor)
+                p = 0
+            if p != self.parent[v]:
+                self.parent[v] = p
+                self.changed = True
+        return v
+
+
+def _exec_flow(ins):
+    """Phase 1: (versions, version at every instruction's entry, version after it, successor lists, phi version per block entry)."""
+    n = len(ins)
+    addr_to_idx = {a: i for i, (a, _, _, _) in enumerate(ins)}
+    succ = [[] for _ in range(n)]
+    leaders = {0}
+    for i, (a, size, op, ops) in enumerate(ins):
+        if op in ("s_endpgm", "s_setpc_b64"):
+            if i + 1 < n:
+                leaders.add(i + 1)
+            continue
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            off = int(ops[-1])
+            if off >= 0x8000:
+                off -= 0x10000
+            t = addr_to_idx.get(a + size + 4 * off)
+            if t is not None:
+                succ[i].append(t)
+                leaders.add(t)
+            if i + 1 < n:
+                leaders.add(i + 1)
+            if op == "s_branch":
+                continue
+        if i + 1 < n:
+            succ[i].append(i + 1)
+    order = sorted(leaders)
+    block_of = {}
+    blocks = []
+    for k, st in enumerate(order):
+        en = order[k + 1] if k + 1 < len(order) else n
+        blocks.append((st, en))
+        block_of[st] = k
+    V = _ExecVersions()
+    # state: (exec version, {sgpr index: (kind, version, half)}, {(vgpr, lane): content})
+    state_in = [None] * len(blocks)
+    state_in[0] = (0, {}, {})
+    ex_in = [None] * n
+    ex_out = [None] * n
+
+    def pair(sg, regs):
+        """content of a 64-bit scalar operand: (kind, version) when both halves hold the two halves of one tracked mask"""
+        if len(regs) != 2:
+            return None
+        lo, hi = sg.get(regs[0]), sg.get(regs[1])
+        if lo is None or hi is None or lo[:2] != hi[:2] or lo[2] != 0 or hi[2] != 1:
+            return None
+        return lo[:2]
+
+    def set_pair(sg, regs, content):
+        for h, r in enumerate(regs):
+            if content is None:
+                sg.pop(r, None)
+            else:
+                sg[r] = (content[0], content[1], h)
+
+    def transfer(bi):
+        st, en = blocks[bi]
+        ex, sg, slots = state_in[bi]
+        sg, slots = dict(sg), dict(slots)
+        for i in range(st, en):
+            _, _, op, ops = ins[i]
+            ex_in[i] = ex
+            new_ex = ex
+            d0 = ops[0] if ops else ""
+            if op.startswith("s_") and not op.startswith(_NO_SDST):
+                src = ops[1:]
+                dst_exec = d0 == "exec"
+                uses_exec = "exec" in src
+                content = None
+                if op in ("s_and_saveexec_b64", "s_andn2_saveexec_b64", "s_xor_saveexec_b64", "s_or_saveexec_b64", "s_orn2_saveexec_b64",
+                          "s_nand_saveexec_b64", "s_nor_saveexec_b64", "s_xnor_saveexec_b64", "s_andn1_saveexec_b64", "s_orn1_saveexec_b64"):
+                    saved = ("eq", ex)
+                    if op in ("s_and_saveexec_b64", "s_andn2_saveexec_b64", "s_andn1_saveexec_b64") and op != "s_andn1_saveexec_b64":
+                        new_ex = V.make(("v", i), ex)
+                    elif op == "s_or_saveexec_b64":
+                        c = pair(sg, _sregs(src[0])) if src else None
+                        new_ex = V.lca(ex, c[1]) if c else V.make(("t", i), 0)
+                    else:
+                        new_ex = V.make(("t", i), 0)
+                    for r in _sregs(d0):
+                        sg.pop(r, None)
+                    set_pair(sg, _sregs(d0), saved)
+                    ex_out[i] = ex = new_ex
+                    continue
+                if dst_exec:
+                    other = [o for o in src if o != "exec"]
+                    c = pair(sg, _sregs(other[0])) if other else None
+                    if op in ("s_and_b64", "s_andn2_b64") and uses_exec and (op == "s_and_b64" or src[0] == "exec"):
+                        new_ex = V.make(("v", i), ex)  # exec & x, exec & ~x: lanes only leave
+                    elif op == "s_xor_b64" and uses_exec and c is not None and V.anc_or_eq(ex, c[1]):
+                        new_ex = V.make(("v", i), ex)  # the `else` mask: exec ^ (lanes inside exec)
+                    elif op == "s_or_b64" and uses_exec and c is not None:
+                        new_ex = V.lca(ex, c[1])       # a restore: back to the version the register holds lanes of
+                    elif op == "s_mov_b64" and c is not None:
+                        new_ex = c[1] if c[0] == "eq" else V.make(("v", i), c[1])
+                    else:
+                        new_ex = V.make(("t", i), 0)
+                    ex_out[i] = ex = new_ex
+                    continue
+                if d0 in ("exec_lo", "exec_hi"):
+                    ex_out[i] = ex = V.make(("t", i), 0)
+                    continue
+                dregs = _sregs(d0)
+                if len(dregs) == 2:
+                    a = src[0] if src else ""
+                    b = src[1] if len(src) > 1 else ""
+                    ca = ("eq", ex) if a == "exec" else pair(sg, _sregs(a))
+                    cb = ("eq", ex) if b == "exec" else pair(sg, _sregs(b))
+                    if op == "s_mov_b64":
+                        content = ("sub", ex) if a in ("0", "0x0") else ca  # (no lanes: inside any version; the seed of a loop's exit mask)
+                    elif op in ("s_and_b64", "s_andn2_b64"):
+                        # x & y lies inside both; x & ~y inside x
+                        cands = [c for c in ((ca, cb) if op == "s_and_b64" else (ca,)) if c is not None]
+                        if cands:
+                            best = max(cands, key=lambda c: len(V.depth_path(c[1])))
+                            content = ("sub", best[1])
+                    elif op in ("s_or_b64", "s_xor_b64") and ca is not None and cb is not None:
+                        content = ("sub", V.lca(ca[1], cb[1]))
+                for r in dregs:
+                    sg.pop(r, None)
+                if content is not None:
+                    set_pair(sg, dregs, content)
+                if op in ("s_mov_b32",) and len(dregs) == 1 and len(src) == 1:
+                    sr = _sregs(src[0])
+                    if len(sr) == 1 and sr[0] in sg:
+                        sg[dregs[0]] = sg[sr[0]]
+            elif op == "v_writelane_b32":
+                m = re.fullmatch(r"v(\d+)", d0)
+                sr = _sregs(ops[1]) if len(ops) > 1 else ()
+                lane = ops[2] if len(ops) > 2 else ""
+                if m and lane.isdigit():
+                    key = (int(m.group(1)), int(lane))
+                    if len(sr) == 1 and sr[0] in sg:
+                        slots[key] = sg[sr[0]]
+                    else:
+                        slots.pop(key, None)
+                elif m:
+                    for k in [k for k in slots if k[0] == int(m.group(1))]:
+                        del slots[k]
+            elif op == "v_readlane_b32":
+                dregs = _sregs(d0)
+                m = re.fullmatch(r"v(\d+)", ops[1]) if len(ops) > 1 else None
+                lane = ops[2] if len(ops) > 2 else ""
+                for r in dregs:
+                    sg.pop(r, None)
+                if m and lane.isdigit() and len(dregs) == 1 and (int(m.group(1)), int(lane)) in slots:
+                    sg[dregs[0]] = slots[(int(m.group(1)), int(lane))]
+            else:
+                if op.startswith("v_cmpx"):
+                    new_ex = V.make(("v", i), ex)
+                # scalar destinations of vector instructions (compares, carries, readfirstlane): operand 0 or 1
+                for o in ops[:2]:
+                    for r in _sregs(o):
+                        sg.pop(r, None)
+                if op.startswith("v_cmp_") and len(_sregs(d0)) == 2:
+                    set_pair(sg, _sregs(d0), ("sub", ex))  # a compare writes 0 for the lanes outside EXEC
+                # a vector register that is written as a whole no longer holds spilled scalars
+                if slots and not op.startswith(("buffer_store", "global_store", "flat_store", "ds_write", "scratch_store", "s_")):
+                    for v in _vgprs(d0):
+                        for k in [k for k in slots if k[0] == v]:
+                            del slots[k]
+                    if op == "v_swap_b32" and len(ops) > 1:
+                        for v in _vgprs(ops[1]):
+                            for k in [k for k in slots if k[0] == v]:
+                                del slots[k]
+            ex_out[i] = ex = new_ex
+        return ex, sg, slots
+
+    def merge(bi, incoming):
+        ex, sg, slots = incoming
+        cur = state_in[bi]
+        if cur is None:
+            state_in[bi] = (ex, sg, slots)
+            return True
+        cex, csg, cslots = cur
+        nex = cex
+        if ex != cex:
+            phi = V.ids.get(("p", bi))
+            if phi is not None and cex == phi:
+                nex = V.make(("p", bi), V.lca(V.parent[phi] if V.parent[phi] is not None else 0, ex)) if not V.anc_or_eq(phi, ex) or ex != phi else phi
+            else:
+                nex = V.make(("p", bi), V.lca(cex, ex))
+        nsg = {k: v for k, v in csg.items() if sg.get(k) == v}
+        nslots = {k: v for k, v in cslots.items() if slots.get(k) == v}
+        if nex != cex or len(nsg) != len(csg) or len(nslots) != len(cslots):
+            state_in[bi] = (nex, nsg, nslots)
+            return True
+        return False
+
+    for _ in range(50):  # (the version forest itself can move: repeat the flow until it does not)
+        V.changed = False
+        work = [0]
+        queued = {0}
+        while work:
+            bi = work.pop()
+            queued.discard(bi)
+            out = transfer(bi)
+            st, en = blocks[bi]
+            for t in succ[en - 1]:
+                tb = block_of[t]
+                if merge(tb, out) and tb not in queued:
+                    work.append(tb)
+                    queued.add(tb)
+        if not V.changed:
+            break
+    entry_version = [state_in[k][0] if state_in[k] is not None else None for k in range(len(blocks))]
+    return V, ex_in, ex_out, succ, blocks, block_of, entry_version
+
+
+_A_DEFS = ("v_accvgpr_write", "v_accvgpr_mov", "ds_read", "global_load", "buffer_load", "flat_load", "scratch_load", "v_mfma", "v_smfmac")
+
+
+def parked_under_divergence(asm, kernels=None):
+    """-> [(kernel, write, read)]: accumulator-register values that can be read under an EXEC wider than the one they were written under
+    (see the comment above).  kernels: substrings of the (mangled) names to look at; None = every kernel that has a `v_accvgpr_write`."""
+    bad = []
+
+    def want(name, ops):
+        if kernels is not None and not any(k in name for k in kernels):
+            return False
+        return any(o.startswith("v_accvgpr_write") for o in ops)
+
+    for name, ins in _parse_kernels(asm, want):
+        V, ex_in, ex_out, succ, blocks, block_of, entry_version = _exec_flow(ins)
+        # phase 2: per accumulator register the version whose lanes are all known to hold a written value (`cov`: a MUST analysis over
+        # the control-flow graph), and one site that wrote it (for the report).  A write under version W: W at or above cov -> cov = W (every
+        # lane rewritten); below or beside it -> cov stays (a partial update of a value whose home is the accumulator register: the other
+        # lanes keep what an earlier, wider write gave them).  An EXEC write or a join to a version that is not inside cov ends the dynamic
+        # instance cov named: the value is no longer known to be whole (None).
+        NONE = -1
+        state_in = [None] * len(blocks)
+        state_in[0] = {}
+        reported = set()
+
+        def through(cov, version):
+            return {a: (w if w[0] != NONE and V.anc_or_eq(w[0], version) else (NONE, w[1])) for a, w in cov.items()}
+
+        def meet(x, y):
+            if x[0] == NONE or y[0] == NONE:
+                return (NONE, x[1])
+            if V.anc_or_eq(x[0], y[0]):
+                return y
+            if V.anc_or_eq(y[0], x[0]):
+                return x
+            return (NONE, x[1])
+
+        def run(bi, report):
+            st, en = blocks[bi]
+            cov = dict(state_in[bi])
+            for i in range(st, en):
+                _, _, op, ops = ins[i]
+                if ex_in[i] is None:
+                    return None
+                is_mfma = op.startswith(("v_mfma", "v_smfmac"))
+                aops = [(k, _aregs(o)) for k, o in enumerate(ops) if o.startswith("a")]
+                if aops:
+                    is_def = op.startswith(_A_DEFS)
+                    rv = 0 if is_mfma else ex_in[i]
+                    if report:
+                        for k, regs in aops:
+                            if is_def and k == 0:
+                                continue
+                            for a in regs:
+                                w = cov.get(a, (NONE, None))
+                                if (w[0] == NONE or not V.anc_or_eq(w[0], rv)) and (a, i) not in reported:
+                                    reported.add((a, i))
+                                    d = ins[w[1]] if w[1] is not None else ("", 0, "(never written)", [])
+                                    bad.append((name, d[2] + " " + ", ".join(d[3]), op + " " + ", ".join(ops)))
+                    if is_def and aops[0][0] == 0:
+                        wv = 0 if is_mfma else ex_in[i]
+                        for a in aops[0][1]:
+                            old = cov.get(a)
+                            if old is None or old[0] == NONE or V.anc_or_eq(wv, old[0]):
+                                cov[a] = (wv, i)
+                if ex_out[i] != ex_in[i]:
+                    cov = through(cov, ex_out[i])
+            return cov
+
+        work, queued = [0], {0}
+        while work:
+            bi = work.pop()
+            queued.discard(bi)
+            out = run(bi, False)
+            if out is None:
+                continue
+            en = blocks[bi][1]
+            for t in succ[en - 1]:
+                tb = block_of[t]
+                inc = through(out, entry_version[tb]) if entry_version[tb] != ex_out[en - 1] else out
+                cur = state_in[tb]
+                if cur is None:
+                    state_in[tb] = dict(inc)
+                    changed = True
+                else:
+                    changed = False
+                    for a, w in inc.items():
+                        # (a register no instruction has written on the other path constrains nothing: the compiler reads no register it
+                        # never wrote, except along paths its own correlated branches rule out -- `if (unit) A; if (!unit) B; use`)
+                        m = meet(cur[a], w) if a in cur else w
+                        if cur.get(a) != m:
+                            cur[a] = m
+                            changed = True
+                if changed and tb not in queued:
+                    work.append(tb)
+                    queued.add(tb)
+        for bi in range(len(blocks)):
+            if state_in[bi] is not None:
+                run(bi, True)
     return bad
 
 
@@ -278,7 +637,7 @@ def scratch_instructions(asm):
 
 # The kernels bench.py's lines are made of (fused rollout, packed record).  VERDICT r02 item 1: at most 16 spilled SGPRs, no
 # accumulation registers, no spilled VGPRs; and small enough for the instruction cache (64 KB per pair of CUs).
-HEADLINE_KERNELS = ("k_rollout_duel<PhiloxRng, 4>", "k_rollout_swar<Spec<3, 4, 0, 1, -1, 1>, 4, PhiloxRng>",
+HEADLINE_KERNELS = ("k_rollout_duel<PhiloxRng, 6, false>", "k_rollout_duel<PhiloxRng, 4, false>", "k_rollout_duel<PhiloxRng, 6, true>", "k_rollout_swar<Spec<3, 4, 0, 1, -1, 1>, 4, PhiloxRng>",
                     "k_rollout_swar2<Spec<8, 4, 0, 1, -1, 2>, 4, PhiloxRng>", "k_rollout_swar<Spec<5, 5, 2, 1, -1, 1>, 4, PhiloxRng>")
 HEADLINE_LIMITS = dict(sgpr_spill=16, agpr=0, vgpr_spill=0, v_accvgpr=0, scratch=0, code_bytes=48 * 1024)
 
@@ -311,7 +670,8 @@ def _analyse(obj: str):
         problems.append(f"{os.path.basename(obj)}: {len(hz)} wide-store data hazards, e.g. {hz[:2]}")
     pk = parked_under_divergence(asm)
     if pk:
-        problems.append(f"{os.path.basename(obj)}: {len(pk)} accumulator-register parking moves inside divergent regions, e.g. {pk[:2]}")
+        problems.append(f"{os.path.basename(obj)}: {len(pk)} accumulator-register values read under a wider EXEC than they were written under, in "
+                        f"{sorted(set(demangle([b[0] for b in pk]).values()))[:4]}, e.g. {[b[1:] for b in pk[:2]]}")
     sc = scratch_instructions(asm)
     if sc:
         problems.append(f"{os.path.basename(obj)}: {len(sc)} scratch instructions, e.g. {sc[:2]}")

@@ -166,6 +166,14 @@ class DeviceReplayBuffer:
         assert policy.crew_model is None or policy.fused_crew is not None, "collect: the crew's model must be a reference MLP on a compiled-in feature layout (or None: random crew)"
         assert env.flattened_state_size == self.state_size and env.n_agents == self.n_agents and env.n_imposters == self.n_imposters
         T, B = self.trajectory_size, env.batch
+        # the carried window and the feed block belong to ONE env (identity, device) between two of its resets: another env of the same
+        # batch, or the same env after reset(), starts from its own current state
+        owner = (id(env), str(env.device), getattr(env, "reset_generation", 0))
+        if getattr(self, "_collect_owner", None) != owner:
+            self._collect_window = None
+            if getattr(self, "_collect_owner", (None, None, None))[:2] != owner[:2]:
+                self._collect_feed = None
+            self._collect_owner = owner
         if getattr(self, "_collect_window", None) is None:  # train.py:318-322: the current state T times
             first = env.observe(ObsConfig("raw", dtype=torch.uint8))
             self._collect_window = first.unsqueeze(1).repeat(1, T, 1).contiguous()
@@ -195,7 +203,8 @@ class DeviceReplayBuffer:
         return num_steps * B
 
     def reset_collection(self) -> None:
-        """Forget the carried sequence window (call after ``env.reset()``: the next ``collect`` starts from the current state)."""
+        """Forget the carried sequence window: the next ``collect`` starts from the current state.  (``collect`` does this by itself when the
+        env it is given is another one, or has been ``reset()`` since the last call.)"""
         self._collect_window = None
 
     @torch.no_grad()

@@ -11,6 +11,7 @@ pkg = importlib.import_module("sus-net_amd")
 B, T, reps = 65536, 128, 8
 kw = dict(batch=B, auto_reset=True, export_state=False, check_errors=False)
 cases = {
+    "itg 1v1 walls (experiment_1v1.ipynb envs['Wall'])": lambda: pkg.BatchedImposterTrainingGround(1, 0, 0, -3, 0, 0, **kw),
     "itg 1v3 j2": lambda: pkg.BatchedImposterTrainingGround(3, 2, 0, -3, 1, 5, **kw),
     "itg 1v10 (visualizing_games.ipynb)": lambda: pkg.BatchedImposterTrainingGround(10, 0, 0, -3, 0, 0, **kw),
     "base 1v3 j5 (replay_buffer_test.ipynb)": lambda: pkg.BatchedFourRoomEnv(1, 3, 5, **kw),
@@ -28,7 +29,7 @@ for name, make in cases.items():
         continue
     env = make()
     env.reset()
-    line = f"{name:40s}"
+    line = f"{name:52s}"
     for packed in (False, True):
         if packed and env.record_layout() is None:
             line += "   packed: none"
