@@ -62,7 +62,8 @@ CONFIGS = {
     # BASELINE.json configs[4]: cfg3's env driven by the reference-architecture MLP (no checkpoints ship with the
     # reference: seeded random init), greedy imposter + uniformly random crew, everything on the device
     "cfg5": dict(workload="cfg5: cfg3 env (1v2, 14x14 walled, 4 jobs) driven by MLP[88,256,128,64,16,7] imposter policy "
-                          "(float32 on the f32-input MFMA) + random crew, the whole tick one HIP kernel (susnet_qnet_policy_step), batch 65536/GPU",
+                          "(float32 on the f32-input MFMA) + random crew, the whole tick one HIP kernel (k_qnet_step; ticks per launch: see "
+                          "config.policy_forward), batch 65536/GPU",
                  cls="base", kw=dict(n_imposters=1, n_crew=2, n_jobs=4), n=14, A=3, J=4, batch=65536, policy=True),
 }
 POLICY_COMPONENTS = ["onehot_pos", "alive_crew", "closest_crew"]
@@ -214,6 +215,55 @@ def cpu_baseline(spec, target_seconds=12.0):
     )
 
 
+def config_block(spec, mode, obs, B, world, ticks_per_step, layout, agent_steps_per_s):
+    """The line's `config`: the workload BASELINE.json names, the per-GPU and whole-job batch, the data-parallel degree."""
+    return {"workload": spec["workload"], "mode": mode, "obs": obs, "batch_per_gpu": B,
+            "global_batch": B * world, "ticks_per_launch": ticks_per_step,
+            "step_definition": (f"one susnet_rollout launch = {ticks_per_step} lockstep ticks x {B} envs per GPU" if mode == "fused"
+                                else "one lockstep tick (sample_actions + step)"),
+            "env_steps_per_bench_step": B * ticks_per_step * world,
+            "trajectory_layout": layout,
+            "rng": "philox4x32-10 in-kernel", "auto_reset": True, "parallelism": f"dp{world}",
+            "agent_steps_per_s": agent_steps_per_s}
+
+
+def dry_run(args, pkg, rank, world):
+    """--dry-run: the distributed control flow of a real run with no device behind it (see the flag's help)."""
+    import torch
+    import torch.distributed as dist
+
+    spec = CONFIGS[args.config]
+    B = args.batch or spec["batch"]
+    mode = "policy" if spec.get("policy") else args.mode
+    ticks_per_step = args.ticks if mode == "fused" else 1
+    start, count = pkg.dist.shard_range(B * world, rank, world)  # the env ids this rank's handle would own (env_id_base = rank * B)
+    assert (start, count) == (rank * B, B)
+    if world > 1:
+        dist.barrier()                                   # sync_all() before the timed region
+        tmax = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)      # the MAX over ranks of the timed region
+        assert tmax.item() == world - 1
+        mine = torch.tensor([float(start)], dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)                      # per-rank launch times in the real run; here: every rank's first env id
+        starts = [int(v.item()) for v in allv]
+    else:
+        starts = [start]
+    table = pkg.dist.all_gather_totals(torch.full((12,), rank + 1, dtype=torch.int64))  # the ONE collective of the path (node metrics)
+    assert table.shape == (world, 12) and int(table[:, 0].sum()) == world * (world + 1) // 2
+    line = {"metric": "env-steps/s", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "dry_run": True, "shard_first_env_ids": starts,
+            "config": config_block(spec, mode, args.obs, B, world, ticks_per_step, None, None)}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without the torch.distributed.run environment: start the N ranks ourselves (one per
     GPU), BEFORE this process makes any GPU call, relay their output and return their exit code."""
@@ -259,10 +309,16 @@ def main():
                     "has been busy this long.  An MI355X that has been idle takes tens of milliseconds of sustained load to reach its steady clocks: 5 "
                     "warm-up launches of 0.1-0.3 ms each leave the timed region on the ramp (cfg3: 107 G with 5 warm-up launches, 118.5 G with 50 "
                     "or 400 -- same box, same binary).  Reported in the line as `settle_ms`; 0 = none")
-    ap.add_argument("--policy-block", type=int, default=64, help="cfg5: ticks per launch of the policy loop (susnet_qnet_policy_rollout: the network image and the "
-                    "launch are paid once per block; the loop runs with fixed networks, as run_game does).  0 = one launch per tick (susnet_qnet_policy_step)")
+    ap.add_argument("--policy-block", type=int, default=5, help="cfg5: ticks per launch of the policy loop (susnet_qnet_policy_rollout: the network image and the "
+                    "launch are paid once per block, the weights are fixed within it).  Default 5 = the reference trainer's train_step_interval (train.py:295, "
+                    "402-416: the networks change every 5 env steps), i.e. its acting loop between two optimizer steps; 64 = run_game's loop with fixed networks "
+                    "(visualize.py:547-582; reported next to the headline as `policy_forms`); 0 = one launch per tick (susnet_qnet_policy_step)")
     ap.add_argument("--repeats", type=int, default=5, help="the K-launch timed region is run this many more times back to back (after the "
                     "headline measurement, which stays as it is): median / min / max of the repeats are reported in `repeats`")
+    ap.add_argument("--dry-run", action="store_true", help="rehearse the N-rank launch on a box without N GPUs: the ranks start, rendezvous and run every "
+                    "collective of the real run (world check, barrier, max over ranks, the metrics all-gather) on host tensors, make NO device call, and rank 0 "
+                    "prints the line with its config block as the real run builds it and `value` null, `dry_run` true (tests/test_dist_gloo.py: BASELINE "
+                    "config 4 = --gpus 8 --config cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the step-API leg, the observation sweep and other_configs")
     args = ap.parse_args()
@@ -286,6 +342,9 @@ def main():
         seen = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
         dist.all_reduce(seen)
         assert int(seen.item()) == args.gpus, f"gathered {int(seen.item())} ranks, expected {args.gpus}"
+    if args.dry_run:
+        dry_run(args, pkg, rank, world)
+        return
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     coll_dev = device if backend == "nccl" else "cpu"
@@ -478,14 +537,7 @@ def main():
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": res["seconds"] * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic", "settle_ms": args.settle_ms,
-        "config": {"workload": spec["workload"], "mode": args.mode, "obs": args.obs, "batch_per_gpu": B,
-                   "global_batch": B * world, "ticks_per_launch": ticks_per_step,
-                   "step_definition": (f"one susnet_rollout launch = {ticks_per_step} lockstep ticks x {B} envs per GPU" if args.mode == "fused"
-                                       else "one lockstep tick (sample_actions + step)"),
-                   "env_steps_per_bench_step": steps_per_launch * world,
-                   "trajectory_layout": res["layout"],
-                   "rng": "philox4x32-10 in-kernel", "auto_reset": True, "parallelism": f"dp{world}",
-                   "agent_steps_per_s": value * A},
+        "config": config_block(spec, args.mode, args.obs, B, world, ticks_per_step, res["layout"], value * A),
         "roofline": roof,
         "episode_metrics": {k: v for k, v in res["metrics"].items() if k != "per_rank_episodes"},
     }
@@ -501,6 +553,18 @@ def main():
                                             + (f"{args.policy_block} ticks per launch (susnet_qnet_policy_rollout)" if args.policy_block > 0 else
                                                "one launch per tick (susnet_qnet_policy_step)"))
         line["config"]["ticks_per_launch"] = max(1, args.policy_block)
+        line["headline_definition"] = (f"cfg5 value = batch x ticks / wall time of the policy loop at {max(1, args.policy_block)} tick(s) per launch with fixed weights "
+                                       "(default 5 = the reference trainer's train_step_interval: rounds 1-3 timed one launch per tick, round 4 blocks of 64 ticks -- "
+                                       "both are in `policy_forms`)")
+        forms = {}
+        for label, blk in (("one_launch_per_tick", 0), ("blocks_of_5_ticks", 5), ("blocks_of_64_ticks", 64)):
+            if blk == args.policy_block:
+                forms[label] = {"value": value, "us_per_tick": res["seconds"] * 1e6 / K, "ticks_per_launch": max(1, blk), "headline": True}
+                continue
+            rp = measure(spec, B, "policy", "flat", 320 if blk else 64, 64 if blk else 16, 1, block_ticks=blk)
+            forms[label] = {"value": B * rp["steps"] / rp["seconds"], "us_per_tick": rp["seconds"] * 1e6 / rp["steps"], "ticks_per_launch": max(1, blk)}
+            del rp
+        line["policy_forms"] = forms
     del res
     secondary = rank == 0 and world == 1 and not args.no_secondary and args.mode != "policy"
     if secondary:
@@ -556,8 +620,8 @@ def main():
                 # one launch per tick (eager, and replayed as hipGraphs of 8 ticks), the torch-module network as the comparison, and the
                 # loop as bench.py --config cfg5 times it: 64 ticks per launch (run_game's loop runs with fixed networks)
                 for label, gt, fused, blk in (("eager", 0, True, 0), ("hip_graph_replay", 8, True, 0), ("torch_modules_hip_graph_replay", 8, False, 0),
-                                              ("blocks_of_64_ticks", 0, True, 64)):
-                    rp = measure(sp, sp["batch"], "policy", "flat", 256 if blk else 64, 64 if blk else 16, 1, graph_ticks=gt, policy_fused=fused, block_ticks=blk)
+                                              ("blocks_of_5_ticks", 0, True, 5), ("blocks_of_64_ticks", 0, True, 64)):
+                    rp = measure(sp, sp["batch"], "policy", "flat", 320 if blk else 64, 64 if blk else 16, 1, graph_ticks=gt, policy_fused=fused, block_ticks=blk)
                     entry[label] = {"value": sp["batch"] * rp["steps"] / rp["seconds"], "us_per_tick": rp["seconds"] * 1e6 / rp["steps"],
                                     "ticks_timed": rp["steps"], **({"ticks_per_graph": gt} if gt else {}), **({"ticks_per_launch": blk} if blk else {})}
                     if rp["qnet"] is not None and (blk or "roofline" not in entry):
@@ -599,9 +663,8 @@ def main():
                                                     "note": "susnet_qnet_policy_rollout: k_qnet_step looping over 64 ticks per launch, replay feed written"}
                     del feed
                 del envc, polc, ring
-                # the loop as the trainer runs it between two optimizer steps (fixed weights): the block launch where the env serves it
-                best = max(("eager", "hip_graph_replay", "blocks_of_64_ticks"), key=lambda k: entry.get(k, {}).get("value", 0.0))
-                entry["value"], entry["value_from"] = entry[best]["value"], best
+                # the loop as the reference trainer runs it between two optimizer steps: 5 ticks with fixed weights (train_step_interval, train.py:295)
+                entry["value"], entry["value_from"] = entry["blocks_of_5_ticks"]["value"], "blocks_of_5_ticks"
                 entry["kernel"] = ("k_qnet_step (float32 Q-network on the f32-input MFMA, argmax, crew draws and the env step as one kernel: one launch per tick -- "
                                    "susnet_qnet_policy_step -- or 64 ticks per launch -- susnet_qnet_policy_rollout)")
                 entry["torch_modules_hip_graph_replay"]["note"] = ("the same tick with the network as torch modules (hipBLASLt f32 GEMMs + PReLU kernels on "
@@ -624,7 +687,8 @@ def main():
     if "other_configs" in line:  # the same numbers in a compact top-level key (the long entries above get truncated in driver records)
         line["others"] = {e["config"]: {"value": e["value"], "frac": (e.get("frac") if "frac" in e else e.get("roofline", {}).get("frac")),
                                         **({"collect_transitions_per_s": e["collect_into_replay_ring"]["value"]} if "collect_into_replay_ring" in e else {}),
-                                        **({"us_per_tick": e["blocks_of_64_ticks"]["us_per_tick"], "launch_per_tick_us": e["eager"]["us_per_tick"]} if "blocks_of_64_ticks" in e else {})}
+                                        **({"us_per_tick": e["blocks_of_5_ticks"]["us_per_tick"], "us_per_tick_blocks_of_64": e["blocks_of_64_ticks"]["us_per_tick"],
+                                            "launch_per_tick_us": e["eager"]["us_per_tick"]} if "blocks_of_64_ticks" in e else {})}
                           for e in line["other_configs"]}
     if world > 1:
         dist.barrier()  # the timed region and its collectives are over on every rank before rank 0 spends host time below

@@ -121,3 +121,27 @@ def test_bench_refuses_a_world_that_differs_from_gpus_under_gloo(tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode != 0
     assert "refusing to report" in p.stderr and '{"metric"' not in p.stdout
+
+
+def test_baseline_config_4_launch_shape_under_gloo():
+    """BASELINE.json configs[3]: `2v6, 14x14 walled grid, batch = 262 144 sharded across 8 x MI355X`.  The exact command --
+    `python bench.py --gpus 8 --config cfg4` as the driver launches it (torch.distributed.run, 8 ranks, 127.0.0.1) -- rehearsed with
+    `--dry-run` under gloo: every rank starts, passes the world check, runs the real run's collectives on host tensors and owns the env
+    ids [r * 32 768, (r + 1) * 32 768); rank 0's line names the whole-job batch and the data-parallel degree.  No device call is made
+    (an 8-GPU node is the driver's to use; this keeps its first real run from being the first time the shape executes)."""
+    import json
+    import subprocess
+
+    bench = _bench_module()
+    env = dict(os.environ, SUSNET_BENCH_BACKEND="gloo")
+    cmd = bench.launch_command(8, _free_port(), ["--gpus", "8", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--dry-run"])
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["dry_run"] is True and line["value"] is None and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert cfg["global_batch"] == 262144 and cfg["batch_per_gpu"] == 32768 and cfg["parallelism"] == "dp8"
+    assert cfg["workload"].startswith("cfg4: FourRoomEnv 2v6, 14x14") and cfg["env_steps_per_bench_step"] == 262144 * 512
+    assert line["shard_first_env_ids"] == [r * 32768 for r in range(8)]

@@ -182,8 +182,8 @@ def test_hip_matches_reference_crc_streams(pkg, name, kernels, monkeypatch):
 
 
 def _tape_layouts():
-    # (the compact 16-byte record exists for the 1v1 game on a grid without walls only)
-    return [(n, lay) for n in crc_names() for lay in ("separate", "packed") + (("compact",) if n.startswith("crc_itg_1v1_nw") else ())]
+    # (the compact 16-byte record exists for the 1v1 game: k_rollout_duel, on the empty grid and -- round 5 -- on the wall map)
+    return [(n, lay) for n in crc_names() for lay in ("separate", "packed") + (("compact",) if n.startswith("crc_itg_1v1_") else ())]
 
 
 @pytest.mark.parametrize("epw", [16, 32, 64])
@@ -692,6 +692,7 @@ def test_long_trajectory_launches_are_chunked(pkg, oracle_mod, monkeypatch):
 
 @pytest.mark.parametrize("name,B,packed", [("base_2v6_j4_14", 32768 + 96, False), ("itg_1v1_nowalls", 65536 + 32, False), ("base_1v2_j4_14", 65536 + 32, False),
                                            ("base_1v2_j4_14", 65536 + 32, True), ("base_2v6_j4_14", 32768, True), ("itg_1v1_nowalls", 65536, "compact"),
+                                           ("itg_1v1_walls", 65536 + 32, "compact"), ("itg_1v1_walls", 65536 + 32, False), ("itg_1v1_walls", 2048, True),
                                            ("tagging_1v4_j5", 4096, False), ("itg_1v5_j3", 2048, False)])
 def test_fused_rollout_large_batches_all_wave_widths(pkg, oracle_mod, name, B, packed):
     """Batches >= 32768 / 65536 run 32 / 64 environments per wave (smaller ones 16): same results.  The BASELINE configurations at the
@@ -1068,6 +1069,7 @@ def test_featurize_matches_oracle_on_tagging_rows(pkg, oracle_mod):
 
 
 @pytest.mark.parametrize("name,comps,B", [("itg_1v1_nowalls", ["onehot_pos"], 1000), ("itg_1v1_nowalls", ["onehot_pos"], 65536 + 40),
+                                          ("itg_1v1_walls", ["onehot_pos"], 1000), ("itg_1v1_walls", ["onehot_pos"], 65536 + 40),  # (experiment_1v1.ipynb: one_hot_wall)
                                           ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], 1000),
                                           ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], 65536 + 8)])
 def test_compiled_in_flat_feature_rollouts_match_the_oracle(pkg, oracle_mod, name, comps, B):
@@ -1080,7 +1082,7 @@ def test_compiled_in_flat_feature_rollouts_match_the_oracle(pkg, oracle_mod, nam
     env.reset()
     ob.reset(threads=0)
     cfg = pkg.ObsConfig("flat", comps)
-    F = {"itg_1v1_nowalls": 36, "base_1v2_j4_14": 88}[name]
+    F = {"itg_1v1_nowalls": 36, "itg_1v1_walls": 36, "base_1v2_j4_14": 88}[name]
     # big batches: the rows of a sample of envs (the first and the last, ragged, waves and a random draw)
     pick = np.arange(B) if B < 4096 else np.unique(np.concatenate([np.arange(256), np.arange(B - 300, B), np.random.default_rng(3).integers(0, B, 600)]))
     for n in (T, 3):
@@ -1692,6 +1694,8 @@ def test_policy_driven_collection_matches_the_reference_trainer_loop(pkg, name):
     meta = g["meta"]
     T, max_size, num_steps = meta["trajectory_size"], meta["max_size"], meta["num_steps"]
     comps = meta["components"]
+    if "kills" in name:  # (round 5) episodes that END: `done` rows whose next_state is the terminal state, then a fresh episode's first row
+        assert int(g["dones"].sum()) >= 15, "the fixture's imposter network chases and kills (generate_collect.py chase_parameters)"
     env = env_from_meta(pkg, meta, 1, rng="numpy", tape_words=1 << 16, auto_reset=True, check_errors=False, obs=pkg.ObsConfig("flat", comps))
     env._reseed([meta["seed"]])
     imp, crew = _collect_models(pkg, g, env.device)

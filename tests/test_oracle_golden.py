@@ -116,3 +116,48 @@ def test_philox_known_answer(oracle_mod):
             want = oracle_mod.philox4x32_10((blk & 0xFFFFFFFF, blk >> 32, e & 0xFFFFFFFF, e >> 32),
                                             (seed & 0xFFFFFFFF, seed >> 32))[d & 3]
             assert words[b, k] == want
+
+
+def _collect_names():
+    import glob
+    import os
+
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "collect_*.npz")))
+
+
+@pytest.mark.parametrize("name", _collect_names())
+def test_oracle_replays_the_reference_collection_ring(oracle_mod, name):
+    """tests/golden/collect_*.npz: the ring the reference's ReplayBuffer holds after the trainer's collection loop (train.py:316-322,
+    345-399, 419-449 around the unmodified env / featurizer / MLPs).  The oracle, from the numpy seed and the recorded actions alone, must
+    rebuild every surviving row: the pre-step state, the post-step state -- the TERMINAL one where the episode ended (`done` rows: the
+    *_kills* fixtures, whose imposter network chases and kills) --, rewards, done, the acting episode's imposters; then a reset where the
+    reference resets (done or truncated)."""
+    g = load_golden(f"{GOLDEN_DIR}/{name}.npz")
+    meta = g["meta"]
+    assert meta["trajectory_size"] == 1
+    ob = oracle_mod.OracleBatch(oracle_mod.config_from_fixture_meta(meta), 1)
+    ob.seed_mt([meta["seed"]])
+    ob.reset()
+    n_steps, max_size = meta["num_steps"], meta["max_size"]
+    first_kept = max(0, n_steps - max_size)
+    ended = 0
+    for s in range(n_steps):
+        row = s % max_size
+        before = ob.obs_raw_u8()[0].astype(np.int16)
+        imps = list(ob.imp_idxs(0))
+        rew, done, trunc, rc = ob.step(g["taken"][s][None].astype(np.int32))
+        assert rc == 0
+        after = ob.obs_raw_u8()[0].astype(np.int16)
+        if s >= first_kept:
+            np.testing.assert_array_equal(g["states"][row, 0], before, err_msg=f"{name} states row {row} (step {s})")
+            np.testing.assert_array_equal(g["next_states"][row, 0], after, err_msg=f"{name} next_states row {row} (step {s})")
+            np.testing.assert_array_equal(g["actions"][row], g["taken"][s], err_msg=f"{name} actions row {row}")
+            assert g["rewards"][row].astype(np.float64).view(np.uint64).tolist() == rew[0].view(np.uint64).tolist(), f"{name} rewards row {row}"
+            assert bool(g["dones"][row]) == bool(done[0]), f"{name} done row {row}"
+            assert sorted(int(i) for i in g["imposters"][row]) == sorted(imps), f"{name} imposters row {row}"
+            ended += int(done[0])
+        if done[0] or trunc[0]:
+            ob.reset()
+    assert ended == int(g["dones"].sum())
+    if "kills" in name:
+        assert ended >= 15
