@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SUSNET_ABI_VERSION 5
+#define SUSNET_ABI_VERSION 6
 
 #define SUSNET_MAX_AGENTS 16
 #define SUSNET_MAX_JOBS 16
@@ -359,6 +359,16 @@ typedef struct susnet_policy_opts {
                         * stream of the handle's Philox key (PHILOX handles only); 0 = greedy */
     int32_t mask_dead; /* != 0: dead agents get index 0 (train.py sets only the living agents' actions); 0: they act like everybody
                         * else (run_game, visualize.py:547-560) -- the step ignores a dead agent's action either way */
+    /* ABI 6 -- the CREW's Q-network inside the one-kernel tick (susnet_qnet_policy_step / susnet_qnet_policy_rollout only; the other
+     * calls take the crew's Q rows as an argument and refuse these fields): run_game drives both teams by their networks
+     * (visualize.py:547-562), train_crew exists (notebooks/experiment.ipynb cell 5).  crew_packed: a susnet_qnet_pack image for the SAME
+     * components as the imposters' network (device, 16-byte aligned), crew_dims / crew_n_dims its layer widths (last = the crew's action
+     * count), crew_q_out: [B][n] float32 (rollout: [T][B][n]) or NULL.  NULL crew_packed = a uniformly random crew.  With both networks and
+     * epsilon = 0 nothing is drawn from the action stream, so numpy-tape (TAPE) handles are served as well. */
+    const float *crew_packed;
+    const int32_t *crew_dims;
+    int32_t crew_n_dims, pad_;
+    float *crew_q_out;
 } susnet_policy_opts;
 int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts /* or NULL */,
                           void *actions_out, int32_t dtype, int32_t layout, void *stream);
@@ -369,8 +379,9 @@ int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float 
  * being written to memory (float32 throughout; layers 2.. on the f32-input matrix instructions, whose result is a k-ordered fmaf
  * chain, so values agree with torch's to float32 summation-order differences).  Served: five Linear layers
  * dims = [F, <=256, <=128, <=64, <=32, <=32] (the reference's [F, 256, 128, 64, 16, n_actions], notebooks/experiment_1v1.ipynb cell 1) on
- * the two compiled-in feature layouts: components {ONEHOT_POS} on the 2-agent 9x9 game (F = 36) and {ONEHOT_POS, ALIVE_CREW,
- * CLOSEST_CREW} on the 3-agent 14x14 game (F = 88).
+ * the compiled-in feature layouts: components {ONEHOT_POS} (F = 36: experiments no_wall / one_hot_wall of notebooks/experiment_1v1.ipynb)
+ * or {COORD_POS} (F = 4, CoordinateAgentPositionsFeaturizer, component.py:384-403: no_wall_coord_features / wall_coord_features) on the
+ * 2-agent 9x9 game, either map, and {ONEHOT_POS, ALIVE_CREW, CLOSEST_CREW} on the 3-agent 14x14 game (F = 88).
  *   susnet_qnet_packed_floats  size of the packed weight image (floats), or SUSNET_E_INVALID when the handle / components / dims are
  *                              not served (callers then run the network themselves and hand Q rows to susnet_policy_actions);
  *   susnet_qnet_pack           HOST: torch-layout weights[l] ([dims[l+1]][dims[l]] row-major), biases[l] ([dims[l+1]]), slopes
@@ -390,8 +401,9 @@ int susnet_step(susnet_env *env, const susnet_step_io *io, void *stream);
  * every other field of io as for susnet_step. */
 int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts /* or NULL */,
                        const susnet_step_io *io, void *stream);
-/* susnet_qnet_forward and susnet_policy_step (imposters by the network, random crew) as ONE kernel -- a whole tick of the acting loop
- * in one launch: the wave that computed its 64 environments' Q rows takes their argmax in registers and steps them.  Arguments as for
+/* susnet_qnet_forward and susnet_policy_step (imposters by the network; the crew random, or by ITS network: opts->crew_packed) as ONE
+ * kernel -- a whole tick of the acting loop in one launch: the wave that computed its 64 environments' Q rows takes their argmax in
+ * registers and steps them (with a crew network the workgroup swaps the LDS image between the two passes).  Arguments as for
  * the two calls; q_out may be NULL (Q rows not kept).  Served: the two compiled-in games the network kernel knows the feature layout of
  * (2-agent 9x9 ImposterTrainingGround; 1v2 14x14 FourRoomEnv with 4 jobs), PHILOX handles; otherwise SUSNET_E_INVALID and the caller
  * uses the two calls. */

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libsusnet_hip.so"
 LIB_PATH = os.environ.get("SUSNET_LIB_PATH", os.path.join(PKG_DIR, LIB_NAME))  # override: A/B experiments only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_AGENTS, MAX_JOBS, MAX_GRID, N_METRICS, N_LIFETIME = 16, 16, 16, 13, 12
 
 VARIANT_BASE, VARIANT_ITG, VARIANT_TAGGING = 0, 1, 2
@@ -98,7 +98,8 @@ class FeedIO(C.Structure):
 
 
 class PolicyOpts(C.Structure):
-    _fields_ = [("epsilon", C.c_float), ("mask_dead", C.c_int32)]
+    _fields_ = [("epsilon", C.c_float), ("mask_dead", C.c_int32), ("crew_packed", C.c_void_p), ("crew_dims", C.POINTER(C.c_int32)),
+                ("crew_n_dims", C.c_int32), ("pad_", C.c_int32), ("crew_q_out", C.c_void_p)]
 
 
 class RecordLayout(C.Structure):

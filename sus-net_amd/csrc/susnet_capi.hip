@@ -873,6 +873,12 @@ static int policy_opts(const susnet_env *env, const susnet_policy_opts *opts, fl
     mask_dead = opts->mask_dead != 0;
     return SUSNET_OK;
 }
+// the crew's network inside the one-kernel tick (susnet_policy_opts.crew_*): everywhere else it must be absent
+static int no_crew_network(const susnet_policy_opts *opts, const char *who) {
+    if (opts && (opts->crew_packed || opts->crew_dims || opts->crew_q_out))
+        return fail(SUSNET_E_INVALID, std::string(who) + ": susnet_policy_opts.crew_* belong to susnet_qnet_policy_step / susnet_qnet_policy_rollout (here the crew's Q rows are an argument)");
+    return SUSNET_OK;
+}
 
 extern "C" int susnet_policy_actions(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts, void *actions_out,
                                      int32_t dtype, int32_t layout, void *stream) {
@@ -884,6 +890,7 @@ extern "C" int susnet_policy_actions(susnet_env *env, const float *q_imposter, c
     float eps;
     int mask_dead;
     if (int rc = policy_opts(env, opts, eps, mask_dead)) return rc;
+    if (int rc = no_crew_network(opts, "susnet_policy_actions")) return rc;
     int64_t sa, sb;
     if (int rc = strides_for(env, layout, sa, sb)) return rc;
     hipLaunchKernelGGL(k_policy_actions, grid_for(env), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->c, env->s, q_imposter, q_crew,
@@ -898,6 +905,7 @@ static int qnet_feat(const susnet_env *env, const int32_t *comp, int32_t ncomp) 
     if (!env || !comp) return 0;
     const Consts &c = env->c;
     if (c.A == 2 && c.N == 9 && ncomp == 1 && comp[0] == SUSNET_F_ONEHOT_POS) return FEAT_ONEHOT;
+    if (c.A == 2 && c.N == 9 && ncomp == 1 && comp[0] == SUSNET_F_COORD_POS) return FEAT_COORD;
     if (c.A == 3 && c.N == 14 && c.n_imp == 1 && ncomp == 3 && comp[0] == SUSNET_F_ONEHOT_POS && comp[1] == SUSNET_F_ALIVE_CREW &&
         comp[2] == SUSNET_F_CLOSEST_CREW)
         return FEAT_ONEHOT_ALIVE_CLOSEST;
@@ -930,14 +938,20 @@ static void qnet_pack(const int32_t *d, const float *const *W, const float *cons
     using Q = QNet<ROW>;
     std::fill(out, out + Q::kPacked, 0.0f);
     // layer 1, transposed: one row per position bit (row kZero stays zero) ...
-    for (int f = 0; f < Q::kOneHot; f++)
-        for (int n = 0; n < d[1]; n++) out[Q::oW1 + f * Q::kRowStride + n] = W[0][(size_t)n * Q::F + f];
+    if constexpr (ROW::kDeadZero) {
+        for (int f = 0; f < Q::kOneHot; f++)
+            for (int n = 0; n < d[1]; n++) out[Q::oW1 + f * Q::kRowStride + n] = W[0][(size_t)n * Q::F + f];
+    } else { // ... the coordinate layout: row (coordinate c, value k) = k x column c of W1 (one float32 rounding, as torch's product has)
+        for (int cc = 0; cc < Q::F; cc++)
+            for (int k = 0; k < ROW::N; k++)
+                for (int n = 0; n < d[1]; n++) out[Q::oW1 + (cc * ROW::N + k) * Q::kRowStride + n] = (float)k * W[0][(size_t)n * Q::F + cc];
+    }
     // ... and one per combination v of the bits behind the one-hots: b1 + the columns of v's set bits, lowest first (float32 sums)
     for (int v = 0; v < (1 << Q::kTailBits); v++)
         for (int n = 0; n < d[1]; n++) {
             float acc = Bv[0][n];
             for (int bit = 0; bit < Q::kTailBits; bit++)
-                if ((v >> bit) & 1) acc += W[0][(size_t)n * Q::F + Q::kOneHot + bit];
+                if ((v >> bit) & 1) acc += W[0][(size_t)n * Q::F + (Q::F - Q::kTailBits) + bit];
             out[Q::oW1 + (Q::kTail + v) * Q::kRowStride + n] = acc;
         }
     const int off_w[4] = {Q::oW2, Q::oW3, Q::oW4, Q::oW5}, off_b[4] = {Q::oB2, Q::oB3, Q::oB4, Q::oB5};
@@ -948,17 +962,22 @@ static void qnet_pack(const int32_t *d, const float *const *W, const float *cons
     }
     for (int l = 0; l < 4; l++) out[Q::oSlope + l] = slopes[l];
 }
-using QRow1 = FlatRow<FEAT_ONEHOT, 2, 9>;
-using QRow3 = FlatRow<FEAT_ONEHOT_ALIVE_CLOSEST, 3, 14>;
+// (the kernels live in translation units of their own: inst_qnet_*.hip)
+namespace susnet {
+SUSNET_QNET_FOR(extern, QRow1, QSpec2)
+SUSNET_QNET_FOR(extern, QRow3, QSpec3)
+SUSNET_QNET_FOR(extern, QRowC, QSpec2)
+}
 
 extern "C" int64_t susnet_qnet_packed_floats(const susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims,
                                              int32_t n_dims) {
     switch (qnet_feat(env, components, n_components)) {
     case FEAT_ONEHOT: if (qnet_dims_ok<QRow1>(dims, n_dims)) return QNet<QRow1>::kPacked; break;
     case FEAT_ONEHOT_ALIVE_CLOSEST: if (qnet_dims_ok<QRow3>(dims, n_dims)) return QNet<QRow3>::kPacked; break;
+    case FEAT_COORD: if (qnet_dims_ok<QRowC>(dims, n_dims)) return QNet<QRowC>::kPacked; break;
     }
     return fail(SUSNET_E_INVALID, "susnet_qnet: served are five Linear layers [F, <=256, <=128, <=64, <=32, <=32] on the compiled-in feature "
-                                  "layouts (onehot_pos on the 2-agent 9x9 game; onehot_pos + alive_crew + closest_crew on the 3-agent 14x14 game)");
+                                  "layouts (onehot_pos or coord_pos on the 2-agent 9x9 game; onehot_pos + alive_crew + closest_crew on the 3-agent 14x14 game)");
 }
 
 extern "C" int susnet_qnet_pack(const susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
@@ -968,21 +987,17 @@ extern "C" int susnet_qnet_pack(const susnet_env *env, const int32_t *components
     if (!weights || !biases || !slopes || !packed) return fail(SUSNET_E_INVALID, "susnet_qnet_pack: null weights / biases / slopes / packed");
     for (int l = 0; l < 5; l++)
         if (!weights[l] || !biases[l]) return fail(SUSNET_E_INVALID, "susnet_qnet_pack: null layer");
-    if (qnet_feat(env, components, n_components) == FEAT_ONEHOT) qnet_pack<QRow1>(dims, weights, biases, slopes, packed);
-    else qnet_pack<QRow3>(dims, weights, biases, slopes, packed);
+    switch (qnet_feat(env, components, n_components)) {
+    case FEAT_ONEHOT: qnet_pack<QRow1>(dims, weights, biases, slopes, packed); break;
+    case FEAT_COORD: qnet_pack<QRowC>(dims, weights, biases, slopes, packed); break;
+    default: qnet_pack<QRow3>(dims, weights, biases, slopes, packed); break;
+    }
     return SUSNET_OK;
 }
 
 template <class ROW>
 static int qnet_launch(susnet_env *env, const float *packed, float *q_out, int n_out, hipStream_t st) {
-    using Q = QNet<ROW>;
-    // ~106 KB of dynamic LDS: above the 64 KB a kernel gets without asking.  The attribute belongs to the CURRENT device's function
-    // object, so it is set before every launch (a host-side table write: cheap; a process-wide "done" flag would leave a second
-    // device without it and race between host threads)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet<ROW>), hipFuncAttributeMaxDynamicSharedMemorySize, Q::kLdsBytes));
-    const unsigned blocks = (unsigned)((env->c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
-    hipLaunchKernelGGL(k_qnet<ROW>, dim3(blocks), dim3(Q::kThreads), Q::kLdsBytes, st, env->c, env->s, packed, q_out, n_out);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY((qnet_launch_k<ROW>(env->c, env->s, packed, q_out, n_out, st)));
     return SUSNET_OK;
 }
 extern "C" int susnet_qnet_forward(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
@@ -991,8 +1006,11 @@ extern "C" int susnet_qnet_forward(susnet_env *env, const int32_t *components, i
     const int64_t n = susnet_qnet_packed_floats(env, components, n_components, dims, n_dims);
     if (n < 0) return (int)n;
     if (!packed || !q_out || (reinterpret_cast<uintptr_t>(packed) & 15u)) return fail(SUSNET_E_INVALID, "susnet_qnet_forward: packed (16-byte aligned) / q_out");
-    if (qnet_feat(env, components, n_components) == FEAT_ONEHOT) return qnet_launch<QRow1>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
-    return qnet_launch<QRow3>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
+    switch (qnet_feat(env, components, n_components)) {
+    case FEAT_ONEHOT: return qnet_launch<QRow1>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
+    case FEAT_COORD: return qnet_launch<QRowC>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
+    default: return qnet_launch<QRow3>(env, packed, q_out, dims[5], static_cast<hipStream_t>(stream));
+    }
 }
 
 // susnet_qnet_policy_step: the network whose kernel also steps (nullptr: a plain / policy step through k_step)
@@ -1001,19 +1019,22 @@ struct QnetFuse {
     const float *packed;
     float *q_out;
     int n_out;
+    // the crew's network (susnet_policy_opts.crew_*), or NULL = a random crew
+    const float *crew_packed;
+    float *crew_q_out;
+    int crew_n_out;
 };
 template <class ROW, class S>
-static int qnet_step_launch(susnet_env *env, const QnetFuse &f, const StepArgs &a, const ObsArgs &o, size_t step_lds, hipStream_t st, int n_ticks, const TickStrides &ts) {
+static int qnet_step_launch(susnet_env *env, bool tape, const QnetFuse &f, const StepArgs &a, const ObsArgs &o, size_t step_lds, hipStream_t st, int n_ticks, const TickStrides &ts) {
     using Q = QNet<ROW>;
     // [table image of the step, shared by the four waves][network image][one region per wave: the rest of a k_step workgroup's LDS]
-    const size_t rest = step_lds - (size_t)kTableWords * 4;
+    const size_t rest = step_lds - (size_t)kTableWords * 4 + (size_t)kStashWords * 4; // (per wave: the teams' greedy actions, then the step's region)
     const size_t sh = (size_t)kTableWords * 4 + (size_t)Q::kLdsBytes + 4 * rest;
     if (sh > 160 * 1024) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: observation too large for the LDS left beside the network image");
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet_step<ROW, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); // (per device: see qnet_launch)
-    const unsigned blocks = (unsigned)((env->c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
-    QStepArgs ka{env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest, n_ticks, ts};
-    hipLaunchKernelGGL((k_qnet_step<ROW, S>), dim3(blocks), dim3(Q::kThreads), sh, st, ka);
-    HIP_TRY(hipGetLastError());
+    QStepArgs ka{env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest, n_ticks, ts, f.crew_packed, f.crew_q_out, f.crew_n_out, 0};
+    if (tape) HIP_TRY((qnet_step_launch_k<ROW, S, TapeRng, true>(ka, sh, st))); // (TAPE: both networks, checked by the caller)
+    else if (f.crew_packed) HIP_TRY((qnet_step_launch_k<ROW, S, PhiloxRng, true>(ka, sh, st)));
+    else HIP_TRY((qnet_step_launch_k<ROW, S, PhiloxRng, false>(ka, sh, st)));
     return SUSNET_OK;
 }
 
@@ -1075,7 +1096,9 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
     CHECK_LDS(sh);
     const dim3 g = grid_for(env), blk(kBlock);
     if (fuse) { // the one-kernel policy tick: the compiled-in games whose feature layout the network kernel knows
-        if (tape) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: the crew draws from the production stream: PHILOX handles only");
+        if (tape && (!fuse->crew_packed || a.epsilon > 0.0f))
+            return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: a random crew and exploration draw from the production stream: PHILOX handles only "
+                                          "(a numpy-tape handle is served with BOTH teams' networks and epsilon = 0: nothing is drawn)");
         if (o.flat_feat != 0) { // the compiled-in feature writer stages 64 bit masks, not the generic writer's byte image
             ObsArgs small = o;
             small.words1 = 64 * 4;
@@ -1085,8 +1108,9 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
         sh = (sh + 15) & ~(size_t)15;
         int rc;
         const TickStrides none = {};
-        if (spec == 3 && fuse->feat == FEAT_ONEHOT_ALIVE_CLOSEST) rc = qnet_step_launch<QRow3, SpecCfg3>(env, *fuse, a, o, sh, st, n_ticks, ts ? *ts : none);
-        else if (spec == 2 && fuse->feat == FEAT_ONEHOT) rc = qnet_step_launch<QRow1, SpecCfg2>(env, *fuse, a, o, sh, st, n_ticks, ts ? *ts : none);
+        if (spec == 3 && fuse->feat == FEAT_ONEHOT_ALIVE_CLOSEST) rc = qnet_step_launch<QRow3, SpecCfg3>(env, tape, *fuse, a, o, sh, st, n_ticks, ts ? *ts : none);
+        else if (spec == 2 && fuse->feat == FEAT_ONEHOT) rc = qnet_step_launch<QRow1, SpecCfg2>(env, tape, *fuse, a, o, sh, st, n_ticks, ts ? *ts : none);
+        else if (spec == 2 && fuse->feat == FEAT_COORD) rc = qnet_step_launch<QRowC, SpecCfg2>(env, tape, *fuse, a, o, sh, st, n_ticks, ts ? *ts : none);
         else return fail(env, SUSNET_E_INVALID, "susnet_qnet_policy_step: served are the two compiled-in games (1v1 9x9 ITG, 1v2 14x14 with 4 jobs)");
         if (rc) return rc;
         env->ticks += (uint64_t)n_ticks;
@@ -1115,7 +1139,28 @@ extern "C" int susnet_step(susnet_env *env, const susnet_step_io *io, void *stre
 extern "C" int susnet_policy_step(susnet_env *env, const float *q_imposter, const float *q_crew, const susnet_policy_opts *opts, const susnet_step_io *io,
                                   void *stream) {
     if (!q_imposter) return fail(SUSNET_E_INVALID, "susnet_policy_step: null q_imposter");
+    if (int rc = no_crew_network(opts, "susnet_policy_step")) return rc;
     return step_impl(env, io, q_imposter, q_crew, stream, nullptr, opts);
+}
+
+// the crew's network of susnet_policy_opts (same components as the imposters'): checked, then into the fuse record
+static int qnet_crew(const susnet_env *env, const int32_t *components, int32_t n_components, const susnet_policy_opts *opts, QnetFuse &f) {
+    f.crew_packed = nullptr;
+    f.crew_q_out = nullptr;
+    f.crew_n_out = 0;
+    if (!opts || !opts->crew_packed) {
+        if (opts && (opts->crew_dims || opts->crew_q_out)) return fail(SUSNET_E_INVALID, "susnet_policy_opts: crew_dims / crew_q_out without crew_packed");
+        return SUSNET_OK;
+    }
+    const int64_t n = susnet_qnet_packed_floats(env, components, n_components, opts->crew_dims, opts->crew_n_dims);
+    if (n < 0) return (int)n;
+    if (reinterpret_cast<uintptr_t>(opts->crew_packed) & 15u) return fail(SUSNET_E_INVALID, "susnet_policy_opts: crew_packed must be 16-byte aligned");
+    if (opts->crew_dims[5] != env->layout.n_actions_crew)
+        return fail(SUSNET_E_INVALID, "susnet_policy_opts: the crew network's output width must be the crew's action count");
+    f.crew_packed = opts->crew_packed;
+    f.crew_q_out = opts->crew_q_out;
+    f.crew_n_out = opts->crew_dims[5];
+    return SUSNET_OK;
 }
 
 extern "C" int susnet_qnet_policy_step(susnet_env *env, const int32_t *components, int32_t n_components, const int32_t *dims, int32_t n_dims,
@@ -1126,7 +1171,8 @@ extern "C" int susnet_qnet_policy_step(susnet_env *env, const int32_t *component
     if (!packed || (reinterpret_cast<uintptr_t>(packed) & 15u)) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: packed (16-byte aligned)");
     if (dims[5] != env->layout.n_actions_imposter)
         return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: the network's output width must be the imposters' action count");
-    const QnetFuse f = {qnet_feat(env, components, n_components), packed, q_out, dims[5]};
+    QnetFuse f = {qnet_feat(env, components, n_components), packed, q_out, dims[5], nullptr, nullptr, 0};
+    if (int rc = qnet_crew(env, components, n_components, opts, f)) return rc;
     return step_impl(env, io, nullptr, nullptr, stream, &f, opts);
 }
 
@@ -1163,8 +1209,9 @@ extern "C" int susnet_qnet_policy_rollout(susnet_env *env, const int32_t *compon
     io.obs = feed->obs ? &obs : nullptr;
     io.term_obs = feed->term_obs;
     io.roles = feed->roles;
-    const TickStrides ts = {B * A, B * A * 4, B, B, B * S, B * 2, B * (int64_t)dims[5] * 4};
-    const QnetFuse f = {qnet_feat(env, components, n_components), packed, feed->q, dims[5]};
+    QnetFuse f = {qnet_feat(env, components, n_components), packed, feed->q, dims[5], nullptr, nullptr, 0};
+    if (int rc = qnet_crew(env, components, n_components, opts, f)) return rc;
+    const TickStrides ts = {B * A, B * A * 4, B, B, B * S, B * 2, B * (int64_t)dims[5] * 4, B * (int64_t)f.crew_n_out * 4};
     return step_impl(env, &io, nullptr, nullptr, stream, &f, opts, n_ticks, &ts);
 }
 

@@ -19,12 +19,16 @@
 
 namespace susnet {
 
-enum : int { FEAT_ONEHOT = 1, FEAT_ONEHOT_ALIVE_CLOSEST = 2 };
+enum : int { FEAT_ONEHOT = 1, FEAT_ONEHOT_ALIVE_CLOSEST = 2, FEAT_COORD = 3 };
 
 template <int FEAT, int A_, int N_>
 struct FlatRow {
     static constexpr int A = A_, N = N_, kOneHot = A * 2 * N;
     static constexpr int F = kOneHot + (FEAT == FEAT_ONEHOT_ALIVE_CLOSEST ? 2 * (A - 1) : 0);
+    // what the Q-network kernel (susnet_qnet.h) needs to know of a layout: the bits behind the position one-hots, and that a dead agent's
+    // positions are all zero (component.py:226-240)
+    static constexpr int kTailBits = F - kOneHot;
+    static constexpr bool kDeadZero = true;
     static_assert(F % 4 == 0 && A >= 2 && N <= 16, "float4 chunks must not straddle rows");
     static constexpr int MW = (F + 31) / 32; // mask words per row
     static constexpr int C = F / 4;          // float4 chunks per row
@@ -70,6 +74,19 @@ struct FlatRow {
             static_for_agents<I + 1>(x, y, alive);
         }
     }
+};
+
+// CoordinateAgentPositionsFeaturizer (src/features/component.py:384-403): the row [x0, y0, x1, y1, ...] as floats, NOT zeroed for a dead
+// agent -- the layout of the reference's `no_wall_coord_features` / `wall_coord_features` experiments (notebooks/experiment_1v1.ipynb).
+// Not a 0/1 row, so it has no bit-mask writer here (the generic observation writer serves it); it exists for the Q-network kernel, whose
+// first layer then gathers one LDS row per COORDINATE VALUE -- k times the coordinate's column of W1, multiplied on the host -- with
+// the very instructions that gather the one-hot layouts' columns: `kOneHot` counts those rows, F is the network's input width.
+template <int A_, int N_>
+struct CoordRow {
+    static constexpr int A = A_, N = N_, kOneHot = A * 2 * N, F = 2 * A, kTailBits = 0;
+    static constexpr bool kDeadZero = false;
+    uint32_t m[1];
+    __device__ __forceinline__ void build(const uint32_t (&)[A], const uint32_t (&)[A], const uint32_t (&)[A]) { m[0] = 0u; }
 };
 
 // The wave's rows -> [nrows][F] float32 at byte offset `base` of the buffer `r` (rows of lanes >= nrows are not written).

@@ -165,8 +165,9 @@ __device__ __forceinline__ void finish_rng(const State &s, int64_t b, const RNG 
 // obs_tick: which [B][F] slot of the observation output this step writes (o.tick_stride elements apart: the multi-tick policy kernel)
 // TABLES = false: the caller has filled the table image already (the multi-tick policy kernel: once per launch, before its barrier)
 template <class RNG, class S, bool TABLES = true>
+// pre_crew >= 0 (with pre_imp): the crew's greedy action too (both teams by their networks: nothing is drawn unless agents explore)
 __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const StepArgs &a, const ObsArgs &o, uint32_t *smem, uint32_t *rest, int tid, int64_t b0,
-                                          int pre_imp, int64_t obs_tick = 0) {
+                                          int pre_imp, int64_t obs_tick = 0, int pre_crew = -1) {
     const int64_t b = b0 + tid;
     const bool active = b < c.B;
     typename StoreFor<S>::type st;
@@ -208,7 +209,8 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
         uint32_t bits = 0;
         const uint64_t step_tick = uniform64(tick_word);
         if (policy) { // visualize.py:547-562: every agent takes its team's argmax (first maximum, like torch.argmax)
-            uint32_t a_imp = 0, a_crew = a.q_crew != nullptr ? 0u : ~0u;
+            const bool crew_net = a.q_crew != nullptr || pre_crew >= 0; // (wave-uniform) the crew acts by a network, not by draws
+            uint32_t a_imp = 0, a_crew = crew_net ? 0u : ~0u;
             float hi = qi[0], hc = qc[0];
 #pragma unroll
             for (int k = 1; k < kMaxPolicyActions; k++) {
@@ -216,6 +218,7 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
                 if (a.q_crew != nullptr && k < a.n_qc && qc[k] > hc) { hc = qc[k]; a_crew = (uint32_t)k; }
             }
             if (pre_imp >= 0) a_imp = (uint32_t)pre_imp;
+            if (pre_crew >= 0) a_crew = (uint32_t)pre_crew;
             if constexpr (!RNG::kNumpy) {
                 ActionStream pas, xs;
                 pas.init();
@@ -224,7 +227,7 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
                                                                    a_imp, a_crew, a.epsilon, e.alive, (uint32_t)a.mask_dead, &rng, &xs, step_tick * (uint64_t)A};
                 // the stream's draws are needed by a random crew and by exploration; they are made for EVERY agent (a word's digits
                 // depend on the draws before them)
-                if (a.q_crew != nullptr && !(a.epsilon > 0.0f)) {
+                if (crew_net && !(a.epsilon > 0.0f)) {
                     for (int i = 0; i < A; i++) sink.set_act(i, 0u);
                 } else {
                     sample_actions_env<S>(c, sink, e, rng, pas, step_tick);

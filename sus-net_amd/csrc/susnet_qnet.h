@@ -43,7 +43,8 @@ struct QNet {
     // all zeros (a dead agent's positions, component.py:226-240); rows kTail + v = b1 + the W1 columns of the set bits of v, v = the
     // row's bits BEHIND the one-hots (alive flags, closest crew: 2^kTailBits combinations, summed on the host; no such bits: just b1).
     // h1 = sum of 2 A position rows + ONE tail row: 2 A + 1 LDS reads per 16-byte slice instead of one per set bit + bias.
-    static constexpr int kOneHot = ROW::kOneHot, kTailBits = F - kOneHot, kZero = kOneHot, kTail = kOneHot + 1;
+    // (the coordinate layout, susnet_flat.h CoordRow: the "one-hot" rows are k x the coordinate's W1 column for every value k, no tail bits)
+    static constexpr int kOneHot = ROW::kOneHot, kTailBits = ROW::kTailBits, kZero = kOneHot, kTail = kOneHot + 1;
     static constexpr int kGather = 2 * ROW::A + 1;
     static constexpr int kRows = kTail + (1 << kTailBits);
     static constexpr int kRowStride = H1 + 4; // floats: consecutive rows start 4 banks apart
@@ -164,14 +165,15 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
         row.build(fx, fy, fal);
         uint32_t tail = 0;
         if constexpr (Q::kTailBits > 0) {
-            static_assert(Q::kOneHot / 32 == (Q::F - 1) / 32, "the tail bits sit in one mask word");
+            static_assert(Q::kOneHot / 32 == (Q::kOneHot + Q::kTailBits - 1) / 32, "the tail bits sit in one mask word");
             tail = (row.m[Q::kOneHot / 32] >> (Q::kOneHot & 31)) & ((1u << Q::kTailBits) - 1u);
         }
         rowp[t][0] = w1 + (Q::kTail + tail) * Q::kRowStride + 4 * h;
 #pragma unroll
         for (int i = 0; i < ROW::A; i++) { // component.py:226-240: [onehot_N(x) | onehot_N(y)] per agent, zeros if dead
-            rowp[t][1 + 2 * i] = w1 + (fal[i] ? (uint32_t)(i * 2 * ROW::N) + fx[i] : (uint32_t)Q::kZero) * Q::kRowStride + 4 * h;
-            rowp[t][2 + 2 * i] = w1 + (fal[i] ? (uint32_t)(i * 2 * ROW::N + ROW::N) + fy[i] : (uint32_t)Q::kZero) * Q::kRowStride + 4 * h;
+            const bool there = fal[i] != 0u || !ROW::kDeadZero; // (coordinates are not zeroed for a dead agent, component.py:389-399)
+            rowp[t][1 + 2 * i] = w1 + (there ? (uint32_t)(i * 2 * ROW::N) + fx[i] : (uint32_t)Q::kZero) * Q::kRowStride + 4 * h;
+            rowp[t][2 + 2 * i] = w1 + (there ? (uint32_t)(i * 2 * ROW::N + ROW::N) + fy[i] : (uint32_t)Q::kZero) * Q::kRowStride + 4 * h;
         }
     }
 
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk
 #define SUSNET_TICK_FENCE_SCOPE "wavefront"
 #endif
 struct TickStrides {
-    int64_t actions, rewards, done, trunc, term_obs, roles, q; // bytes
+    int64_t actions, rewards, done, trunc, term_obs, roles, q, q_crew; // bytes
 };
 // All the arguments as ONE by-value struct, so the kernel can re-read them from the kernel-argument segment inside the tick loop (scalar
 // loads through a pointer the optimiser cannot see through) instead of carrying ~100 scalar registers across the Q-network, where every
@@ -350,6 +352,11 @@ struct QStepArgs {
     ObsArgs o;
     int step_lds_bytes, n_ticks;
     TickStrides ts;
+    // the CREW's network (run_game drives both teams by their networks, visualize.py:547-562; train_crew, notebooks/experiment.ipynb cell 5):
+    // a second packed image of the same feature layout, or NULL = the crew draws from the action stream
+    const float *pk_crew;
+    float *q_crew_out;
+    int n_out_crew, pad_;
 };
 typedef __attribute__((address_space(4))) const char *KernargPtr;
 template <class T>
@@ -360,7 +367,36 @@ __device__ __forceinline__ T kernarg_read(KernargPtr base, size_t off) {
 }
 #define SUSNET_KARG(base, field) kernarg_read<decltype(QStepArgs::field)>(base, offsetof(QStepArgs, field))
 
-template <class ROW, class S>
+// The network image of a packed network -> LDS, all 256 threads: every load in flight before the first write (one memory round trip)
+// tid: the thread's index in the workgroup -- inside a tick loop an OPAQUE copy (the per-thread addresses and range tests below are loop
+// invariants: hoisted, they would be held across the matrix section)
+template <class ROW>
+__device__ __forceinline__ void qnet_fill_image(const float *pk, float *w1, int tid) {
+    using Q = QNet<ROW>;
+    constexpr int kFill = (Q::kLdsFloats / 4 + Q::kThreads - 1) / Q::kThreads;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(pk);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(w1);
+    f32x4 tmp[kFill];
+#pragma unroll
+    for (int i = 0; i < kFill; i++) {
+        const int k = tid + Q::kThreads * i;
+        tmp[i] = src[k < Q::kLdsFloats / 4 ? k : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < kFill; i++) {
+        const int k = tid + Q::kThreads * i;
+        if (k < Q::kLdsFloats / 4) dst[k] = tmp[i];
+    }
+}
+
+// BOTH TEAMS by their networks (pk_crew != NULL): per tick the workgroup runs the imposters' network, swaps the LDS image for the crew's
+// (two barriers: everybody has read the old image / the new one is complete), runs the crew's, and each wave steps its environments with
+// both argmaxes; the next tick swaps back.  Waves past the batch stay in the loop for the fills and barriers (they hold no environment:
+// no network pass, no step).  With the crew's network and no exploration nothing is drawn from the action stream, so numpy-tape handles
+// are served too (RNG = TapeRng: the reference's collection loop with two networks, tests/golden/collect_*.npz).
+// TWO: both networks (a kernel of its own: the one-network tick keeps its register budget).
+constexpr int kStashWords = 128; // per wave, in front of its step region: the two teams' greedy actions across the network passes
+template <class ROW, class S, class RNG = PhiloxRng, bool TWO = false>
 __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
     using Q = QNet<ROW>;
     // dynamic LDS: [the step's table image, at address 0: its readers use absolute addresses][the network image][4 wave regions]
@@ -369,71 +405,80 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
     static_assert((kTableWords * 4) % 16 == 0, "the network image is copied in 16-byte pieces");
     const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t b00 = ((int64_t)blockIdx.x * 4 + wave0) * Q::kEnvsPerWave;
-    {
-        const float *pk = ka.pk;
-        constexpr int kFill = (Q::kLdsFloats / 4 + Q::kThreads - 1) / Q::kThreads;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(pk);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(w1);
-        f32x4 tmp[kFill];
-#pragma unroll
-        for (int i = 0; i < kFill; i++) {
-            const int k = (int)threadIdx.x + Q::kThreads * i;
-            tmp[i] = src[k < Q::kLdsFloats / 4 ? k : 0];
-        }
-#pragma unroll
-        for (int i = 0; i < kFill; i++) {
-            const int k = (int)threadIdx.x + Q::kThreads * i;
-            if (k < Q::kLdsFloats / 4) dst[k] = tmp[i];
-        }
-    }
+    qnet_fill_image<ROW>(ka.pk, w1, (int)threadIdx.x);
     // the step's table image (launch-constant): written ONCE, by the first wave, and published to the other three by the barrier -- no
-    // wave writes LDS words another one reads after this point
+    // wave writes LDS words another one reads after this point (but for the image swaps of TWO, which have barriers of their own)
     if (wave0 == 0) {
         TableLoad<true> tl;
         tl.issue(ka.c, ka.o.comp, lane0);
         tl.commit(dyn, lane0, true);
     }
     __syncthreads();
-    if (b00 >= ka.c.B) return; // (after the only barrier; the step below synchronises inside the wave only)
-    bool unit = true;
-#pragma unroll
-    for (int l = 0; l < 4; l++) unit = unit && ka.pk[Q::oSlope + l] >= 0.0f && ka.pk[Q::oSlope + l] <= 1.0f;
+    const bool live = b00 < ka.c.B;
+    if (!TWO && !live) return; // (one network: no barrier past this point; the step below synchronises inside the wave only)
     const int n_ticks = ka.n_ticks;
+    // one network pass of my 64 environments (pass 0: the imposters' network, 1: the crew's); the greedy action goes to the wave's stash
+    // in LDS -- not a register: every vector register is spoken for inside qnet_wave, and a value carried across it costs scratch
+    auto net_pass = [&](int pass, int k) __attribute__((always_inline)) {
+        // (the optimiser would otherwise hoist every lane-dependent invariant of the step -- table-fill addresses, LDS offsets, ~150
+        // vector registers of them -- out of the tick loop and keep them across the Q-network; an opaque copy of the lane id per use
+        // site makes them per-tick values again)
+        int lane = lane0, wave = wave0;
+        int64_t b0 = b00;
+        KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp), "+v"(lane), "+s"(wave), "+s"(b0));
+        const Consts &c = ka.c; // (the tables: read in place)
+        const auto *agent = SUSNET_KARG(kp, s.agent);
+        const float *pk = pass ? SUSNET_KARG(kp, pk_crew) : SUSNET_KARG(kp, pk);
+        float *q_out = pass ? SUSNET_KARG(kp, q_crew_out) : SUSNET_KARG(kp, q_out);
+        const int n_out = pass ? SUSNET_KARG(kp, n_out_crew) : SUSNET_KARG(kp, n_out);
+        const int64_t qstride = pass ? SUSNET_KARG(kp, ts.q_crew) : SUSNET_KARG(kp, ts.q);
+        const int step_lds_bytes = SUSNET_KARG(kp, step_lds_bytes);
+        bool unit = true; // wave-uniform: scalar loads and compares
+#pragma unroll
+        for (int l = 0; l < 4; l++) unit = unit && pk[Q::oSlope + l] >= 0.0f && pk[Q::oSlope + l] <= 1.0f;
+        uint32_t aw[2][ROW::A];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int64_t b = b0 + 32 * t + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < ROW::A; i++) { // (rows are padded to Bp: no branch around the load -- see qnet_wave's epilogue)
+                const uint32_t wv = (uint32_t)agent[(size_t)i * c.Bp + b];
+                aw[t][i] = b < c.B ? wv : 0u;
+            }
+        }
+        float *qk = q_out ? reinterpret_cast<float *>(reinterpret_cast<char *>(q_out) + (int64_t)k * qstride) : nullptr;
+        const uint32_t am = unit ? qnet_wave<ROW, true>(c, aw, pk, w1, qk, n_out, b0, lane) : qnet_wave<ROW, false>(c, aw, pk, w1, qk, n_out, b0, lane);
+        int lane_s = lane0; // (a fresh copy: nothing lane-derived crosses the matrix section)
+        asm volatile("" : "+v"(lane_s));
+        uint32_t *stash = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
+        stash[(pass ? 64 : 0) + lane_s] = am;
+    };
 #pragma clang loop unroll(disable)
     for (int k = 0; k < n_ticks; k++) {
         if (k > 0) { // what this wave stored at tick k - 1 (its environments' state) is what it loads now
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, SUSNET_TICK_FENCE_SCOPE);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SUSNET_TICK_FENCE_SCOPE);
         }
-        // (the optimiser would otherwise hoist every lane-dependent invariant of the step -- table-fill addresses, LDS offsets, ~150
-        // vector registers of them -- out of the tick loop and keep them across the Q-network; an opaque copy of the lane id per use
-        // site makes them per-tick values again)
-        uint32_t a_imp;
-        {
-            int lane = lane0;
-            int64_t b0 = b00;
-            KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(kp), "+v"(lane), "+s"(b0));
-            const Consts &c = ka.c; // (the tables: read in place)
-            const auto *agent = SUSNET_KARG(kp, s.agent);
-            const float *pk = SUSNET_KARG(kp, pk);
-            float *q_out = SUSNET_KARG(kp, q_out);
-            const int n_out = SUSNET_KARG(kp, n_out);
-            const int64_t qstride = SUSNET_KARG(kp, ts.q);
-            uint32_t aw[2][ROW::A];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int64_t b = b0 + 32 * t + (lane & 31);
-#pragma unroll
-                for (int i = 0; i < ROW::A; i++) { // (rows are padded to Bp: no branch around the load -- see qnet_wave's epilogue)
-                    const uint32_t wv = (uint32_t)agent[(size_t)i * c.Bp + b];
-                    aw[t][i] = b < c.B ? wv : 0u;
+        if constexpr (!TWO) {
+            net_pass(0, k);
+        } else {
+#pragma clang loop unroll(disable)
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass > 0 || k > 0) { // the other team's image: every wave has read the one that is there; nobody reads before it is whole
+                    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(kp));
+                    const float *pk = pass ? SUSNET_KARG(kp, pk_crew) : SUSNET_KARG(kp, pk);
+                    int tid_f = wave0 * 64 + lane0;
+                    asm volatile("" : "+v"(tid_f));
+                    __syncthreads();
+                    qnet_fill_image<ROW>(pk, w1, tid_f);
+                    __syncthreads();
                 }
+                if (live) net_pass(pass, k);
             }
-            float *qk = q_out ? reinterpret_cast<float *>(reinterpret_cast<char *>(q_out) + (int64_t)k * qstride) : nullptr;
-            a_imp = unit ? qnet_wave<ROW, true>(c, aw, pk, w1, qk, n_out, b0, lane) : qnet_wave<ROW, false>(c, aw, pk, w1, qk, n_out, b0, lane);
         }
-        {
+        if (live) {
             int lane = lane0, wave = wave0;
             int64_t b0 = b00;
             KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -444,7 +489,10 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
             const ObsArgs &o = ka.o; // (a component list indexed at run time: read in place)
             const TickStrides ts = SUSNET_KARG(kp, ts);
             const int step_lds_bytes = SUSNET_KARG(kp, step_lds_bytes);
-            uint32_t *rest = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
+            uint32_t *stash = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
+            wave_lds_publish();
+            const int a_imp = (int)stash[lane], a_crew = TWO ? (int)stash[64 + lane] : -1;
+            uint32_t *rest = stash + kStashWords;
             auto shift = [&](auto *p, int64_t bytes) __attribute__((always_inline)) { return p ? reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + (int64_t)k * bytes) : p; };
             ak.actions = ak.actions ? static_cast<const void *>(static_cast<const char *>(ak.actions) + (int64_t)k * ts.actions) : nullptr;
             ak.rewards.ptr = ak.rewards.ptr ? static_cast<void *>(static_cast<char *>(ak.rewards.ptr) + (int64_t)k * ts.rewards) : nullptr;
@@ -453,10 +501,42 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
             ak.term_obs = shift(ak.term_obs, ts.term_obs);
             ak.roles = shift(ak.roles, ts.roles);
             ak.tick = ak.tick + (uint64_t)k;
-            step_wave<PhiloxRng, S, false>(c, s, ak, o, dyn, rest, lane, b0, (int)a_imp, (int64_t)k);
+            step_wave<RNG, S, false>(c, s, ak, o, dyn, rest, lane, b0, a_imp, (int64_t)k, a_crew);
         }
     }
 }
 #undef SUSNET_KARG
+
+// ---- launchers: one translation unit per feature layout (inst_qnet_*.hip: these kernels are the library's largest), declared to the host
+// side (susnet_capi.hip) as extern templates
+template <class ROW>
+hipError_t qnet_launch_k(const Consts &c, const State &s, const float *packed, float *q_out, int n_out, hipStream_t st) {
+    using Q = QNet<ROW>;
+    // ~106 KB of dynamic LDS: above the 64 KB a kernel gets without asking.  The attribute belongs to the CURRENT device's function
+    // object, so it is set before every launch (a host-side table write: cheap; a process-wide "done" flag would leave a second
+    // device without it and race between host threads)
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet<ROW>), hipFuncAttributeMaxDynamicSharedMemorySize, Q::kLdsBytes)) return e;
+    const unsigned blocks = (unsigned)((c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
+    hipLaunchKernelGGL(k_qnet<ROW>, dim3(blocks), dim3(Q::kThreads), Q::kLdsBytes, st, c, s, packed, q_out, n_out);
+    return hipGetLastError();
+}
+template <class ROW, class S, class RNG, bool TWO>
+hipError_t qnet_step_launch_k(const QStepArgs &ka, size_t lds_bytes, hipStream_t st) {
+    using Q = QNet<ROW>;
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qnet_step<ROW, S, RNG, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
+    const unsigned blocks = (unsigned)((ka.c.B + Q::kEnvsPerBlock - 1) / Q::kEnvsPerBlock);
+    hipLaunchKernelGGL((k_qnet_step<ROW, S, RNG, TWO>), dim3(blocks), dim3(Q::kThreads), lds_bytes, st, ka);
+    return hipGetLastError();
+}
+using QRow1 = FlatRow<FEAT_ONEHOT, 2, 9>;                  // `onehot_pos` on the 1v1 9x9 game
+using QRow3 = FlatRow<FEAT_ONEHOT_ALIVE_CLOSEST, 3, 14>;   // `onehot_pos + alive_crew + closest_crew` on the 1v2 14x14 game
+using QRowC = CoordRow<2, 9>;                              // `coord_pos` on the 1v1 9x9 game
+using QSpec2 = Spec<2, 0, SUSNET_VARIANT_ITG, 0, 0, 1>;
+using QSpec3 = Spec<3, 4, SUSNET_VARIANT_BASE, 1, -1, 1>;
+#define SUSNET_QNET_FOR(X, ROW, SPEC)                                                                                  \
+    X template hipError_t qnet_launch_k<ROW>(const Consts &, const State &, const float *, float *, int, hipStream_t); \
+    X template hipError_t qnet_step_launch_k<ROW, SPEC, PhiloxRng, false>(const QStepArgs &, size_t, hipStream_t);    \
+    X template hipError_t qnet_step_launch_k<ROW, SPEC, PhiloxRng, true>(const QStepArgs &, size_t, hipStream_t);     \
+    X template hipError_t qnet_step_launch_k<ROW, SPEC, TapeRng, true>(const QStepArgs &, size_t, hipStream_t);
 
 } // namespace susnet

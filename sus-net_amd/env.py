@@ -472,11 +472,18 @@ class BatchedFourRoomEnv:
         return buf
 
     @staticmethod
-    def _policy_opts(epsilon: float, mask_dead: bool):
-        """susnet_policy_opts pointer (None = greedy, dead agents act like everybody else)."""
-        if not epsilon and not mask_dead:
+    def _policy_opts(epsilon: float, mask_dead: bool, net_crew: "Optional[PackedQNet]" = None, crew_q_out: Optional[torch.Tensor] = None):
+        """susnet_policy_opts pointer (None = greedy, dead agents act like everybody else, a random crew).  ``net_crew``: the crew's packed
+        network for the one-kernel tick (``crew_q_out``: where its Q rows go, or None)."""
+        if not epsilon and not mask_dead and net_crew is None:
             return None
-        return C.byref(L.PolicyOpts(float(epsilon), 1 if mask_dead else 0))
+        o = L.PolicyOpts(float(epsilon), 1 if mask_dead else 0)
+        if net_crew is not None:
+            o.crew_packed, o.crew_dims, o.crew_n_dims = net_crew.packed.data_ptr(), net_crew.cdims, len(net_crew.dims)
+            if crew_q_out is not None:
+                assert crew_q_out.dtype == torch.float32 and crew_q_out.is_contiguous() and crew_q_out.shape[-1] == net_crew.dims[-1]
+                o.crew_q_out = crew_q_out.data_ptr()
+        return C.byref(o)
 
     def policy_actions(self, q_imposter: torch.Tensor, q_crew: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                        epsilon: float = 0.0, mask_dead: bool = False) -> torch.Tensor:
@@ -609,10 +616,15 @@ class BatchedFourRoomEnv:
                 self.poll_errors()
         return self._state_tuple(), self._rewards_view, self._done, self._trunc, self.metrics.get_metrics(), buf
 
-    def supports_qnet_policy_step(self, net: "PackedQNet") -> bool:
-        """Whether ``qnet_policy_step`` serves this env: the compiled-in 1v1 9x9 ITG / 1v2 14x14 4-job games on the production stream
-        (a packed record layout exists exactly for the compiled-in games, and among them the agent count names the game)."""
-        if self.rng_kind != "philox" or net.dims[-1] != self.n_imposter_actions:
+    def supports_qnet_policy_step(self, net: "PackedQNet", net_crew: "Optional[PackedQNet]" = None, epsilon: float = 0.0) -> bool:
+        """Whether ``qnet_policy_step`` serves this env: the compiled-in 1v1 9x9 ITG / 1v2 14x14 4-job games (a packed record layout exists
+        exactly for the compiled-in games, and among them the agent count names the game) on the production stream -- or, with the crew's
+        network too (``net_crew``) and no exploration, on numpy tapes as well: nothing is drawn then."""
+        if net is None or net.dims[-1] != self.n_imposter_actions:
+            return False
+        if net_crew is not None and (net_crew.dims[-1] != self.n_crew_actions or list(net_crew.components) != list(net.components)):
+            return False
+        if self.rng_kind != "philox" and (net_crew is None or epsilon > 0.0):
             return False
         lay = self.record_layout()
         if lay is None or lay.n_obs_segments != 1:  # (one observation segment: a fully compiled-in game, not a family kernel)
@@ -620,10 +632,10 @@ class BatchedFourRoomEnv:
         return (self.VARIANT, self.n_agents, self.n_jobs, self.n_rows) in ((L.VARIANT_ITG, 2, 0, 9), (L.VARIANT_BASE, 3, 4, 14))
 
     def qnet_policy_step(self, net: "PackedQNet", actions_out: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None,
-                         epsilon: float = 0.0, mask_dead: bool = False):
+                         epsilon: float = 0.0, mask_dead: bool = False, net_crew: "Optional[PackedQNet]" = None, q_crew_out: Optional[torch.Tensor] = None):
         """A whole tick of the acting loop in ONE kernel (``susnet_qnet_policy_step``): the imposters' network (``net``), its argmax, the
-        crew's random draws and the step.  Returns like ``policy_step``; raises ``RuntimeError`` where the library does not serve the
-        configuration (callers fall back to ``qnet_forward`` + ``policy_step``)."""
+        crew's random draws -- or the crew's own network, ``net_crew`` -- and the step.  Returns like ``policy_step``; raises ``RuntimeError``
+        where the library does not serve the configuration (callers fall back to ``qnet_forward`` + ``policy_step``)."""
         if actions_out is None:
             if getattr(self, "_policy_actions_buf", None) is None:
                 self._policy_actions_buf = torch.zeros(self.batch, self.n_agents, dtype=torch.int64, device=self.device)
@@ -635,8 +647,8 @@ class BatchedFourRoomEnv:
         io.actions, io.actions_dtype, io.actions_layout = buf.data_ptr(), dtype, layout
         with self._on_device():
             L.check(self.lib.susnet_qnet_policy_step(self._h, net.components, len(net.components), net.cdims, len(net.dims), net.packed.data_ptr(),
-                                                     q_out.data_ptr() if q_out is not None else None, self._policy_opts(epsilon, mask_dead), C.byref(io),
-                                                     self._stream()))
+                                                     q_out.data_ptr() if q_out is not None else None, self._policy_opts(epsilon, mask_dead, net_crew, q_crew_out),
+                                                     C.byref(io), self._stream()))
             if self.export_state:
                 self._export(full=False)
             if self.check_errors:
@@ -687,9 +699,11 @@ class BatchedFourRoomEnv:
         io.actions, io.rewards = feed["actions"][t].data_ptr(), feed["rewards"][t].data_ptr()
         io.done, io.truncated = feed["done"][t].data_ptr(), feed["truncated"][t].data_ptr()
         io.term_obs, io.roles = feed["term_obs"][t].data_ptr(), feed["roles"][t].data_ptr()
-        opts = self._policy_opts(epsilon, mask_dead)
+        one_kernel = (net_imposter is not None and q_imposter is None and q_crew is None and
+                      self.supports_qnet_policy_step(net_imposter, net_crew, epsilon))
+        opts = self._policy_opts(epsilon, mask_dead, net_crew if one_kernel else None)
         with self._on_device():
-            if net_imposter is not None and net_crew is None and q_crew is None and self.supports_qnet_policy_step(net_imposter):
+            if one_kernel:
                 if q_out is not None:  # (the one-kernel tick can also emit the Q rows it acted on)
                     assert q_out.dtype == torch.float32 and tuple(q_out.shape) == (self.batch, net_imposter.dims[-1]) and q_out.is_contiguous()
                 L.check(self.lib.susnet_qnet_policy_step(self._h, net_imposter.components, len(net_imposter.components), net_imposter.cdims,
@@ -706,12 +720,12 @@ class BatchedFourRoomEnv:
                 slot.copy_(bounce)
 
     def policy_rollout_into(self, feed: Dict[str, torch.Tensor], n_ticks: int, net_imposter: "PackedQNet", epsilon: float = 0.0, mask_dead: bool = True,
-                            q_out: Optional[torch.Tensor] = None) -> None:
+                            q_out: Optional[torch.Tensor] = None, net_crew: "Optional[PackedQNet]" = None, q_crew_out: Optional[torch.Tensor] = None) -> None:
         """``n_ticks`` policy ticks (slots 0 .. n_ticks - 1 of ``feed``) in ONE launch (``susnet_qnet_policy_rollout``): what ``policy_tick_into``
         does per tick, with the network image loaded and the launch paid once -- the acting loop between two optimizer steps.  Needs
         ``supports_qnet_policy_step(net_imposter)`` (a compiled-in game, the production stream, a random crew)."""
-        assert self.auto_reset and self.supports_qnet_policy_step(net_imposter) and 1 <= n_ticks <= feed["n_ticks"]
-        assert feed["obs"][0].data_ptr() % 16 == 0 and (self.batch * self.flattened_state_size) % 16 == 0, \
+        assert self.auto_reset and self.supports_qnet_policy_step(net_imposter, net_crew, epsilon) and 1 <= n_ticks <= feed["n_ticks"]
+        assert feed["obs"][0].data_ptr() % 16 == 0 and (n_ticks == 1 or (self.batch * self.flattened_state_size) % 16 == 0), \
             "the fused raw observation is written in 16-byte pieces: batch x flattened_state_size must be a multiple of 16"
         io = L.FeedIO()
         io.actions, io.rewards = feed["actions"].data_ptr(), feed["rewards"].data_ptr()
@@ -722,18 +736,19 @@ class BatchedFourRoomEnv:
             io.q = q_out.data_ptr()
         with self._on_device():
             L.check(self.lib.susnet_qnet_policy_rollout(self._h, net_imposter.components, len(net_imposter.components), net_imposter.cdims,
-                                                        len(net_imposter.dims), net_imposter.packed.data_ptr(), self._policy_opts(epsilon, mask_dead),
-                                                        C.byref(io), int(n_ticks), self._stream()))
+                                                        len(net_imposter.dims), net_imposter.packed.data_ptr(),
+                                                        self._policy_opts(epsilon, mask_dead, net_crew, q_crew_out), C.byref(io), int(n_ticks), self._stream()))
 
-    def policy_block(self, n_ticks: int, net_imposter: "PackedQNet", epsilon: float = 0.0, mask_dead: bool = False) -> None:
+    def policy_block(self, n_ticks: int, net_imposter: "PackedQNet", epsilon: float = 0.0, mask_dead: bool = False,
+                     net_crew: "Optional[PackedQNet]" = None) -> None:
         """``n_ticks`` ticks of the acting loop in ONE launch with nothing kept but the state and the episode metrics: ``run_game``'s loop with
         fixed networks (visualize.py:547-582), i.e. ``policy_rollout_into`` without a feed.  The fused observation (``env.obs``) is refreshed
         once, after the block."""
-        assert self.auto_reset and self.supports_qnet_policy_step(net_imposter) and n_ticks >= 1
+        assert self.auto_reset and self.supports_qnet_policy_step(net_imposter, net_crew, epsilon) and n_ticks >= 1
         io = L.FeedIO()
         with self._on_device():
             L.check(self.lib.susnet_qnet_policy_rollout(self._h, net_imposter.components, len(net_imposter.components), net_imposter.cdims,
-                                                        len(net_imposter.dims), net_imposter.packed.data_ptr(), self._policy_opts(epsilon, mask_dead),
+                                                        len(net_imposter.dims), net_imposter.packed.data_ptr(), self._policy_opts(epsilon, mask_dead, net_crew),
                                                         C.byref(io), int(n_ticks), self._stream()))
             if self._obs_spec is not None:
                 L.check(self.lib.susnet_observe(self._h, C.byref(self._obs_spec), self._stream()))

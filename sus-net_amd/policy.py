@@ -206,9 +206,9 @@ class PolicyRollout:
         self.fused_crew = pack_mlp(env, crew_model, components) if fused and crew_model is not None else None
         self._packed_version = (_weights_version(imposter_model), _weights_version(crew_model))
         # ... and with a random crew on one of the compiled-in games the whole tick -- network, argmax, the crew's draws, the step -- is
-        # ONE kernel (susnet_qnet_policy_step)
-        self.one_kernel_tick = (self.fused_imposter is not None and crew_model is None and env.rng_kind == "philox" and
-                                env.supports_qnet_policy_step(self.fused_imposter))
+        # ONE kernel (susnet_qnet_policy_step); so it is with both teams' networks (round 5: the LDS image is swapped between the two passes)
+        self.one_kernel_tick = (self.fused_imposter is not None and (crew_model is None or self.fused_crew is not None) and
+                                env.supports_qnet_policy_step(self.fused_imposter, self.fused_crew, self.epsilon))
         B = env.batch
         self._spatial = torch.zeros(B, 1, 1, device=env.device)  # FlatFeaturizer's dummy spatial input
         self._actions = torch.zeros(B, env.n_agents, dtype=torch.int64, device=env.device)
@@ -250,7 +250,8 @@ class PolicyRollout:
         env = self.env
         if self.one_kernel_tick:
             self.refresh_weights(force=False)
-            _, rew, done, trunc, _, a = env.qnet_policy_step(self.fused_imposter, actions_out=self._actions, epsilon=self.epsilon, mask_dead=self.mask_dead)
+            _, rew, done, trunc, _, a = env.qnet_policy_step(self.fused_imposter, actions_out=self._actions, epsilon=self.epsilon, mask_dead=self.mask_dead,
+                                                             net_crew=self.fused_crew)
             return a, rew, done, trunc
         q_imp, q_crew = self.q_rows()
         fits = max(env.n_imposter_actions, env.n_crew_actions) <= 16 and (q_crew is not None or env.rng_kind == "philox")
@@ -288,7 +289,7 @@ class PolicyRollout:
             left = int(n_steps)
             while left > 0:
                 n = min(left, int(block_ticks))
-                env.policy_block(n, self.fused_imposter, epsilon=self.epsilon, mask_dead=self.mask_dead)
+                env.policy_block(n, self.fused_imposter, epsilon=self.epsilon, mask_dead=self.mask_dead, net_crew=self.fused_crew)
                 left -= n
             return {}
         out: Dict[str, List[torch.Tensor]] = {"actions": [], "rewards": [], "done": [], "truncated": []}

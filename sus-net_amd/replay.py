@@ -183,14 +183,14 @@ class DeviceReplayBuffer:
             feed = self._collect_feed = env.alloc_feed(n_block)
         io = self._ring_io(env, feed, self._collect_window)
         # one launch per BLOCK where the env serves the whole tick in one kernel and the block's observation slots are 16-byte aligned
-        fused_block = (one_launch_per_block and policy.fused_crew is None and policy.crew_model is None and env.supports_qnet_policy_step(policy.fused_imposter)
-                       and (B * self.state_size) % 16 == 0)
+        fused_block = (one_launch_per_block and env.supports_qnet_policy_step(policy.fused_imposter, policy.fused_crew, epsilon)
+                       and (n_block == 1 or (B * self.state_size) % 16 == 0))
         done_ticks = 0
         while done_ticks < num_steps:
             n = min(n_block, num_steps - done_ticks)
             policy.refresh_weights(force=False)  # (the optimizer may have stepped since the last block)
             if fused_block:  # the whole block in ONE launch (susnet_qnet_policy_rollout)
-                env.policy_rollout_into(feed, n, policy.fused_imposter, epsilon=epsilon, mask_dead=mask_dead)
+                env.policy_rollout_into(feed, n, policy.fused_imposter, epsilon=epsilon, mask_dead=mask_dead, net_crew=policy.fused_crew)
             else:
                 for t in range(n):
                     env.policy_tick_into(feed, t, net_imposter=policy.fused_imposter, net_crew=policy.fused_crew, epsilon=epsilon, mask_dead=mask_dead)

@@ -1368,12 +1368,16 @@ def test_policy_step_equals_policy_actions_then_step(pkg, oracle_mod, name, crew
     assert int(e1.tick) == int(e2.tick) == T
 
 
+@pytest.mark.parametrize("crew_net", [False, True], ids=["random-crew", "crew-network"])
 @pytest.mark.parametrize("eps", [0.0, 0.25])
-@pytest.mark.parametrize("name,comps", [("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"]), ("itg_1v1_nowalls", ["onehot_pos"])])
-def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps, eps):
+@pytest.mark.parametrize("name,comps", [("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"]), ("itg_1v1_nowalls", ["onehot_pos"]),
+                                        ("itg_1v1_walls", ["coord_pos"])])
+def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps, eps, crew_net):
     """susnet_qnet_policy_step (network, argmax, crew draws, step: ONE kernel) against susnet_qnet_forward + susnet_policy_step on a twin
     handle with the same seed: actions, reward bit patterns, done / truncated, the fused float observation and the exported state, tick
-    after tick; B no multiple of the kernel's 256 environments per workgroup; the Q rows it can also emit."""
+    after tick; B no multiple of the kernel's 256 environments per workgroup; the Q rows it can also emit.  crew-network (round 5): BOTH
+    teams by their networks inside the one kernel (visualize.py:547-562) -- the workgroup swaps the LDS image between the two passes --
+    against the twin's two network launches + susnet_policy_step."""
     B, T = 3000 + 41, 60
     obs = pkg.ObsConfig("flat", comps)
     e1, _ = make_pair(pkg, oracle_mod, name, B, 23, auto_reset=True, check_errors=True, obs=obs)
@@ -1383,9 +1387,11 @@ def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps
     with torch.random.fork_rng(devices=[]):
         torch.manual_seed(6)
         model = pkg.MLP([e1.obs.shape[-1], 256, 128, 64, 16, e1.n_imposter_actions]).to(e1.device).eval()
-    two = pkg.PolicyRollout(e1, model, crew_model=None, components=comps, epsilon=eps, mask_dead=eps > 0)  # (0.25: the trainer's acting rule)
-    one = pkg.PolicyRollout(e2, model, crew_model=None, components=comps, epsilon=eps, mask_dead=eps > 0)
+        crew = pkg.MLP([e1.obs.shape[-1], 200, 128, 48, 16, e1.n_crew_actions]).to(e1.device).eval() if crew_net else None
+    two = pkg.PolicyRollout(e1, model, crew_model=crew, components=comps, epsilon=eps, mask_dead=eps > 0)  # (0.25: the trainer's acting rule)
+    one = pkg.PolicyRollout(e2, model, crew_model=crew, components=comps, epsilon=eps, mask_dead=eps > 0)
     assert one.one_kernel_tick and two.one_kernel_tick, "both games are served by the one-kernel tick"
+    assert (one.fused_crew is not None) == crew_net
     two.one_kernel_tick = False  # the twin takes the two-launch path
     ends = 0
     for tick in range(T):
@@ -1400,7 +1406,13 @@ def test_one_kernel_policy_tick_equals_two_launches(pkg, oracle_mod, name, comps
     assert int(e1.tick) == int(e2.tick) == T  # (episode ends inside a policy step: test_policy_step_equals_policy_actions_then_step)
     q = torch.empty(B, e2.n_imposter_actions, device=e2.device)
     want = e2.qnet_forward(one.fused_imposter).clone()
-    e2.qnet_policy_step(one.fused_imposter, q_out=q)
+    if not crew_net:
+        e2.qnet_policy_step(one.fused_imposter, q_out=q)
+    else:
+        qc = torch.empty(B, e2.n_crew_actions, device=e2.device)
+        want_c = e2.qnet_forward(one.fused_crew).clone()
+        e2.qnet_policy_step(one.fused_imposter, q_out=q, net_crew=one.fused_crew, q_crew_out=qc)
+        assert torch.equal(qc, want_c), "the crew's Q rows"
     assert torch.equal(q, want), "the Q rows the one-kernel tick emits are the network kernel's"
 
 
@@ -1459,6 +1471,9 @@ def test_one_kernel_policy_tick_long_horizon_and_full_size(pkg, oracle_mod):
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [256, 128, 64, 32], (-0.2, 1.5, 0.3, 0.01), 300),  # slopes outside [0, 1]: compare / select PReLU
     ("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], [1, 1, 1, 1], (0.25, 0.25, 0.25, 0.25), 1),        # the narrowest stack, one environment
     ("itg_1v1_nowalls", ["onehot_pos"], [256, 128, 64, 16], (0.1, 0.3, 0.5, 0.7), 5037),                                # notebooks/experiment_1v1.ipynb
+    ("itg_1v1_walls", ["onehot_pos"], [256, 128, 64, 16], (0.25, 0.25, 0.25, 0.25), 1000),                              # ... one_hot_wall
+    ("itg_1v1_nowalls", ["coord_pos"], [256, 128, 64, 16], (0.1, 0.3, 0.5, 0.7), 5037),                                 # ... no_wall_coord_features
+    ("itg_1v1_walls", ["coord_pos"], [256, 128, 64, 16], (0.25, 0.25, 1.5, -0.5), 777),                                 # ... wall_coord_features
 ])
 def test_qnet_forward_matches_torch_mlp(pkg, oracle_mod, name, comps, hidden, slopes, B):
     """susnet_qnet_forward (state words -> Q rows in one kernel: layer 1 as a gather of W1 columns, layers 2..5 on the f32 matrix
@@ -1492,6 +1507,44 @@ def test_qnet_forward_matches_torch_mlp(pkg, oracle_mod, name, comps, hidden, sl
             assert bool((gap <= 1e-5 * max(scale, 1e-3)).all())
             env.step(env.sample_actions())
     assert pkg.policy.pack_mlp(env, pkg.MLP([env.obs.shape[-1], 64, 7]).to(env.device), comps) is None  # another depth: torch serves it
+
+
+@pytest.mark.parametrize("tag", ["nowalls", "walls"])
+def test_qnet_coordinate_layout_matches_the_reference_mlp(pkg, tag):
+    """The coordinate feature layout (CoordinateAgentPositionsFeaturizer, component.py:384-403: two of the four live experiments of
+    notebooks/experiment_1v1.ipynb) through the Q-network kernel, against the REFERENCE's own objects: tests/golden/model_mlp_coord_1v1_*.npz
+    holds states of a 1v1 rollout on either map (24 of them with a dead crew member: its coordinates stay in the row), the reference
+    featurizer's rows and the Q rows of two reference `MLP`s.  The states are imported, one per environment; the fused flat observation must
+    equal the featurizer's rows exactly and susnet_qnet_forward the Q rows to float32 summation-order tolerance (layer 1 gathers k x W1
+    columns multiplied on the host), with the same argmax wherever the reference's margin is not a numerical tie."""
+    g = load_golden(f"{GOLDEN_DIR}/model_mlp_coord_1v1_{tag}.npz")
+    meta = g["meta"]
+    rows = g["rows"].astype(np.int64)
+    n = len(rows)
+    comps = meta["components"]
+    env = env_from_meta(pkg, meta, n, rng="philox", obs=pkg.ObsConfig("flat", comps), check_errors=False)
+    env.reset()
+    env.set_state(agent_positions=rows[:, :4].reshape(n, 2, 2), alive_agents=rows[:, 4:6])
+    feats = env.observe(pkg.ObsConfig("flat", comps))
+    np.testing.assert_array_equal(np_(feats), g["features"], err_msg="flat coordinate features")
+    assert int((rows[:, 5] == 0).sum()) >= 20
+    for team in ("imposter", "crew"):
+        model = pkg.policy.MLP(meta["dims"][team])
+        model.load_state_dict({k[len(team) + 2:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(team + "::")})
+        model = model.to(env.device).eval()
+        net = pkg.policy.pack_mlp(env, model, comps)
+        assert net is not None, "the Q-network kernel serves the coordinate layout on the 1v1 game"
+        got = np_(env.qnet_forward(net))
+        want = g["q_" + team]
+        scale = float(np.abs(want).max())
+        assert float(np.abs(got - want).max()) <= 2e-5 * max(scale, 1e-3), (team, float(np.abs(got - want).max()), scale)
+        top2 = np.sort(want, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * max(scale, 1e-3)
+        np.testing.assert_array_equal(got.argmax(1)[clear], want.argmax(1)[clear], err_msg=team + " argmax")
+    # the one-kernel policy tick serves the layout too (network, argmax, the crew's draws and the step in one launch)
+    model = pkg.policy.MLP(meta["dims"]["imposter"]).to(env.device).eval()
+    pol = pkg.PolicyRollout(env, model, None, components=comps)
+    assert pol.one_kernel_tick
 
 
 def test_captured_policy_tick_replays_against_the_oracle(pkg, oracle_mod):
@@ -1770,26 +1823,34 @@ def test_one_kernel_collection_matches_the_step_by_step_policy_loop(pkg, one_lau
     np.testing.assert_array_equal(term[:, 3 * A:3 * A + 8], prev[:, 3 * A:3 * A + 8], err_msg="job cells stay within an episode")
 
 
-@pytest.mark.parametrize("name,comps,B", [("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], 16 * 61), ("itg_1v1_nowalls", ["onehot_pos"], 16 * 37)])
-def test_policy_block_in_one_launch_equals_one_launch_per_tick(pkg, oracle_mod, name, comps, B):
+@pytest.mark.parametrize("crew_net", [False, True], ids=["random-crew", "crew-network"])
+@pytest.mark.parametrize("name,comps,B", [("base_1v2_j4_14", ["onehot_pos", "alive_crew", "closest_crew"], 16 * 61), ("itg_1v1_nowalls", ["onehot_pos"], 16 * 37),
+                                          ("itg_1v1_walls", ["coord_pos"], 16 * 37)])
+def test_policy_block_in_one_launch_equals_one_launch_per_tick(pkg, oracle_mod, name, comps, B, crew_net):
     """susnet_qnet_policy_rollout (the policy tick looped INSIDE the kernel, the wave re-reading the state it stored) against
     susnet_qnet_policy_step called once per tick on a twin: every feed array of every tick, the Q rows, and the state afterwards.
-    B is not a multiple of the 256 environments of a workgroup, and the run crosses episode ends."""
+    B is not a multiple of the 256 environments of a workgroup (so some waves of the last workgroup hold no environment: with the crew's
+    network they still take part in the image swaps), and the run crosses episode ends."""
     n = 40
     mk = lambda: make_pair(pkg, oracle_mod, name, B, 5, auto_reset=True, check_errors=False, max_time_steps=12, obs=pkg.ObsConfig("flat", comps))[0]
     env, twin = mk(), mk()
     model = pkg.policy.reference_imposter_mlp(env, comps, seed=9)
-    pol, tp = (pkg.PolicyRollout(e, model, None, components=comps, epsilon=0.2, mask_dead=True) for e in (env, twin))
-    if not env.supports_qnet_policy_step(pol.fused_imposter):
+    crew = None
+    if crew_net:
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(10)
+            crew = pkg.MLP([env.obs.shape[-1], 96, 64, 32, 16, env.n_crew_actions]).to(env.device).eval()
+    pol, tp = (pkg.PolicyRollout(e, model, crew, components=comps, epsilon=0.2, mask_dead=True) for e in (env, twin))
+    if not env.supports_qnet_policy_step(pol.fused_imposter, pol.fused_crew, 0.2):
         pytest.skip("no one-kernel tick for this game")
     env.reset(), twin.reset()
     nq = pol.fused_imposter.dims[-1]
     fa, fb = env.alloc_feed(n), twin.alloc_feed(n)
     qa = torch.zeros(n, B, nq, device=env.device)
     qb = torch.zeros(n, B, nq, device=env.device)
-    env.policy_rollout_into(fa, n, pol.fused_imposter, epsilon=0.2, mask_dead=True, q_out=qa)
+    env.policy_rollout_into(fa, n, pol.fused_imposter, epsilon=0.2, mask_dead=True, q_out=qa, net_crew=pol.fused_crew)
     for k in range(n):
-        twin.policy_tick_into(fb, k, tp.fused_imposter, epsilon=0.2, mask_dead=True, q_out=qb[k])
+        twin.policy_tick_into(fb, k, tp.fused_imposter, net_crew=tp.fused_crew, epsilon=0.2, mask_dead=True, q_out=qb[k])
     torch.cuda.synchronize()
     for key in ("actions", "rewards", "done", "truncated", "obs", "term_obs", "roles"):
         a, b = fa[key][:n].contiguous(), fb[key][:n].contiguous()
@@ -1799,9 +1860,9 @@ def test_policy_block_in_one_launch_equals_one_launch_per_tick(pkg, oracle_mod, 
     raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
     assert torch.equal(env.observe(raw8), twin.observe(raw8)) and torch.equal(env.episode_index(), twin.episode_index())
     # and a second block continues where the first stopped (tick counter, episode counters)
-    env.policy_rollout_into(fa, 7, pol.fused_imposter, epsilon=0.2, mask_dead=True)
+    env.policy_rollout_into(fa, 7, pol.fused_imposter, epsilon=0.2, mask_dead=True, net_crew=pol.fused_crew)
     for k in range(7):
-        twin.policy_tick_into(fb, k, tp.fused_imposter, epsilon=0.2, mask_dead=True)
+        twin.policy_tick_into(fb, k, tp.fused_imposter, net_crew=tp.fused_crew, epsilon=0.2, mask_dead=True)
     torch.cuda.synchronize()
     assert torch.equal(fa["actions"][:7], fb["actions"][:7]) and torch.equal(fa["obs"][:7], fb["obs"][:7])
 
