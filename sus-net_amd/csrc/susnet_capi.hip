@@ -1028,7 +1028,10 @@ template <class ROW, class S>
 static int qnet_step_launch(susnet_env *env, bool tape, const QnetFuse &f, const StepArgs &a, const ObsArgs &o, size_t step_lds, hipStream_t st, int n_ticks, const TickStrides &ts) {
     using Q = QNet<ROW>;
     // [table image of the step, shared by the four waves][network image][one region per wave: the rest of a k_step workgroup's LDS]
-    const size_t rest = step_lds - (size_t)kTableWords * 4 + (size_t)kStashWords * 4; // (per wave: the teams' greedy actions, then the step's region)
+    // per wave: the teams' greedy actions, then the step's region -- without the group-words area a k_step workgroup of the byte-parallel
+    // configurations reserves (step_wave<.., TABLES = false> carves none: nothing stages the action stream here)
+    const size_t group_words = HasGroupWords<S>::value ? (size_t)kGroupWords * 4 : 0;
+    const size_t rest = step_lds - (size_t)kTableWords * 4 - group_words + (size_t)kStashWords * 4;
     const size_t sh = (size_t)kTableWords * 4 + (size_t)Q::kLdsBytes + 4 * rest;
     if (sh > 160 * 1024) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: observation too large for the LDS left beside the network image");
     QStepArgs ka{env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest, n_ticks, ts, f.crew_packed, f.crew_q_out, f.crew_n_out, 0};

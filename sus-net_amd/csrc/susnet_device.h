@@ -545,7 +545,9 @@ struct TableLoad {
 // addresses); rest: the wave's own region behind it (k_step / the rollouts: smem + kTableWords; the one-kernel policy tick keeps ONE
 // table image for its four waves and gives each wave a region of its own further up)
 // JOBMAP: the kernel keeps the cell -> job map behind the group words (fused rollouts of the byte-parallel configurations)
-template <class S, bool JOBMAP = false>
+// GROUPWORDS = false: the caller's wave regions hold no group-words area (the one-kernel policy tick never stages the action stream, and
+// with the network image beside them its four wave regions are tight: susnet_qnet.h)
+template <class S, bool JOBMAP = false, bool GROUPWORDS = true>
 __device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, uint32_t *rest, int tid, typename StoreFor<S>::type &st) {
     Tables T;
     T.grid = smem;
@@ -555,7 +557,7 @@ __device__ __forceinline__ Tables carve_lds(const Consts &c, uint32_t *smem, uin
     T.rew = reinterpret_cast<const float *>(smem + kRewardTableWord);
     st.init(rest, c.A, c.J, tid);
     if (S::kGeneric) rest += (2 * c.A + c.J) * kBlock;
-    if (HasGroupWords<S>::value) rest += kGroupWords;
+    if (HasGroupWords<S>::value && GROUPWORDS) rest += kGroupWords;
     if (JOBMAP) rest += lds_jobmap_words(c.N);
     T.perm = reinterpret_cast<uint8_t *>(rest);
     T.stage = rest;

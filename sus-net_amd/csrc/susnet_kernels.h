@@ -171,7 +171,7 @@ __device__ __forceinline__ void step_wave(const Consts &c, const State &s, const
     const int64_t b = b0 + tid;
     const bool active = b < c.B;
     typename StoreFor<S>::type st;
-    Tables T = carve_lds<S>(c, smem, rest, tid, st);
+    Tables T = carve_lds<S, false, TABLES>(c, smem, rest, tid, st); // (TABLES = false: the policy kernel's wave regions, without a group-words area)
     // One step per launch is latency-bound: every load the step needs is issued here, back to back and without a branch
     // between them (state rows are padded to Bp, so lanes past B read their own padding; their action index is clamped),
     // and only then are the tables written to LDS -- one memory round trip instead of one per table, per agent, per field.
