@@ -384,7 +384,7 @@ def main():
             env.step(a)
         return 2 * n_ticks
 
-    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0, policy_fused=True, n_repeats=0, block_ticks=0):
+    def measure(spec, B, mode, obs_mode, K, W, ticks, want_packed=-1, graph_ticks=0, policy_fused=True, n_repeats=0, block_ticks=0, crew_network=False):
         """W untimed + K timed bench steps of one configuration.  fused: a step is one launch of `ticks` ticks; step / policy:
         one tick (policy with graph_ticks > 0: the tick loop replayed as hipGraphs of graph_ticks ticks, K rounded up to whole graphs)."""
         oc = obs_config(obs_mode) if mode == "fused" else None
@@ -405,7 +405,8 @@ def main():
         bufs = env.alloc_rollout(ticks, obs=oc, packed=("compact" if compact else packed)) if mode == "fused" else None
         if mode == "policy":
             model = pkg.policy.reference_imposter_mlp(env, POLICY_COMPONENTS, seed=0)
-            pr = pkg.PolicyRollout(env, model, crew_model=None, components=POLICY_COMPONENTS, fused=policy_fused)
+            crew_model = pkg.policy.reference_crew_mlp(env, POLICY_COMPONENTS, seed=1) if crew_network else None  # (run_game: both teams by their networks)
+            pr = pkg.PolicyRollout(env, model, crew_model=crew_model, components=POLICY_COMPONENTS, fused=policy_fused)
             assert (pr.fused_imposter is not None) == policy_fused, "the reference MLP on this layout is served by susnet_qnet_forward"
             if graph_ticks > 0:
                 graph, _ = pr.capture(graph_ticks)
@@ -627,6 +628,13 @@ def main():
                     if rp["qnet"] is not None and (blk or "roofline" not in entry):
                         entry["roofline"] = rp["qnet"]
                     del rp
+                # BOTH teams by their networks (visualize.py:547-562: run_game's loop): the same kernel swapping the LDS image between the two
+                # network passes of a tick -- one launch per tick, and 64 ticks per launch
+                for label, blk in (("both_teams_one_launch_per_tick", 0), ("both_teams_blocks_of_64_ticks", 64)):
+                    rp = measure(sp, sp["batch"], "policy", "flat", 256 if blk else 64, 64 if blk else 16, 1, block_ticks=blk, crew_network=True)
+                    entry[label] = {"value": sp["batch"] * rp["steps"] / rp["seconds"], "us_per_tick": rp["seconds"] * 1e6 / rp["steps"], "ticks_timed": rp["steps"],
+                                    "networks": "imposter MLP[88,256,128,64,16,7] + crew MLP[88,256,128,64,16,6], both inside k_qnet_step<.., TWO>"}
+                    del rp
                 # the trainer's collection loop on the same env: the one-kernel tick writing the replay feed + one susnet_ring_append per
                 # 64 ticks (DeviceReplayBuffer.collect: train.py:345-399), epsilon-greedy as the trainer acts
                 envc = make_env(pkg, sp, sp["batch"], seed, rank * sp["batch"], device, obs_cfg=pkg.ObsConfig("flat", POLICY_COMPONENTS))
@@ -688,7 +696,10 @@ def main():
         line["others"] = {e["config"]: {"value": e["value"], "frac": (e.get("frac") if "frac" in e else e.get("roofline", {}).get("frac")),
                                         **({"collect_transitions_per_s": e["collect_into_replay_ring"]["value"]} if "collect_into_replay_ring" in e else {}),
                                         **({"us_per_tick": e["blocks_of_5_ticks"]["us_per_tick"], "us_per_tick_blocks_of_64": e["blocks_of_64_ticks"]["us_per_tick"],
-                                            "launch_per_tick_us": e["eager"]["us_per_tick"]} if "blocks_of_64_ticks" in e else {})}
+                                            "launch_per_tick_us": e["eager"]["us_per_tick"],
+                                            "both_teams_us_per_tick": e.get("both_teams_one_launch_per_tick", {}).get("us_per_tick"),
+                                            "both_teams_us_per_tick_blocks_of_64": e.get("both_teams_blocks_of_64_ticks", {}).get("us_per_tick")}
+                                           if "blocks_of_64_ticks" in e else {})}
                           for e in line["other_configs"]}
     if world > 1:
         dist.barrier()  # the timed region and its collectives are over on every rank before rank 0 spends host time below

@@ -1,0 +1,6 @@
+// the byte-parallel family: 7 agents, TAG (three imposters) -- one translation unit of the parallel build (tools/gen_family.py, susnet_family.h)
+#include "susnet_family.h"
+namespace susnet {
+SUSNET_FAMILY_INSTANTIATE(7, SUSNET_VARIANT_TAGGING, 1, 3)
+SUSNET_FAMILY_INSTANTIATE(7, SUSNET_VARIANT_TAGGING, 0, 3)
+}

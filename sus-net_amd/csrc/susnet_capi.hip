@@ -19,7 +19,7 @@
 
 namespace susnet {
 SUSNET_DECLARE(GenericSpec) SUSNET_DECLARE(SpecCfg2) SUSNET_DECLARE(SpecCfg3) SUSNET_DECLARE(SpecCfg4) SUSNET_DECLARE(SpecTag5)
-SUSNET_DECLARE(SpecA<2>) SUSNET_DECLARE(SpecA<3>) SUSNET_DECLARE(SpecA<4>) SUSNET_DECLARE(SpecA<5>) SUSNET_DECLARE(SpecA<6>) SUSNET_DECLARE(SpecA<7>) SUSNET_DECLARE(SpecA<8>)
+SUSNET_DECLARE(SpecA<2>)
 #define X SUSNET_FAMILY_DECLARE
 SUSNET_FAMILY(X)
 #undef X
@@ -335,7 +335,9 @@ static int pick_spec(const Consts &c, bool float_exact, bool force_generic) {
         for (size_t i = 0; i < sizeof(kFamily) / sizeof(kFamily[0]); i++)
             if (kFamily[i].A == c.A && kFamily[i].variant == c.variant && kFamily[i].order_random == (c.order_random ? 1 : 0) && kFamily[i].n_imp == c.n_imp)
                 return kFamilySpecBase + (int)i;
-    if (c.A >= 2 && c.A <= 8 && c.J <= 8) return 10 + c.A; // SpecA<A>: the per-turn kernels (1v1 on a wall map, three or more imposters)
+    // (every 3..8-agent game with at most 8 jobs is in the family -- one to three imposters: base.py:247-249 allows no more below nine agents --,
+    // so the per-turn kernels with a compiled-in agent count, SpecA<3..8> of rounds 2-4 and their 400-500 spilled SGPRs, are gone)
+    if (c.A == 2 && c.J <= 8) return 12; // SpecA<2>: the 2-agent games that are not the compiled-in one (jobs, shuffled roles) through the per-turn kernels
     return 0;
 }
 
@@ -1126,12 +1128,6 @@ static int step_impl(susnet_env *env, const susnet_step_io *io, const float *q_i
     case 4: launch_step<SpecCfg4>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     case 6: launch_step<SpecTag5>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     case 12: launch_step<SpecA<2>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
-    case 13: launch_step<SpecA<3>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
-    case 14: launch_step<SpecA<4>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
-    case 15: launch_step<SpecA<5>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
-    case 16: launch_step<SpecA<6>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
-    case 17: launch_step<SpecA<7>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
-    case 18: launch_step<SpecA<8>>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     default: launch_step<GenericSpec>(tape, g, blk, sh, st, env->c, env->s, a, o); break;
     }
     HIP_TRY(hipGetLastError());
@@ -1381,12 +1377,6 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         case 4: launch_rollout<SpecCfg4>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         case 6: launch_rollout<SpecTag5>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         case 12: launch_rollout<SpecA<2>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 13: launch_rollout<SpecA<3>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 14: launch_rollout<SpecA<4>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 15: launch_rollout<SpecA<5>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 16: launch_rollout<SpecA<6>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 17: launch_rollout<SpecA<7>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
-        case 18: launch_rollout<SpecA<8>>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         default: launch_rollout<GenericSpec>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         }
         HIP_TRY(hipGetLastError());

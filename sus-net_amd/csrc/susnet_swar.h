@@ -27,13 +27,22 @@
 
 namespace susnet {
 
+// f(std::integral_constant<int, I>{}) for I = BEGIN .. END - 1 (susnet_kernels.h has the same helper for the kernels)
+template <int BEGIN, int END, class F>
+__device__ __forceinline__ void swar_static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        swar_static_for<BEGIN + 1, END>(f);
+    }
+}
+
 template <class S>
 struct UseSwar {
     // (kJ = -1: the job count is read at run time -- at most 8 -- : the FAMILY of byte-parallel kernels, one instantiation per agent
     // count, variant, order and imposter count, serving every job count: susnet_kernels.h SpecFam)
     static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kA <= 8 && S::kJ >= -1 && S::kJ <= 8 && S::kOrd >= 0 &&
                                   (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG || S::kVar == SUSNET_VARIANT_TAGGING) &&
-                                  (S::kNI == 1 || S::kNI == 2);
+                                  (S::kNI >= 1 && S::kNI <= 3);
 };
 
 // 0x80 flags -> 0xff bytes
@@ -169,7 +178,7 @@ struct Swar {
 template <class S>
 __device__ __forceinline__ void swar_refresh_alive(Swar<S> &w) {
     using W = Swar<S>;
-    constexpr uint32_t neg32[2] = {(W::NI >= 1 ? 0x20u : 0u) | (W::NI >= 2 ? 0x2000u : 0u), 0u}; // indices [:n_imposters], NOT the imposter mask (base.py:559)
+    constexpr uint32_t neg32[2] = {(W::NI >= 1 ? 0x20u : 0u) | (W::NI >= 2 ? 0x2000u : 0u) | (W::NI >= 3 ? 0x200000u : 0u), 0u}; // indices [:n_imposters], NOT the imposter mask (base.py:559)
 #pragma unroll
     for (int q = 0; q < W::NW; q++) {
         w.al80[q] = (w.al[q] & k01) << 7;
@@ -572,13 +581,44 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         }
         bool second_first = false; // two imposters: the one with the earlier turn kills first
         if (NI == 2) second_first = kb[1] != 0u && (kb[0] == 0u || rb[1] < rb[0]);
+        // three imposters: the attempting ones in turn order -- turn `it` goes to the slot with the it-th smallest key (rank of an
+        // attempting imposter, 0x100 + slot for the others: they come last and do nothing)
+        uint32_t key3[3] = {0u, 0u, 0u};
+        if (NI == 3) {
 #pragma unroll
-        for (int it = 0; it < NI; it++) {
-            const int s0 = it, s1 = NI - 1 - it; // slot if the natural order holds / if it is swapped
-            const uint32_t kbi = second_first ? kb[s1] : kb[s0], rbi = second_first ? rb[s1] : rb[s0], cbi = second_first ? cb[s1] : cb[s0];
+            for (int s = 0; s < 3; s++) key3[s] = kb[s < NI ? s : 0] != 0u ? (rb[s < NI ? s : 0] & 0x7fu) : 0x100u + (uint32_t)s;
+        }
+        // (one copy of the body per kill turn, made by the template machinery: `#pragma unroll` is a request the optimiser may turn
+        // down -- silently under -Wno-pass-failed --, and a loop left rolled indexes vk80[it] / gek80[it] at run time, i.e. in scratch
+        // memory: that is what the three-imposter kernels did at first)
+        swar_static_for<0, NI>([&](auto itc) __attribute__((always_inline)) {
+            constexpr int it = decltype(itc)::value;
+            constexpr int s0 = it, s1 = NI - 1 - it; // two imposters: slot if the natural order holds / if it is swapped
+            uint32_t kbi, rbi, cbi, hot_of[NW];
+            if (NI == 3) {
+                const uint32_t m = key3[0] < key3[1] ? (key3[0] < key3[2] ? 0u : 2u) : (key3[1] < key3[2] ? 1u : 2u); // the slot whose turn it is
+                // (picked with masks, not with selects: a select between elements of one array is turned into ONE load with a selected
+                // index -- a run-time index into `w`, which then lives in scratch memory)
+                const uint32_t p0 = 0u - (m == 0u ? 1u : 0u), p1 = 0u - (m == 1u ? 1u : 0u), p2 = 0u - (m == 2u ? 1u : 0u);
+                constexpr int i1 = NI > 1 ? 1 : 0, i2 = NI > 2 ? 2 : 0;
+                kbi = (kb[0] & p0) | (kb[i1] & p1) | (kb[i2] & p2);
+                rbi = (rb[0] & p0) | (rb[i1] & p1) | (rb[i2] & p2);
+                cbi = (cb[0] & p0) | (cb[i1] & p1) | (cb[i2] & p2);
+#pragma unroll
+                for (int q = 0; q < NW; q++) hot_of[q] = (w.ihot[0][q] & p0) | (w.ihot[i1][q] & p1) | (w.ihot[i2][q] & p2);
+                key3[0] |= p0 & 0x200u; // (taken)
+                key3[1] |= p1 & 0x200u;
+                key3[2] |= p2 & 0x200u;
+            } else {
+                kbi = second_first ? kb[s1] : kb[s0];
+                rbi = second_first ? rb[s1] : rb[s0];
+                cbi = second_first ? cb[s1] : cb[s0];
+#pragma unroll
+                for (int q = 0; q < NW; q++) hot_of[q] = second_first ? w.ihot[s1][q] : w.ihot[s0][q];
+            }
             // (no ballot on "somebody attempts" for the first kill turn: in a wave of 64 environments somebody nearly always does;
             // the second turn only has work where BOTH imposters attempt)
-            if (it > 0 && __builtin_amdgcn_ballot_w64(kbi != 0u) == 0ull) continue;
+            if (it > 0 && __builtin_amdgcn_ballot_w64(kbi != 0u) == 0ull) return;
             const uint32_t tb = rbi & k7f;
             uint32_t ge80[NW], cand[NW];
             uint32_t nc = 0;
@@ -591,7 +631,7 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             }
             // A crew member on the killer's cell is rare (a fraction of a percent per environment): everything below the candidate
             // search sits behind a ballot.
-            if (__builtin_amdgcn_ballot_w64(nc != 0u) == 0ull) continue;
+            if (__builtin_amdgcn_ballot_w64(nc != 0u) == 0ull) return;
             // base.py:497: uniform among the candidates (ascending agent index).  With one candidate -- nearly always --
             // the victim is the lowest set flag; several candidates (rare) are handled behind a wave-uniform branch.
             uint32_t v80[NW];
@@ -623,13 +663,13 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                 w.al80[q] &= ~v80[q];
                 w.crew80[q] &= ~v80[q];
                 w.ridx[q] += v80[q] >> 3;                                       // the victim's rewards come from the "dead" rows from now on (base.py:562)
-                const uint32_t hot = hit ? (second_first ? w.ihot[s1][q] : w.ihot[s0][q]) : 0u;
+                const uint32_t hot = hit ? hot_of[q] : 0u;
                 kc80[q] |= hot;                                                 // base.py:514-515 (the victim's slot ends as dead_penalty)
                 idx4[q] += (v80[q] >> 3) + (hot >> 5);                          // RC_KILL * 4 for the killer
                 pend80[q] |= v80[q] & ge80[q];                                  // killed before its own turn: it never acts
                 if (W::kTag) { vk80[it][q] = v80[q]; gek80[it][q] = ge80[q]; }
             }
-        }
+        });
     }
 #endif
     // final positions: a victim that had not acted yet stays where it was

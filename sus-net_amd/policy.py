@@ -163,6 +163,16 @@ def reference_imposter_mlp(env, components: Sequence[str], seed: int = 0) -> MLP
     return model.to(env.device).eval()
 
 
+def reference_crew_mlp(env, components: Sequence[str], seed: int = 1) -> MLP:
+    """The crew's network of the same architecture, `[F, 256, 128, 64, 16, n_crew_actions]` (train_crew, notebooks/experiment.ipynb cell 5;
+    run_game's crew_model, visualize.py:547-562), seeded init."""
+    spec, o1, _ = env._make_obs(ObsConfig("flat", list(components)), 1)
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        model = MLP([o1.shape[-1], 256, 128, 64, 16, env.n_crew_actions])
+    return model.to(env.device).eval()
+
+
 def pack_mlp(env, model, components: Sequence[str], into=None):
     """``env.qnet_pack`` of a reference ``MLP`` (Linear / nn.PReLU() alternating, dqn.py:322-329), or None if ``model`` is something
     else or the library does not serve its shape on this env.  ``into``: an image of the same stack to overwrite in place."""

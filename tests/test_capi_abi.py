@@ -158,7 +158,9 @@ def test_packed_record_layouts(pkg):
     assert len(sizes) == 1
     A, F = layout(variant=L.VARIANT_TAGGING, n_imposters=2, n_crew=5, n_jobs=3)
     assert lay.n_obs_segments == 4 and sum(lay.obs_segments[k][1] for k in range(4)) == F
-    A, F = layout(n_imposters=3, n_crew=5, n_jobs=2)  # three imposters: the per-turn kernels, no packed mode
+    A, F = layout(n_imposters=3, n_crew=5, n_jobs=2)  # three imposters: in the family since round 5 (the per-turn SpecA<3..8> kernels are gone)
+    assert lay.record_bytes > 0 and lay.planar == 1 and lay.n_obs_segments == 3
+    A, F = layout(n_imposters=4, n_crew=9, n_jobs=2)  # more than 8 agents: the generic kernels, no packed mode
     assert lay.record_bytes == 0
 
 

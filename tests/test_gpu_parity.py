@@ -817,11 +817,11 @@ def test_fused_rollout_with_float_observations_matches_oracle(pkg, oracle_mod, n
 @pytest.mark.parametrize("A", [3, 4, 5, 6, 7, 8])
 def test_family_sweep_matches_oracle(pkg, oracle_mod, cls, A):
     """The byte-parallel FAMILY instantiations (susnet_family.h: 3..8 agents x {FourRoomEnv, ImposterTrainingGround, tagging} x action order x
-    1..2 imposters, job count and role shuffle at run time), each through BOTH trajectory layouts -- packed records and separate tensors with
+    1..3 imposters, job count and role shuffle at run time), each through BOTH trajectory layouts -- packed records and separate tensors with
     the raw observation -- against the oracle: job counts 0 / 3 / 8, fixed and shuffled roles, a ragged last wave, 12-step episodes."""
     B, T, n_cases = 64 * 2 + 3, 36, 0
     raw8 = pkg.ObsConfig("raw", dtype=torch.uint8)
-    for n_imp in ((1,) if cls == "itg" else (1, 2)):
+    for n_imp in ((1,) if cls == "itg" else (1, 2, 3)):  # (round 5: three imposters -- the kill turns of three killers in turn order)
         if A - n_imp <= (0 if cls == "itg" else n_imp):  # (base.py:243-249: more crew members than imposters)
             continue
         for J in (0, 3, 8):

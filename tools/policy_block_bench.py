@@ -43,6 +43,18 @@ def main():
     out["launch_per_tick_us"] = timed(tick, 4 * T) / (4 * T)
     out["network_alone_us"] = timed(lambda: env.qnet_forward(net), 100) / 100
     out["block_us_per_tick_again"] = timed(lambda: env.policy_rollout_into(feed, T, net, epsilon=0.1, mask_dead=True), 6) / (6 * T)
+    out["block_of_5_us_per_tick"] = timed(lambda: env.policy_rollout_into(feed, 5, net, epsilon=0.1, mask_dead=True), 60) / (60 * 5)
+    # both teams by their networks (round 5: the crew's image swapped in between the two passes of a tick)
+    crew = pkg.policy.pack_mlp(env, pkg.policy.reference_crew_mlp(env, comps, seed=1), comps)
+    for _ in range(2):
+        env.policy_rollout_into(feed, T, net, epsilon=0.1, mask_dead=True, net_crew=crew)
+    torch.cuda.synchronize()
+    out["both_teams_block_us_per_tick"] = timed(lambda: env.policy_rollout_into(feed, T, net, epsilon=0.1, mask_dead=True, net_crew=crew), 6) / (6 * T)
+    def tick2():
+        env.policy_tick_into(feed, k[0] % T, net, net_crew=crew, epsilon=0.1, mask_dead=True)
+        k[0] += 1
+    out["both_teams_launch_per_tick_us"] = timed(tick2, 4 * T) / (4 * T)
+    out["both_teams_block_of_5_us_per_tick"] = timed(lambda: env.policy_rollout_into(feed, 5, net, epsilon=0.1, mask_dead=True, net_crew=crew), 60) / (60 * 5)
     print(json.dumps(out))
 
 
