@@ -1354,6 +1354,13 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
         return fail(env, SUSNET_E_INVALID, "susnet_rollout on a TAPE handle stores the full trajectory with the raw uint8 observation, as separate "
                                       "tensors or as packed records (nothing else)");
     const int chunk = (out == OUT_TRAJ_RAW8 || out == OUT_TRAJ || out == OUT_RECORD || out == OUT_RECORD16 || out == OUT_TRAJ_FLAT) ? (int)std::min<uint64_t>((uint64_t)io->n_ticks, fit) : io->n_ticks;
+    // the family's 9 .. 12-agent instantiations serve the trajectory / record / state-only modes; anything else (float observations, partial
+    // outputs: OUT_ANY) runs the generic kernel on the same state blob and the same streams
+    const int run_spec = (is_family(spec) && env->c.A > 8 && out == OUT_ANY) ? 0 : spec;
+    if (run_spec != spec) {
+        sh = lds_bytes(env, o, true, 0, true);
+        CHECK_LDS(sh);
+    }
     for (int t0 = 0; t0 < io->n_ticks; t0 += chunk) {
         a.n_ticks = std::min(chunk, io->n_ticks - t0);
         a.tick_base = env->ticks + (uint64_t)t0;
@@ -1370,8 +1377,8 @@ extern "C" int susnet_rollout(susnet_env *env, const susnet_rollout_io *io, void
             if (a.term_obs) a.term_obs += (uint64_t)chunk * (uint64_t)o.tick_stride;
             if (a.roles) a.roles += (uint64_t)chunk * (uint64_t)env->c.B;
         }
-        if (is_family(spec)) kFamily[spec - kFamilySpecBase].rollout(tape, out, g, blk, sh, st, env->c, env->s, a, o);
-        else switch (spec) {
+        if (is_family(run_spec)) kFamily[run_spec - kFamilySpecBase].rollout(tape, out, g, blk, sh, st, env->c, env->s, a, o);
+        else switch (run_spec) {
         case 2: launch_rollout<SpecCfg2>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         case 3: launch_rollout<SpecCfg3>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;
         case 4: launch_rollout<SpecCfg4>(tape, out, g, blk, sh, st, env->c, env->s, a, o); break;

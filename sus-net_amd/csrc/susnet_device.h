@@ -220,7 +220,7 @@ using GenericSpec = Spec<-1, -1, -1, -1>;
 // configurations whose fused rollouts stage the action stream in LDS a group of ticks at a time (the byte-parallel kernels:
 // agent count, variant and order compiled in, 3 .. 8 agents); the host reserves the space for exactly these (susnet_capi.hip)
 template <class S>
-struct HasGroupWords { static constexpr bool value = !S::kGeneric && S::kStaticAw && S::kA >= 3 && S::kA <= 8; };
+struct HasGroupWords { static constexpr bool value = !S::kGeneric && S::kStaticAw && S::kA >= 3 && S::kA <= 12; };
 
 // ---------------------------------------------------------------------------------------------------
 // word sources
@@ -435,8 +435,9 @@ __device__ __forceinline__ uint32_t lds_move_lookup(uint32_t row_cell) { return 
 __device__ __forceinline__ float lds_reward_lookup(uint32_t byte_index) { return *(lds_f32_ptr)(uintptr_t)(lds_table_addr(kRewardTableWord) + byte_index); }
 
 // The byte-parallel rollouts (susnet_swar.h GroupWords) stage the action-stream words of one GROUP of ticks behind the tables:
-// at most 12 words x 64 environments (cfg4: 3 words per tick, 4 ticks; with two lanes per environment 24 words x 32)
-constexpr uint32_t kGroupWords = 768;
+// at most 20 words x 64 environments (12 agents in a shuffled order: 5 words per tick, 4 ticks; cfg4: 3 words per tick -- with two lanes per
+// environment 24 words x 32)
+constexpr uint32_t kGroupWords = 1280;
 // ... and, in the fused rollouts of those kernels, the per-environment cell -> job map behind the group words (susnet_swar.h JobMap:
 // one 64-byte row per cell value x | y << 4 of an N x N grid)
 __host__ __device__ inline uint32_t lds_jobmap_words(int N) { return ((uint32_t)(((N - 1) << 4) | (N - 1)) + 1u) * 16u; }
@@ -468,32 +469,44 @@ struct LdsStore {
 
 // compiled-in flavour (A, J <= 8): byte lanes of packed VGPR words -- a data-dependent index is a shift,
 // never a memory access (per-lane arrays indexed at run time would be demoted to scratch memory)
-template <int N_, bool WIDE = (N_ > 4)>
+template <int N_, int TIER = (N_ > 8 ? 2 : (N_ > 4 ? 1 : 0))>
 struct PackedBytes;
 template <int N_>
-struct PackedBytes<N_, false> { // up to 4 bytes in one VGPR
+struct PackedBytes<N_, 0> { // up to 4 bytes in one VGPR
     uint32_t w = 0;
     __device__ __forceinline__ uint32_t get(int i) const { return (w >> (8 * i)) & 0xffu; }
     __device__ __forceinline__ void set(int i, uint32_t v) { w = (w & ~(0xffu << (8 * i))) | ((v & 0xffu) << (8 * i)); }
 };
 template <int N_>
-struct PackedBytes<N_, true> { // 5..8 bytes in a VGPR pair (measured faster than two halves + selects)
+struct PackedBytes<N_, 1> { // 5..8 bytes in a VGPR pair (measured faster than two halves + selects)
     uint64_t w = 0;
     __device__ __forceinline__ uint32_t get(int i) const { return (uint32_t)(w >> (8 * i)) & 0xffu; }
     __device__ __forceinline__ void set(int i, uint32_t v) { w = (w & ~((uint64_t)0xffu << (8 * i))) | ((uint64_t)(v & 0xffu) << (8 * i)); }
 };
+template <int N_>
+struct PackedBytes<N_, 2> { // 9..12 bytes: the pair + one more VGPR (the byte-parallel kernels for 9 .. 12 agents index it statically)
+    uint64_t w = 0;
+    uint32_t x = 0;
+    __device__ __forceinline__ uint32_t get(int i) const { return i < 8 ? (uint32_t)(w >> (8 * (i & 7))) & 0xffu : (x >> (8 * (i & 3))) & 0xffu; }
+    __device__ __forceinline__ void set(int i, uint32_t v) {
+        const uint64_t nw = (w & ~((uint64_t)0xffu << (8 * (i & 7)))) | ((uint64_t)(v & 0xffu) << (8 * (i & 7)));
+        const uint32_t nx = (x & ~(0xffu << (8 * (i & 3)))) | ((v & 0xffu) << (8 * (i & 3)));
+        w = i < 8 ? nw : w;
+        x = i < 8 ? x : nx;
+    }
+};
 
 template <int A, int J>
 struct RegStore {
-    static_assert(A <= 8 && J <= 8, "RegStore packs at most 8 agents / jobs");
+    static_assert(A <= 12 && J <= 8, "RegStore packs at most 12 agents / 8 jobs");
     PackedBytes<A> xyw, actw;
     PackedBytes<(J > 0 ? J : 1)> jobw;
-    uint32_t cntw = 0; // 4 bits per agent
+    uint32_t cntw = 0; // 4 bits per agent (tag counts: tagging games have at most 8 agents here)
     __device__ __forceinline__ void init(uint32_t *, int, int, int) {}
     __device__ __forceinline__ uint32_t xy(int i) const { return xyw.get(i); }
     __device__ __forceinline__ void set_xy(int i, uint32_t cell) { xyw.set(i, cell); }
-    __device__ __forceinline__ uint32_t cnt(int i) const { return (cntw >> (4 * i)) & 15u; }
-    __device__ __forceinline__ void set_cnt(int i, uint32_t v) { cntw = (cntw & ~(15u << (4 * i))) | ((v & 15u) << (4 * i)); }
+    __device__ __forceinline__ uint32_t cnt(int i) const { return i < 8 ? (cntw >> (4 * (i & 7))) & 15u : 0u; }
+    __device__ __forceinline__ void set_cnt(int i, uint32_t v) { cntw = i < 8 ? (cntw & ~(15u << (4 * (i & 7)))) | ((v & 15u) << (4 * (i & 7))) : cntw; }
     __device__ __forceinline__ void set_agent(int i, uint32_t cell, uint32_t c) { set_xy(i, cell); set_cnt(i, c); }
     __device__ __forceinline__ uint32_t job(int j) const { return jobw.get(j); }
     __device__ __forceinline__ void set_job(int j, uint32_t v) { jobw.set(j, v); }
@@ -665,6 +678,16 @@ __device__ __forceinline__ void shuffle_nibbles(RNG &rng, ORD &v, int n) {
 #pragma unroll
     for (int i = n - 1; i >= 1; i--) {
         int j = (int)(STATIC ? rng.bounded_at((uint32_t)i + 1u, n - 1 - i) : rng.bounded((uint32_t)i + 1u));
+        nibble_swap(v, i, j);
+    }
+}
+
+// the same with the loop left ROLLED (9 .. 12 agents on numpy tapes: eleven unrolled rejection loops cost the fused rollouts their last registers)
+template <class RNG, class ORD>
+__device__ __forceinline__ void shuffle_nibbles_rolled(RNG &rng, ORD &v, int n) {
+#pragma clang loop unroll(disable)
+    for (int i = n - 1; i >= 1; i--) {
+        const int j = (int)rng.bounded((uint32_t)i + 1u);
         nibble_swap(v, i, j);
     }
 }

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     typename StoreFor<S>::type st;
     Tables T = setup_lds<S, true, true>(c, smem, tid, st);
     if (tid < 16) T.comp[tid] = (uint32_t)o.comp[tid];
-    if (!RNG::kNumpy && RankLut<S>::kOk) build_rank_lut<S>(smem, tid);
+    if constexpr (!RNG::kNumpy && RankLut<S>::kOk) build_rank_lut<S>(smem, tid);
     JobMap::clear_all(kJobMapWord, c.N, tid); // the cell -> job map (susnet_swar.h): zeroed once, then kept by the lanes that own the columns
     wave_lds_fence();
     JobMap jm;
@@ -755,10 +755,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     life.clear();
     const int64_t AB = (int64_t)A * c.B;
     const int64_t bb = active ? b : 0;
-    uint8_t *pa = a.actions ? a.actions + bb * A : nullptr;
-    float *pr = a.rewards ? a.rewards + bb * A : nullptr;
-    uint8_t *pd = a.done ? a.done + bb : nullptr;
-    uint8_t *pt = a.trunc ? a.trunc + bb : nullptr;
+    // OUT_ANY: the four optional trajectory outputs, addressed from the tick index where they are stored (round 4 carried four 64-bit
+    // per-lane cursors through the step: eight registers the 12-agent kernels do not have)
+    auto any_ptr = [&](auto *base, int tick, int64_t per_tick, int64_t lane_off) __attribute__((always_inline)) {
+        return base ? base + ((int64_t)tick * per_tick + lane_off) : base;
+    };
     constexpr int kRawF = S::kRawF;
     const uint64_t nt = (uint64_t)(a.n_ticks > 0 ? a.n_ticks : 0);
     BufDst da = make_buf_dst(a.actions, nt * (uint64_t)AB, (uint32_t)(bb * A));
@@ -840,7 +841,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
     // writer that pushed the 5..8-agent kernels past 256 vector registers, i.e. into accumulator-register copies inside code that runs
     // under divergent EXEC by design (isa_checks.parked_under_divergence).  There a finishing lane draws its episode on the spot -- the
     // same RESET-stream words, so the same episode.
-    constexpr bool kAhead = !RNG::kNumpy && OUT != OUT_ANY;
+    // (nor with 9 .. 12 agents: three words per quantity, 60 registers per copy of the state)
+    constexpr bool kAhead = !RNG::kNumpy && OUT != OUT_ANY && S::kA <= 8;
     W wn = w;
     typename StoreFor<S>::type stn = st;
     uint32_t impn = 0;
@@ -858,7 +860,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 identity_ranks<S>(R);
                 if (S::kOrd > 0) {
                     OrderOf<S> ord = (OrderOf<S>)0xFEDCBA9876543210ull;
-                    shuffle_nibbles<false>(rng, ord, A);
+                    if constexpr (A > 8) shuffle_nibbles_rolled(rng, ord, A);
+                    else shuffle_nibbles<false>(rng, ord, A);
                     ranks_from_order<S>(ord, R);
                 }
             } else {
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 KSTAMP(0);
             }
             if (kTraj) store_packed_bytes<A>(da, act);
-            else if (OUT == OUT_ANY && pa != nullptr) store_packed_bytes<A>(PtrDst{pa}, act);
+            else if (OUT == OUT_ANY && a.actions != nullptr) store_packed_bytes<A>(PtrDst{any_ptr(a.actions, tick, AB, bb * A)}, act);
             float rr[A];
             bool done, trunc;
             // (the win rules run unconditionally at the launch's first tick only: the state may come from outside; see step_swar)
@@ -891,9 +894,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 dd.st8(0u, done ? 1u : 0u);
                 dt.st8(0u, trunc ? 1u : 0u);
             } else if (OUT == OUT_ANY) {
-                if (pr != nullptr) store_row_f32<A>(PtrDst{reinterpret_cast<uint8_t *>(pr)}, rr);
-                if (pd != nullptr) *pd = done ? 1 : 0;
-                if (pt != nullptr) *pt = trunc ? 1 : 0;
+                if (a.rewards != nullptr) store_row_f32<A>(PtrDst{reinterpret_cast<uint8_t *>(any_ptr(a.rewards, tick, AB, bb * A))}, rr);
+                if (a.done != nullptr) *any_ptr(a.done, tick, (int64_t)c.B, bb) = done ? 1 : 0;
+                if (a.trunc != nullptr) *any_ptr(a.trunc, tick, (int64_t)c.B, bb) = trunc ? 1 : 0;
             }
             if (kFeed(OUT) && a.roles != nullptr) a.roles[(int64_t)tick * c.B + b] = (uint16_t)swar_imp_bits(w);
             KSTAMP(2);
@@ -1042,12 +1045,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                 store_record_planar<kRecDwords>(drec, (uint32_t)c.B, (uint32_t)bb, rec);
             }
             KSTAMP(4);
-            if (OUT == OUT_ANY) {
-                pa = pa ? pa + AB : pa;
-                pr = pr ? pr + AB : pr;
-                pd = pd ? pd + c.B : pd;
-                pt = pt ? pt + c.B : pt;
-            }
         }
         if (OUT == OUT_ANY) { // any observation mode: through the cooperative writer, on the bitmask / packed-store form
             if (active) from_swar<S>(c, w, st, e);
@@ -1551,7 +1548,9 @@ void launch_rollout(bool tape, int out, dim3 g, dim3 blk, size_t sh, hipStream_t
         else if (out == OUT_TRAJ_RAW8) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ_RAW8>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_TRAJ) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_TRAJ>), g, blk, sh, st, c, s, a, o);
         else if (out == OUT_RECORD) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_RECORD>), g, blk, sh, st, c, s, a, o);
-        else hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
+        else if constexpr (SPEC::kA <= 8) hipLaunchKernelGGL((k_rollout_swar<SPEC, OUT_ANY>), g, blk, sh, st, c, s, a, o);
+        // (9 .. 12 agents: OUT_ANY -- float observations, partial outputs -- runs the generic kernel, chosen by the host: the general
+        // observation writer beside three words per quantity does not fit 256 vector registers)
     } else {
         if (tape && out == OUT_RECORD) { // (SpecCfg2 on a wall map: the table kernel)
             if constexpr (!SPEC::kGeneric && SPEC::kRawF > 0) hipLaunchKernelGGL((k_rollout<SPEC, OUT_RECORD, TapeRng>), g, blk, sh, st, c, s, a, o);

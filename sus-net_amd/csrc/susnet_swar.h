@@ -40,8 +40,10 @@ template <class S>
 struct UseSwar {
     // (kJ = -1: the job count is read at run time -- at most 8 -- : the FAMILY of byte-parallel kernels, one instantiation per agent
     // count, variant, order and imposter count, serving every job count: susnet_kernels.h SpecFam)
-    static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kA <= 8 && S::kJ >= -1 && S::kJ <= 8 && S::kOrd >= 0 &&
-                                  (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG || S::kVar == SUSNET_VARIANT_TAGGING) &&
+    // (9 .. 12 agents -- three words of agent bytes: FourRoomEnv / ImposterTrainingGround rules; the tag section pairs words by v_perm and stays at 8)
+    static constexpr bool value = !S::kGeneric && S::kA >= 3 && S::kJ >= -1 && S::kJ <= 8 && S::kOrd >= 0 &&
+                                  ((S::kA <= 8 && (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG || S::kVar == SUSNET_VARIANT_TAGGING)) ||
+                                   (S::kA <= 12 && (S::kVar == SUSNET_VARIANT_BASE || S::kVar == SUSNET_VARIANT_ITG))) &&
                                   (S::kNI >= 1 && S::kNI <= 3);
 };
 
@@ -164,12 +166,16 @@ struct Swar {
     uint32_t ridx[NW];         //   per agent the byte index into the reward table of "no assignment, nobody won": 16 if dead + 32 for indices [:n_imposters] (base.py:559,562)
     uint32_t im80[NW];         // imposter: 0x80 per agent (constant within an episode)
     uint32_t isel[NI];         // v_perm selector that extracts imposter s's byte (zeros elsewhere)
-    uint32_t iselb[NI];        // v_perm selector that puts imposter s's byte into ALL four bytes
-    uint32_t ihot[NI][NW];     // 0x80 at imposter s's byte
+    uint32_t iselb[NW > 2 ? 1 : NI]; // v_perm selector that puts imposter s's byte into ALL four bytes (over the pair {word 1, word 0}); with three
+                               // words of agents it is formed from isel where it is used, together with its twin over word 2 (swar_isel_all)
+    // (three words of agents -- 9 .. 12 -- keep neither ihot nor nact: both follow from isel / im80 in a few instructions where they
+    // are needed, and the fused rollouts of those games have no registers to spare)
+    static constexpr bool kLean = NW > 2;
+    uint32_t ihot[kLean ? 1 : NI][kLean ? 1 : NW]; // 0x80 at imposter s's byte
     uint32_t jb[JMAX > 0 ? JMAX : 1]; // job cell in all four bytes (constant within an episode)
     uint32_t jobs_obs[JMAX > 4 ? 4 : 2]; // x0 y0 x1 y1 | x2 y2 x3 y3 | ... of the job cells (observation bytes; constant within an episode)
     uint32_t jd[JW];           // completed: 0x01 per job
-    uint32_t nact[A];          // len(agent_action_map[i]) (constant within an episode)
+    uint32_t nact[kLean ? 1 : A]; // len(agent_action_map[i]) (constant within an episode)
     // tagging.py: used_tag_actions (0x01 per agent), tag_counts (one byte per agent), tag_reset_timer
     uint32_t used[NW], cnt[NW], timer;
 };
@@ -178,12 +184,12 @@ struct Swar {
 template <class S>
 __device__ __forceinline__ void swar_refresh_alive(Swar<S> &w) {
     using W = Swar<S>;
-    constexpr uint32_t neg32[2] = {(W::NI >= 1 ? 0x20u : 0u) | (W::NI >= 2 ? 0x2000u : 0u) | (W::NI >= 3 ? 0x200000u : 0u), 0u}; // indices [:n_imposters], NOT the imposter mask (base.py:559)
+    constexpr uint32_t neg32 = (W::NI >= 1 ? 0x20u : 0u) | (W::NI >= 2 ? 0x2000u : 0u) | (W::NI >= 3 ? 0x200000u : 0u); // indices [:n_imposters], NOT the imposter mask (base.py:559)
 #pragma unroll
     for (int q = 0; q < W::NW; q++) {
         w.al80[q] = (w.al[q] & k01) << 7;
         w.crew80[q] = w.al80[q] & ~w.im80[q];
-        w.ridx[q] = (((w.al[q] & k01) ^ k01) << 4) + neg32[q > 0 ? 1 : 0]; // (bytes past the last agent read as dead: never looked up)
+        w.ridx[q] = (((w.al[q] & k01) ^ k01) << 4) + (q == 0 ? neg32 : 0u); // (bytes past the last agent read as dead: never looked up)
     }
 }
 
@@ -198,8 +204,10 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
 #pragma unroll
     for (int s = 0; s < W::NI; s++) {
         w.isel[s] = 0x0c0c0c0cu;
+        if constexpr (!W::kLean) {
 #pragma unroll
-        for (int q = 0; q < W::NW; q++) w.ihot[s][q] = 0;
+            for (int q = 0; q < W::NW; q++) w.ihot[s][q] = 0;
+        }
     }
     uint32_t seen = 0; // imposters met so far (ascending agent index)
 #pragma unroll
@@ -209,7 +217,7 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
         w.al[q] |= ((e.alive >> i) & 1u) << sh;
         const uint32_t is = (imp >> i) & 1u;
         w.im80[q] |= (is << 7) << sh;
-        w.nact[i] = S::nr_crew(c) + is + (W::kTag ? (uint32_t)(W::A - 1) : 0u); // imposters have one more action (base.py:82-99, pred_prey.py:4-19); tagging.py:68-75
+        if constexpr (!W::kLean) w.nact[i] = S::nr_crew(c) + is + (W::kTag ? (uint32_t)(W::A - 1) : 0u); // imposters have one more action (base.py:82-99, pred_prey.py:4-19); tagging.py:68-75
         if (W::kTag) {
             w.used[q] |= ((e.used >> i) & 1u) << sh;
             w.cnt[q] |= st.cnt(i) << sh;
@@ -217,14 +225,17 @@ __device__ __forceinline__ void to_swar(const Consts &c, const Store &st, const 
 #pragma unroll
         for (int s = 0; s < W::NI; s++) {
             const bool mine = is && seen == (uint32_t)s;
-            w.isel[s] = mine ? (0x0c0c0c00u | (uint32_t)i) : w.isel[s]; // byte i of {word 1, word 0} -> byte 0
-            w.ihot[s][q] |= mine ? (0x80u << sh) : 0u;
+            w.isel[s] = mine ? (0x0c0c0c00u | (uint32_t)i) : w.isel[s]; // byte i of {word 1, word 0} -> byte 0 (i >= 8: of word 2, see iselb / iselc)
+            if constexpr (!W::kLean) w.ihot[s][q] |= mine ? (0x80u << sh) : 0u;
         }
         seen += is;
     }
     swar_refresh_alive<S>(w);
 #pragma unroll
-    for (int s = 0; s < W::NI; s++) w.iselb[s] = (w.isel[s] & 0xffu) * k01;
+    for (int s = 0; s < W::NI; s++) {
+        const uint32_t idx = w.isel[s] & 0xffu; // (0x0c: the slot has no imposter)
+        if constexpr (W::NW <= 2) w.iselb[s] = idx * k01;
+    }
 #pragma unroll
     for (int q = 0; q < W::JW; q++) w.jd[q] = 0;
 #pragma unroll
@@ -267,6 +278,12 @@ __device__ __forceinline__ void from_swar(const Consts &c, const Swar<S> &w, Sto
 // imposter flag (0 / 1) of agent i
 template <class S>
 __device__ __forceinline__ uint32_t swar_is_imp(const Swar<S> &w, int i) { return (w.im80[i / 4] >> (8 * (i & 3) + 7)) & 1u; }
+// len(agent_action_map[i]): kept per agent, or (kLean) the role list's length from the imposter flag (base.py:82-99, pred_prey.py:4-19)
+template <class S>
+__device__ __forceinline__ uint32_t swar_nact(const Consts &c, const Swar<S> &w, int i) {
+    if constexpr (Swar<S>::kLean) return S::nr_crew(c) + swar_is_imp(w, i);
+    else return w.nact[i];
+}
 template <class S>
 __device__ __forceinline__ uint32_t swar_imp_bits(const Swar<S> &w) {
     uint32_t m = 0;
@@ -306,7 +323,10 @@ __device__ __forceinline__ void sample_actions_swar(const Consts &c, const WT &w
         if (i == 0 || k != S::kAw.word[i - 1])
             word = POS >= 0 ? as.word_in_group(rng, (tick - (uint64_t)(POS >= 0 ? POS : 0)) * Wt, (POS >= 0 ? POS : 0) * S::kAw.W + k)
                             : as.word(rng, tick * Wt + (uint64_t)k);
-        const uint64_t p = (uint64_t)word * (uint64_t)w.nact[i];
+        uint32_t n_i;
+        if constexpr (std::is_same<WT, Swar<S>>::value) n_i = swar_nact<S>(c, w, i);
+        else n_i = w.nact[i];
+        const uint64_t p = (uint64_t)word * (uint64_t)n_i;
         dg[i] = (uint32_t)(p >> 32);
         word = (uint32_t)p;
     }
@@ -319,23 +339,34 @@ __device__ __forceinline__ void sample_actions_swar(const Consts &c, const Swar<
 #pragma unroll
     for (int q = 0; q < W::NW; q++) act[q] = 0;
 #pragma unroll
-    for (int i = 0; i < W::A; i++) act[i / 4] |= rng.bounded(w.nact[i]) << (8 * (i & 3));
+    for (int i = 0; i < W::A; i++) act[i / 4] |= rng.bounded(swar_nact<S>(c, w, i)) << (8 * (i & 3));
 }
 
 // ranks (byte = rank | 0x80) from a turn order (4 bits per turn): the numpy-parity path shuffles an order list
 template <class S, class ORD>
 __device__ __forceinline__ void ranks_from_order(ORD order, uint32_t (&R)[Swar<S>::NW]) {
     using W = Swar<S>;
-    uint64_t r = 0;
+    if constexpr (W::NW <= 2) {
+        uint64_t r = 0;
 #pragma unroll
-    for (int k = 0; k < W::A; k++) r |= (uint64_t)(0x80u | (uint32_t)k) << (8u * nibble(order, k));
-    R[0] = (uint32_t)r;
-    if (W::NW > 1) R[W::NW - 1] = (uint32_t)(r >> 32);
+        for (int k = 0; k < W::A; k++) r |= (uint64_t)(0x80u | (uint32_t)k) << (8u * nibble(order, k));
+        R[0] = (uint32_t)r;
+        if (W::NW > 1) R[W::NW - 1] = (uint32_t)(r >> 32);
+    } else { // (three words: the word is picked with masks -- a run-time index into R[] would put it in scratch memory)
+#pragma unroll
+        for (int q = 0; q < W::NW; q++) R[q] = 0u;
+#pragma unroll
+        for (int k = 0; k < W::A; k++) {
+            const uint32_t pos = nibble(order, k), v = (0x80u | (uint32_t)k) << (8u * (pos & 3u));
+#pragma unroll
+            for (int q = 0; q < W::NW; q++) R[q] |= (pos >> 2) == (uint32_t)q ? v : 0u;
+        }
+    }
 }
 template <class S>
 __device__ __forceinline__ void identity_ranks(uint32_t (&R)[Swar<S>::NW]) {
-    R[0] = 0x83828180u;
-    if (Swar<S>::NW > 1) R[Swar<S>::NW - 1] = 0x87868584u;
+#pragma unroll
+    for (int q = 0; q < Swar<S>::NW; q++) R[q] = 0x83828180u + 0x04040404u * (uint32_t)q;
 }
 
 // ---- turn ranks from tables ---------------------------------------------------------------------------------------------------
@@ -477,7 +508,9 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     using W = Swar<S>;
     constexpr int A = W::A, J = W::JMAX, NW = W::NW, NI = W::NI; // (J: job SLOTS; the job count itself is Jn)
     const int Jn = S::J(c);
-    constexpr uint32_t kLive[2] = {A >= 4 ? 0xffffffffu : (1u << (8 * (A & 3))) - 1u, A >= 8 ? 0xffffffffu : (A > 4 ? (1u << (8 * (A & 3))) - 1u : 0u)};
+    static_assert(!W::kTag || NW <= 2, "the tag section pairs the two agent words by v_perm");
+    constexpr uint32_t kLive[3] = {A >= 4 ? 0xffffffffu : (1u << (8 * (A & 3))) - 1u, A >= 8 ? 0xffffffffu : (A > 4 ? (1u << (8 * (A & 3))) - 1u : 0u),
+                                   A >= 12 ? 0xffffffffu : (A > 8 ? (1u << (8 * (A & 3))) - 1u : 0u)};
     e.m_steps += 1; // base.py:366
     // production protocol: the event cursor is block-aligned at the start of a step.  It only ever moves in the kill tail (one word
     // per landed kill), so the fused rollouts (JobMap flavour) align once per launch and again right after a kill (realign_after_kill)
@@ -574,10 +607,19 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         uint32_t kb[NI], rb[NI], cb[NI]; // per imposter slot, in ALL four bytes: kill flag (0x80 / 0), rank | 0x80, cell
 #pragma unroll
         for (int s = 0; s < NI; s++) {
-            const uint32_t hi = NW > 1 ? NW - 1 : 0;
-            kb[s] = __builtin_amdgcn_perm(NW > 1 ? kill80[hi] : 0u, kill80[0], w.iselb[s]);
-            rb[s] = __builtin_amdgcn_perm(NW > 1 ? R[hi] : 0u, R[0], w.iselb[s]);
-            cb[s] = __builtin_amdgcn_perm(NW > 1 ? w.xy[hi] : 0u, w.xy[0], w.iselb[s]);
+            if constexpr (NW > 2) { // imposter s among agents 0 .. 7: its byte of the pair {word 1, word 0}; among 8 .. 11: of word 2 (the other
+                                    // selector yields zeros; 0x0c0c0c0c: no imposter in the slot)
+                const uint32_t idx = w.isel[s] & 0xffu;
+                const uint32_t sb = idx < 8u ? idx * k01 : 0x0c0c0c0cu, sc = (idx >= 8u && idx < 12u) ? (idx - 8u) * k01 : 0x0c0c0c0cu;
+                kb[s] = __builtin_amdgcn_perm(kill80[1], kill80[0], sb) | __builtin_amdgcn_perm(0u, kill80[NW > 2 ? 2 : 0], sc);
+                rb[s] = __builtin_amdgcn_perm(R[1], R[0], sb) | __builtin_amdgcn_perm(0u, R[NW > 2 ? 2 : 0], sc);
+                cb[s] = __builtin_amdgcn_perm(w.xy[1], w.xy[0], sb) | __builtin_amdgcn_perm(0u, w.xy[NW > 2 ? 2 : 0], sc);
+            } else {
+                kb[s] = __builtin_amdgcn_perm(NW > 1 ? kill80[NW > 1 ? 1 : 0] : 0u, kill80[0], w.iselb[s]);
+                rb[s] = __builtin_amdgcn_perm(NW > 1 ? R[NW > 1 ? 1 : 0] : 0u, R[0], w.iselb[s]);
+                cb[s] = __builtin_amdgcn_perm(NW > 1 ? w.xy[NW > 1 ? 1 : 0] : 0u, w.xy[0], w.iselb[s]);
+            }
+
         }
         bool second_first = false; // two imposters: the one with the earlier turn kills first
         if (NI == 2) second_first = kb[1] != 0u && (kb[0] == 0u || rb[1] < rb[0]);
@@ -604,8 +646,14 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                 kbi = (kb[0] & p0) | (kb[i1] & p1) | (kb[i2] & p2);
                 rbi = (rb[0] & p0) | (rb[i1] & p1) | (rb[i2] & p2);
                 cbi = (cb[0] & p0) | (cb[i1] & p1) | (cb[i2] & p2);
+                if constexpr (W::kLean) {
+                    const uint32_t idx = ((w.isel[0] & p0) | (w.isel[i1] & p1) | (w.isel[i2] & p2)) & 0xffu;
 #pragma unroll
-                for (int q = 0; q < NW; q++) hot_of[q] = (w.ihot[0][q] & p0) | (w.ihot[i1][q] & p1) | (w.ihot[i2][q] & p2);
+                    for (int q = 0; q < NW; q++) hot_of[q] = (idx >> 2) == (uint32_t)q ? 0x80u << (8u * (idx & 3u)) : 0u;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NW; q++) hot_of[q] = (w.ihot[0][q] & p0) | (w.ihot[W::kLean ? 0 : i1][q] & p1) | (w.ihot[W::kLean ? 0 : i2][q] & p2);
+                }
                 key3[0] |= p0 & 0x200u; // (taken)
                 key3[1] |= p1 & 0x200u;
                 key3[2] |= p2 & 0x200u;
@@ -613,8 +661,14 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                 kbi = second_first ? kb[s1] : kb[s0];
                 rbi = second_first ? rb[s1] : rb[s0];
                 cbi = second_first ? cb[s1] : cb[s0];
+                if constexpr (W::kLean) {
+                    const uint32_t idx = (second_first ? w.isel[s1] : w.isel[s0]) & 0xffu;
 #pragma unroll
-                for (int q = 0; q < NW; q++) hot_of[q] = second_first ? w.ihot[s1][q] : w.ihot[s0][q];
+                    for (int q = 0; q < NW; q++) hot_of[q] = (idx >> 2) == (uint32_t)q ? 0x80u << (8u * (idx & 3u)) : 0u;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NW; q++) hot_of[q] = second_first ? w.ihot[W::kLean ? 0 : s1][q] : w.ihot[W::kLean ? 0 : s0][q];
+                }
             }
             // (no ballot on "somebody attempts" for the first kill turn: in a wave of 64 environments somebody nearly always does;
             // the second turn only has work where BOTH imposters attempt)
@@ -635,8 +689,14 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             // base.py:497: uniform among the candidates (ascending agent index).  With one candidate -- nearly always --
             // the victim is the lowest set flag; several candidates (rare) are handled behind a wave-uniform branch.
             uint32_t v80[NW];
-            v80[0] = cand[0] & (0u - cand[0]);
-            if (NW > 1) v80[NW - 1] = cand[0] != 0u ? 0u : (cand[NW - 1] & (0u - cand[NW - 1]));
+            {
+                uint32_t seen = 0u; // (0 / all ones) a lower word had a candidate
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    v80[q] = (cand[q] & (0u - cand[q])) & ~seen;
+                    seen |= 0u - (cand[q] != 0u ? 1u : 0u);
+                }
+            }
             uint32_t before = 0; // kills of THIS step that this environment landed already
 #pragma unroll
             for (int q = 0; q < NW; q++) before += (uint32_t)__popc(kc80[q]);
@@ -644,14 +704,24 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
                 if (nc > 1u) {
                     if (!RNG::kNumpy) rng.cur = cur0 + (uint64_t)before; // production protocol: one word per landed kill, its value only matters here
                     const uint32_t r = rng.bounded(nc); // numpy draws nothing for a single candidate: only here
-                    uint32_t c0 = cand[0], c1 = NW > 1 ? cand[NW - 1] : 0u;
-                    for (uint32_t k = 0; k < r; k++) {
-                        const bool lo = c0 != 0u;
-                        c0 = lo ? (c0 & (c0 - 1u)) : c0;
-                        c1 = lo ? c1 : (c1 & (c1 - 1u));
+                    uint32_t cw[NW];
+#pragma unroll
+                    for (int q = 0; q < NW; q++) cw[q] = cand[q];
+                    for (uint32_t k = 0; k < r; k++) { // drop the lowest candidate (ascending agent index), r times
+                        uint32_t dropped = 0u;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) {
+                            const uint32_t here = (cw[q] != 0u ? 1u : 0u) & ~dropped;
+                            cw[q] = here ? (cw[q] & (cw[q] - 1u)) : cw[q];
+                            dropped |= here;
+                        }
                     }
-                    v80[0] = c0 & (0u - c0);
-                    if (NW > 1) v80[NW - 1] = c0 != 0u ? 0u : (c1 & (0u - c1));
+                    uint32_t seen = 0u;
+#pragma unroll
+                    for (int q = 0; q < NW; q++) {
+                        v80[q] = (cw[q] & (0u - cw[q])) & ~seen;
+                        seen |= 0u - (cw[q] != 0u ? 1u : 0u);
+                    }
                 }
             }
             const bool hit = nc != 0u;
@@ -870,15 +940,29 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
             any_new |= vt80[q];
         }
         if (__builtin_amdgcn_ballot_w64(any_new != 0u) != 0ull) { // tag_counts[target] += 1 per counted tag
-            uint64_t cn = (uint64_t)w.cnt[0] | ((uint64_t)(NW > 1 ? w.cnt[hi] : 0u) << 32);
+            // the step's increments first, FOUR bits per target in one register (a target collects at most A - 1 <= 7 tags): a shift-and-add
+            // per tagger (round 4: a 64-bit shift and a 64-bit add per tagger on the byte counts themselves: ~35 instructions a tick) ...
+            uint32_t inc4 = 0;
+            uint32_t sh4[NW];
+#pragma unroll
+            for (int q = 0; q < NW; q++) sh4[q] = tgt[q] << 2; // 4 * target per agent byte (< 32)
 #pragma unroll
             for (int i = 0; i < A; i++) {
-                const uint32_t bit = (vt80[i / 4] >> (8 * (i & 3) + 7)) & 1u;
-                const uint32_t sh = ((tgt[i / 4] >> (8 * (i & 3))) & 7u) << 3;
-                cn += (uint64_t)bit << sh;
+                const uint32_t bit = __builtin_amdgcn_ubfe(vt80[i / 4], 8u * (uint32_t)(i & 3) + 7u, 1u);
+                const uint32_t sh = __builtin_amdgcn_ubfe(sh4[i / 4], 8u * (uint32_t)(i & 3), 5u);
+                inc4 += bit << sh;
             }
-            w.cnt[0] = (uint32_t)cn;
-            if (NW > 1) w.cnt[hi] = (uint32_t)(cn >> 32);
+            // ... then spread to one byte per target and added to the counts (no byte overflows: counts stay below 8)
+            uint32_t lo = inc4 & 0xffffu;
+            lo = (lo | (lo << 8)) & 0x00ff00ffu;
+            lo = (lo | (lo << 4)) & 0x0f0f0f0fu;
+            w.cnt[0] += lo;
+            if (NW > 1) {
+                uint32_t hi4 = inc4 >> 16;
+                hi4 = (hi4 | (hi4 << 8)) & 0x00ff00ffu;
+                hi4 = (hi4 | (hi4 << 4)) & 0x0f0f0f0fu;
+                w.cnt[hi] += hi4;
+            }
         }
         // tagging.py:180: tag_counts *= alive_agents.  A count only ever grows on a LIVING target (tagging.py:105), so the product
         // changes something exactly when this step killed somebody (a vote's ejection is followed by the reset of all counts) --
@@ -895,14 +979,19 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
         w.timer += 1u;                                                               // tagging.py:182
         const bool due = w.timer >= (uint32_t)c.tag_interval;
         if (__builtin_amdgcn_ballot_w64(due) != 0ull) { // tagging.py:184-207
-            uint32_t best = 0, highest = w.cnt[0] & 0xffu;
+            // np.argmax (first maximum) as ONE maximum over keys count << 3 | (7 - index): a larger count wins, among equal counts the
+            // lower index (counts < 8: a key fits its byte)
+            uint32_t kmax = 0;
 #pragma unroll
-            for (int i = 1; i < A; i++) { // np.argmax: first maximum
-                const uint32_t v = (w.cnt[i / 4] >> (8 * (i & 3))) & 0xffu;
-                const bool gt = v > highest;
-                highest = gt ? v : highest;
-                best = gt ? (uint32_t)i : best;
+            for (int q = 0; q < NW; q++) {
+                const uint32_t keys = (w.cnt[q] << 3) + (q == 0 ? 0x04050607u : 0x00010203u);
+#pragma unroll
+                for (int i = 4 * q; i < A && i < 4 * q + 4; i++) {
+                    const uint32_t kv = __builtin_amdgcn_ubfe(keys, 8u * (uint32_t)(i & 3), 8u);
+                    kmax = kv > kmax ? kv : kmax;
+                }
             }
+            const uint32_t best = 7u - (kmax & 7u), highest = kmax >> 3;
             uint32_t alive_sum = 0;
 #pragma unroll
             for (int q = 0; q < NW; q++) alive_sum += (uint32_t)__popc(w.al[q] & kLive[q] & k01);

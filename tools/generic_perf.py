@@ -1,5 +1,6 @@
 """Throughput of configurations OTHER than the four fully compiled-in BASELINE games: the byte-parallel family kernels (any job count up
-to 8, 3..8 agents, at most 2 imposters: susnet_family.h) and the per-turn kernels behind them. GPU box only.
+to 8, 3..12 agents -- tagging 3..8 --, at most 3 imposters: susnet_family.h), the 1v1 wall-map duel kernel and the generic kernels behind
+them. GPU box only.
 Both trajectory layouts: separate tensors (actions, rewards, done, truncated, raw uint8 observation) and packed records."""
 import importlib
 import sys
@@ -18,7 +19,9 @@ cases = {
     "base 1v2 j4 14x14 (cfg3: compiled in)": lambda: pkg.BatchedFourRoomEnv(1, 2, 4, grid_size=14, **kw),
     "base 1v2 j3 14x14": lambda: pkg.BatchedFourRoomEnv(1, 2, 3, grid_size=14, **kw),
     "base 2v6 j5 14x14": lambda: pkg.BatchedFourRoomEnv(2, 6, 5, grid_size=14, **kw),
-    "base 3v9 j8 16x16 (per-turn kernels)": lambda: pkg.BatchedFourRoomEnv(3, 9, 8, grid_size=16, **kw),
+    "base 3v9 j8 16x16 (12 agents, 3 imposters)": lambda: pkg.BatchedFourRoomEnv(3, 9, 8, grid_size=16, **kw),
+    "base 3v5 j3 (three imposters)": lambda: pkg.BatchedFourRoomEnv(3, 5, 3, **kw),
+    "base 4v9 j4 16x16 (13 agents: generic kernels)": lambda: pkg.BatchedFourRoomEnv(4, 9, 4, grid_size=16, **kw),
     "tagging 2v6 j4 14x14": lambda: pkg.BatchedFourRoomEnvWithTagging(2, 6, 4, grid_size=14, **kw),
     "tagging 1v4 j5 (tag5: compiled in)": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 5, **kw),
     "tagging 1v4 j4": lambda: pkg.BatchedFourRoomEnvWithTagging(1, 4, 4, **kw),
