@@ -487,9 +487,11 @@ def main():
             issued = 2.0 * B * sum(a * b for a, b in zip(pad[1:-1], pad[2:]))       # layers 2..5 at their padded widths: what the matrix core executes
             model_flops = 2.0 * B * sum(a * b for a, b in zip(net.dims[:-1], net.dims[1:]))  # the reference MLP's own multiply-adds, layer 1 included
             traffic, traffic_source = None, None
-            cpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_qnet_counters.json")
-            if B == 65536 and os.path.exists(cpath):  # WRITE_SIZE + 2 x FETCH_SIZE of the same kernel on the same batch (tools/profile_cfg5.sh)
-                traffic, traffic_source = json.load(open(cpath)).get("traffic_bytes_per_launch"), "profiles/r04_qnet_counters.json"
+            import glob
+
+            cpaths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_qnet_counters.json")))
+            if B == 65536 and cpaths:  # WRITE_SIZE + 2 x FETCH_SIZE of the same kernel on the same batch (tools/profile_cfg5.sh): the newest round's
+                traffic, traffic_source = json.load(open(cpaths[-1])).get("traffic_bytes_per_launch"), "profiles/" + os.path.basename(cpaths[-1])
             alone = {"kernel": "k_qnet<FlatRow<2,3,14>> (susnet_qnet_forward), 50 launches outside the timed region", "avg_launch_us": us,
                      "achieved": issued / us / 1e6, "frac": issued / us / 1e6 / MFMA_F32_PEAK_TFLOPS, "model_tflops": model_flops / us / 1e6,
                      "traffic": traffic, "traffic_source": traffic_source}

@@ -316,6 +316,8 @@ CONFIGS = {
     "tagging_2v6_j4_14": dict(cls="tagging", kw=dict(n_imposters=2, n_crew=6, n_jobs=4, tag_reset_interval=11, time_step_reward=-1), n=14),
     "itg_1v5_j3": dict(cls="itg", kw=dict(n_crew=5, n_jobs=3, kill_reward=-3, sabotage_reward=1, end_of_game_reward=7,
                                          time_step_reward=-1, shuffle_imposter_index=True), n=9),
+    # notebooks/visualizing_games.ipynb: ImposterTrainingGround(n_crew=10): 11 agents = three words of agent bytes (round 5)
+    "itg_1v10": dict(cls="itg", kw=dict(n_crew=10, n_jobs=0, kill_reward=-3, sabotage_reward=0, end_of_game_reward=0, time_step_reward=0), n=9),
 }
 
 
@@ -587,7 +589,8 @@ def test_sharding_is_invisible(pkg, oracle_mod):
     np.testing.assert_array_equal(tot, np_(lo.lifetime_totals()) + np_(hi.lifetime_totals()))
 
 
-@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "itg_1v1_walls", "itg_1v1_shuffle", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v5_j3"])
+@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "itg_1v1_walls", "itg_1v1_shuffle", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v5_j3",
+                                  "itg_1v10", "base_3v9_j8_16"])
 def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
     B, T, seed = 1000, 120, 9
     env, ob = make_pair(pkg, oracle_mod, name, B, seed, auto_reset=True, check_errors=False)
@@ -629,7 +632,7 @@ def test_fused_rollout_matches_oracle(pkg, oracle_mod, name):
     compare_full_state(env, ob, f"{name} after the short launches")
 
 
-@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "itg_1v1_walls", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5"])
+@pytest.mark.parametrize("name", ["itg_1v1_nowalls", "itg_1v1_walls", "base_1v2_j4_14", "base_2v6_j4_14", "tagging_1v4_j5", "itg_1v10", "base_3v9_j8_16"])
 def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch):
     """The packed per-env-step record (one wide store per lane) holds the same fields as the separate trajectory tensors;
     its strided views are checked against the oracle loop, across launches of odd lengths and a chunked launch."""
@@ -638,7 +641,8 @@ def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch
     if env.record_layout() is None:
         pytest.skip("configuration not compiled in")
     lay = env.record_layout()
-    assert lay.record_bytes % 4 == 0 and max(lay.off_obs + env.flattened_state_size, lay.off_truncated + 1) <= lay.record_bytes
+    segs = [tuple(lay.obs_segments[k]) for k in range(lay.n_obs_segments)]  # (family records: the observation in up to four segments)
+    assert lay.record_bytes % 4 == 0 and sum(n for _, n in segs) == env.flattened_state_size and lay.off_truncated + 1 <= lay.record_bytes
     env.reset()
     ob.reset(threads=0)
     obs_cfg = pkg.ObsConfig("raw", dtype=torch.uint8)
@@ -657,11 +661,11 @@ def test_packed_record_rollout_matches_oracle(pkg, oracle_mod, name, monkeypatch
             ob.reset(mask=(odone | otrunc).astype(bool))
             np.testing.assert_array_equal(np_(traj["obs"])[s], ob.obs_raw_u8())
         used = np.zeros(lay.record_bytes, dtype=bool)  # (the field order is the layout's business: read it through the offsets)
-        for off, n in ((lay.off_rewards, 4 * env.n_agents), (lay.off_actions, env.n_agents), (lay.off_done, 1), (lay.off_truncated, 1),
-                       (lay.off_obs, env.flattened_state_size)):
+        for off, n in [(lay.off_rewards, 4 * env.n_agents), (lay.off_actions, env.n_agents), (lay.off_done, 1), (lay.off_truncated, 1)] + segs:
             assert not used[off:off + n].any(), "record fields overlap"
             used[off:off + n] = True
-        assert not np_(env.unpack_record(traj["record"]))[:, :, ~used].any(), "padding bytes are zero"
+        if lay.n_obs_segments == 1:  # (the family's record keeps eight job slots whatever the job count: unused slots hold zeros / stale cells)
+            assert not np_(env.unpack_record(traj["record"]))[:, :, ~used].any(), "padding bytes are zero"
     env._export(full=True)
     compare_full_state(env, ob, f"{name} after packed rollouts")
 

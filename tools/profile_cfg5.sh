@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the policy-in-the-loop configuration (BASELINE config 5) under rocprofv3 --kernel-trace --stats,
-# (the policy loop in blocks of 64 ticks per launch -- bench.py's default --policy-block -- and with one launch per tick), unprofiled beside it, and the network kernel's own timing (tools/qnet_bench.py).  Output under gpurun_out/prof_$PROF_TAG/cfg5/.
+# (the policy loop in blocks of 5 ticks per launch -- bench.py's default --policy-block: the reference trainer's train_step_interval --, with one launch per tick and in blocks of 64), unprofiled beside it, and the network kernel's own timing (tools/qnet_bench.py).  Output under gpurun_out/prof_$PROF_TAG/cfg5/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/prof_${PROF_TAG:-cur}/cfg5
 rm -rf "$OUT" && mkdir -p "$OUT"
@@ -11,6 +11,10 @@ python3 $CMD > $OUT/bench_unprofiled.json 2> $OUT/unprofiled.err || exit 1
 # the same loop with ONE launch per tick (susnet_qnet_policy_step): what a caller that cannot batch ticks gets
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_per_tick -- python3 $CMD --policy-block 0 > $OUT/bench_per_tick_under_rocprofv3.json 2> $OUT/stats_per_tick.err || exit 1
 find $OUT/stats_per_tick -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_per_tick.csv
+# ... and with 64 ticks per launch (run_game's loop with fixed networks: round 4's headline form)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_block64 -- python3 $CMD --policy-block 64 > $OUT/bench_block64_under_rocprofv3.json 2> $OUT/stats_block64.err || exit 1
+find $OUT/stats_block64 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_block64.csv
+python3 tools/policy_block_bench.py > $OUT/policy_block_bench.json 2> $OUT/policy_block.err || exit 1
 python3 tools/qnet_bench.py > $OUT/qnet_bench.json 2> $OUT/qnet.err || exit 1
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 echo cfg5-profile-ok

@@ -4,7 +4,7 @@
 # Output under gpurun_out/prof_$PROF_TAG/<config>/ (a fresh directory per tag: gpurun MERGES into the local gpurun_out/).  --kernel-trace --stats in one run; each PMC group in its own run (never
 # combined with other trace domains).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-CONFIGS="${*:-cfg2 cfg3 cfg4 tag5}"
+CONFIGS="${*:-cfg2 cfg2w cfg3 cfg4 tag5}"
 for CFG in $CONFIGS; do
   OUT=gpurun_out/prof_${PROF_TAG:-cur}/$CFG
   rm -rf "$OUT" && mkdir -p "$OUT"

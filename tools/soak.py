@@ -14,7 +14,8 @@ import test_gpu_parity as T  # noqa: E402
 
 om.build()
 NAMES = sys.argv[1:] or ["itg_1v1_nowalls", "base_1v2_j4_14", "tagging_1v4_j5", "base_2v6_j4_14",
-                         "tagging_2v6_j4_14", "itg_1v5_j3"]  # (the last two: byte-parallel FAMILY kernels -- run-time job count, roles drawn per episode)
+                         "tagging_2v6_j4_14", "itg_1v5_j3",  # (these two: byte-parallel FAMILY kernels -- run-time job count, roles drawn per episode)
+                         "itg_1v1_walls", "itg_1v10", "base_3v9_j8_16"]  # (round 5: the wall-map duel kernel; 11 / 12 agents, three imposters)
 for name in NAMES:
     B, seed = 1536, 5
     spec = dict(T.CONFIGS[name])
