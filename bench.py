@@ -627,7 +627,7 @@ def main():
                     rp = measure(sp, sp["batch"], "policy", "flat", 320 if blk else 64, 64 if blk else 16, 1, graph_ticks=gt, policy_fused=fused, block_ticks=blk)
                     entry[label] = {"value": sp["batch"] * rp["steps"] / rp["seconds"], "us_per_tick": rp["seconds"] * 1e6 / rp["steps"],
                                     "ticks_timed": rp["steps"], **({"ticks_per_graph": gt} if gt else {}), **({"ticks_per_launch": blk} if blk else {})}
-                    if rp["qnet"] is not None and (blk or "roofline" not in entry):
+                    if rp["qnet"] is not None and (blk == 5 or "roofline" not in entry):  # (the roofline of the form `value` is taken from: 5 ticks per launch)
                         entry["roofline"] = rp["qnet"]
                     del rp
                 # BOTH teams by their networks (visualize.py:547-562: run_game's loop): the same kernel swapping the LDS image between the two

@@ -773,11 +773,12 @@ def test_two_lanes_per_env_rollout_equals_the_one_lane_kernel(pkg, oracle_mod, m
 
 
 @pytest.mark.parametrize("name,obs", [("itg_1v5_j3", "flat"), ("base_2v6_j4_14", "flat"), ("base_2v6_j4_14", "planes"), ("tagging_2v6_j4_14", "planes"),
-                                      ("tagging_1v4_j5", "planes")])
+                                      ("tagging_1v4_j5", "planes"), ("itg_1v10", "flat"), ("base_3v9_j8_16", "planes"), ("itg_1v1_walls", "planes")])
 def test_fused_rollout_with_float_observations_matches_oracle(pkg, oracle_mod, name, obs):
-    """The OUT_ANY instantiations of the byte-parallel rollouts (any observation mode fused in: the largest kernels of the library, the
-    8-agent ones past 256 registers with values parked in accumulator registers): a ragged last wave, many in-launch resets, the full
-    trajectory and the float observation of every tick against the oracle."""
+    """The OUT_ANY instantiations of the byte-parallel rollouts (any observation mode fused in: the largest kernels of the library -- round 5:
+    back under 256 registers, no accumulator registers, the episode of a finishing lane drawn on the spot): a ragged last wave, many
+    in-launch resets, the full trajectory and the float observation of every tick against the oracle.  The 11 / 12-agent games hand this
+    mode to the generic kernel on the same state blob and streams; the 1v1 wall-map game runs its table kernel here."""
     B, T, seed = 64 * 9 + 23, 90, 13
     short = name + "@20"  # (episodes of at most 20 steps: every environment resets several times inside the launch)
     CONFIGS[short] = dict(CONFIGS[name], kw=dict(CONFIGS[name]["kw"], max_time_steps=20))

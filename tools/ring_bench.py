@@ -71,6 +71,20 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / KERNEL_LAUNCHES
             kernel[tile] = {"us_per_launch": us, "written_TBs": per * B * row_bytes / us / 1e6}
+            # ... and IN ITS PLACE in the pipeline: right after the rollout launch that wrote the trajectory block (which then still sits in
+            # the 256 MB cache), each append bracketed by its own event pair -- what populate_fused / collect pay per block
+            pairs = []
+            for _ in range(KERNEL_LAUNCHES):
+                env_t.rollout_into(per, bufs)
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                launch()
+                p1.record()
+                pairs.append((p0, p1))
+            torch.cuda.synchronize()
+            us_p = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+            kernel[tile]["in_pipeline"] = {"us_per_launch_median": us_p[len(us_p) // 2], "us_per_launch_mean": sum(us_p) / len(us_p),
+                                           "written_TBs_at_median": per * B * row_bytes / us_p[len(us_p) // 2] / 1e6, "launches": len(us_p)}
             del env_t, bufs, window, io
         os.environ.pop("SUSNET_RING_TILE", None)
         out[-1]["append_launch"] = {"ticks": per, "rows": per * B, "launches_timed": KERNEL_LAUNCHES, "by_variant": kernel,
