@@ -167,6 +167,7 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     uint32_t pend80 = 0;
     uint32_t idx4 = w.ridx; // reward-table byte index per agent: the episode's base + what this step adds (see step_swar)
     bool changed = check_win; // something the win rules read moved this step (the same in both lanes of a pair)
+#ifndef SUSNET_EXP_SKIP_KILL // diagnostic builds only (tools/build_variant_tu.sh, profiles/r05_step_sections_cfg4.md): a section's share of the tick -- WRONG results
     {
         const uint64_t cur0 = rng.cur; // the step's (aligned) event cursor: a landed kill takes word cur0 + kills landed before it
         const Pair pk = both_halves(kill80), pr = both_halves(R), px = both_halves(w.xy);
@@ -225,15 +226,21 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
             pend80 |= v80 & ge80;    // killed before its own turn: it never acts
         }
     }
+#endif
     w.xy = sel_bytes(ff_from80(pend80), w.xy, newt); // a victim that had not acted yet stays where it was
     mid(); // (the fused rollout samples the next tick here: see step_swar)
 
     // ---- FIX (base.py:518-524) / SABOTAGE (527-533) through the cell -> job map (see susnet_swar.h) ------------------------------
     uint32_t fc80 = 0, sc80 = 0;
+#ifndef SUSNET_EXP_SKIP_JOBS
     if (W::kBase) {
         static_assert(J <= 4, "one word of job status bytes");
         const uint32_t hj80 = jobat & (fix80 | sab80) & ~pend80; // (flag bits only) a living job actor, not killed before its turn, on a job
+#ifdef SUSNET_EXP_FREE_JOBS // experiment: the body without its gate (same results)
+        {
+#else
         if (__builtin_amdgcn_ballot_w64(hj80 != 0u) != 0ull) {
+#endif
             const uint32_t sel = jobat & 0x03030303u;                                  // the job's index
             const uint32_t dj80 = __builtin_amdgcn_perm(0u, w.jd, sel) << 7;          // completed? (0x80 / 0)
             const uint32_t succ = hj80 & ~(w.im80 ^ dj80);                             // crew on an open job, imposter on a completed one
@@ -294,12 +301,19 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
             }
         }
     }
+#endif
 
     // ---- check_win_condition: base.py:409-460 / pred_prey.py:78-99 --------------------------------------------------------------
     uint32_t wsel = 0u;
     done = false;
     if (W::kBase && J == 0) changed = true; // FourRoomEnv's "all jobs done" holds at every step when there are none (base.py:430)
+#ifdef SUSNET_EXP_SKIP_WIN
+    if (false) {
+#elif defined(SUSNET_EXP_FREE_WIN)
+    {
+#else
     if (__builtin_amdgcn_ballot_w64(changed) != 0ull) { // (only when a kill landed / a job flipped this step: see step_swar)
+#endif
         const uint32_t mine = (uint32_t)__popc(w.al80) | ((uint32_t)__popc(w.al80 & w.im80) << 8);
         const Pair pa = both_halves(mine);
         const uint32_t sum = pa.lo + pa.hi;
@@ -322,7 +336,11 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     // from the episode's base (Swar2::ridx) and collected this step's assignment codes and outcome where they arose
     {
 #pragma unroll
+#ifdef SUSNET_EXP_SKIP_REWARDS
+        for (int i = 0; i < 4; i++) rr[i] = __uint_as_float(idx4 ^ (uint32_t)i);
+#else
         for (int i = 0; i < 4; i++) rr[i] = lds_reward_lookup((idx4 >> (8 * i)) & 0xffu);
+#endif
     }
     trunc = false; // base.py:392-395: t saturates at max_time_steps - 1
     if (e.t == (uint32_t)(c.max_t - 1)) trunc = true;

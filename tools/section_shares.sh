@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): what each section of the byte-parallel step costs, from DIAGNOSTIC builds that leave one section out
 # (tools/build_variant.sh lib_skip_X -DSUSNET_EXP_SKIP_X for X in KILL JOBS TAG REWARDS: wrong results, right instruction counts for the rest).
-#   usage: tools/section_shares.sh "cfg3 tag5"      -> gpurun_out/sections.txt : VALU / SALU / LDS per wave-tick, cycles, launch us per variant
+#   usage: [LIBS="shipped lib4_skip_KILL ..."] tools/section_shares.sh "cfg3 tag5"      -> gpurun_out/sections.txt : VALU / SALU / LDS per wave-tick, cycles, launch us per variant
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 CFGS="${1:-cfg3 tag5}"
 OUTF=gpurun_out/sections.txt
 : > $OUTF
-for CFG in $CFGS; do for LIB in shipped lib_skip_KILL lib_skip_JOBS lib_skip_TAG lib_skip_REWARDS; do
+for CFG in $CFGS; do for LIB in ${LIBS:-shipped lib_skip_KILL lib_skip_JOBS lib_skip_TAG lib_skip_REWARDS}; do
   if [ "$LIB" = shipped ]; then unset SUSNET_LIB_PATH; else export SUSNET_LIB_PATH=$PWD/tools/_exp/$LIB.so; [ -f "$SUSNET_LIB_PATH" ] || continue; fi
   OUT=gpurun_out/sections/$CFG/$LIB
   rm -rf "$OUT" && mkdir -p "$OUT"
