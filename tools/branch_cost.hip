@@ -71,6 +71,13 @@
 #define P_SCMP_FILL8_T(r) "v_add_u32 v100, v90, v100\nv_cmp_eq_u32 s[22:23], v91, v100\n" FILL8 "s_cmp_eq_u64 s[22:23], 0\ns_cbranch_scc1 1f\nv_mov_b32 v131, v131\n1:\n"
 #define P_VCCZ_FILL8_AFTER_NT(r) "v_add_u32 v100, v90, v100\n" FILL8 "v_cmp_ne_u32 vcc, v91, v100\ns_cbranch_vccz 1f\nv_mov_b32 v131, v131\n1:\n"
 
+// gates on values that are already on the scalar side (a wave-uniform flag kept as a lane mask / as a 32-bit scalar)
+#define P_SMASK_VCCNZ_NT(r) "v_add_u32 v" S(r) ", v90, v" S(r) "\ns_andn2_b64 vcc, exec, s[22:23]\ns_cbranch_vccz 1f\nv_mov_b32 v131, v131\n1:\n"
+#define P_SMASK_VCCNZ_T(r) "v_add_u32 v" S(r) ", v90, v" S(r) "\ns_andn2_b64 vcc, exec, s[22:23]\ns_cbranch_vccnz 1f\nv_mov_b32 v131, v131\n1:\n"
+#define P_SCMP64_NT(r) "v_add_u32 v" S(r) ", v90, v" S(r) "\ns_cmp_lg_u64 s[22:23], 0\ns_cbranch_scc1 1f\nv_mov_b32 v131, v131\n1:\n"
+#define P_SCMP32_NT(r) "v_add_u32 v" S(r) ", v90, v" S(r) "\ns_cmp_lg_u32 s21, 0\ns_cbranch_scc1 1f\nv_mov_b32 v131, v131\n1:\n"
+#define P_SCMP32_T(r) "v_add_u32 v" S(r) ", v90, v" S(r) "\ns_cmp_eq_u32 s21, 0\ns_cbranch_scc1 1f\nv_mov_b32 v131, v131\n1:\n"
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k(uint32_t *out, long long *cycles, int iters) {
     __shared__ uint32_t lds[64]; // (the LDS round-trip test walks it: every word holds a byte offset inside it)
@@ -115,6 +122,11 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, long long *cycles, int i
         if constexpr (KIND == 54) asm volatile(REP16(P_SCMP_FILL8_NT) : : : CLOB);
         if constexpr (KIND == 55) asm volatile(REP16(P_SCMP_FILL8_T) : : : CLOB);
         if constexpr (KIND == 56) asm volatile(REP16(P_VCCZ_FILL8_AFTER_NT) : : : CLOB);
+        if constexpr (KIND == 60) asm volatile("s_mov_b64 s[22:23], 0\n" REP16(P_SMASK_VCCNZ_NT) : : : CLOB);
+        if constexpr (KIND == 61) asm volatile("s_mov_b64 s[22:23], 0\n" REP16(P_SMASK_VCCNZ_T) : : : CLOB);
+        if constexpr (KIND == 62) asm volatile("s_mov_b64 s[22:23], 0\n" REP16(P_SCMP64_NT) : : : CLOB);
+        if constexpr (KIND == 63) asm volatile("s_mov_b32 s21, 0\n" REP16(P_SCMP32_NT) : : : CLOB);
+        if constexpr (KIND == 64) asm volatile("s_mov_b32 s21, 0\n" REP16(P_SCMP32_T) : : : CLOB);
         if constexpr (KIND == 40) asm volatile(REP16(P_INLINE_CONST) : : : CLOB);
         if constexpr (KIND == 41) asm volatile(REP16(P_ROT4) : : : CLOB);
         if constexpr (KIND == 42) asm volatile(REP16(P_ROT8) : : : CLOB);
@@ -196,6 +208,11 @@ int main() {
     run<53>("v_add, v_cmp -> vcc, FOUR v_add, s_cbranch_vccz not taken (per five + branch)", out, cyc);
     run<54>("v_add, v_cmp -> sgpr pair, eight v_add, s_cmp_eq_u64, s_cbranch_scc1 not taken", out, cyc);
     run<55>("v_add, v_cmp -> sgpr pair, eight v_add, s_cmp_eq_u64, s_cbranch_scc1 taken", out, cyc);
+    run<60>("v_add, s_andn2_b64 vcc, exec, mask (set long before), s_cbranch_vccz not taken", out, cyc);
+    run<61>("v_add, s_andn2_b64 vcc, exec, mask, s_cbranch_vccnz taken", out, cyc);
+    run<62>("v_add, s_cmp_lg_u64 mask, 0, s_cbranch_scc1 not taken", out, cyc);
+    run<63>("v_add, s_cmp_lg_u32 flag, 0, s_cbranch_scc1 not taken", out, cyc);
+    run<64>("v_add, s_cmp_eq_u32 flag, 0, s_cbranch_scc1 taken", out, cyc);
     run<40>("v_add_u32 with an inline constant", out, cyc);
     run<41>("four rotating chains of v_add_u32 (per FOUR)", out, cyc);
     run<42>("eight rotating chains of v_add_u32 (per EIGHT)", out, cyc);
