@@ -18,14 +18,15 @@ OUT = os.path.join(PKG_DIR, "libsusnet_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-pass-failed"]
 # -amdgpu-sched-strategy=max-ilp for the stepping kernels: they run at ONE wave per SIMD by design (a wave per 64 environments), so the
 # scheduler's default goal -- registers for occupancy -- buys nothing; scheduled for instruction-level parallelism the same sources run
-# faster (same-box A/B, gpurun_out/r05v, r05w, r05x: cfg3 +3-7 %, cfg4 +3-5 %, tag5 +1-2 %, cfg2 +0.5-2 %) and every ISA check below still
-# passes.  Not for the Q-network units: their matrix sections are scheduled by hand (sched_barrier) and the network kernel alone came
-# out 11 % slower under it (49.3 -> 55.1 us; the one-kernel tick unchanged)
+# faster (same-box A/B, gpurun_out/r05v, r05w, r05x: cfg3 +3-7 %, cfg4 +3-5 %, tag5 +1-2 %; the family within +- 2 %) and every ISA check
+# below still passes.  Not for the Q-network units: their matrix sections are scheduled by hand (sched_barrier) and the network kernel
+# alone came out 11 % slower under it (49.3 -> 55.1 us; the one-kernel tick unchanged).  Nor for the 1v1 unit: no-walls within noise
+# (+0.7 %), the wall-map flavour 3 % slower (300.9 -> 292.1 G, gpurun_out/r05ad)
 ILP_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def flags_for(src: str):
-    return FLAGS + ([] if os.path.basename(src).startswith("inst_qnet") else ILP_FLAGS)
+    return FLAGS + ([] if os.path.basename(src).startswith(("inst_qnet", "inst_cfg2")) else ILP_FLAGS)
 
 
 def sources():

@@ -1034,7 +1034,8 @@ static int qnet_step_launch(susnet_env *env, bool tape, const QnetFuse &f, const
     // configurations reserves (step_wave<.., TABLES = false> carves none: nothing stages the action stream here)
     const size_t group_words = HasGroupWords<S>::value ? (size_t)kGroupWords * 4 : 0;
     const size_t rest = step_lds - (size_t)kTableWords * 4 - group_words + (size_t)kStashWords * 4;
-    const size_t sh = (size_t)kTableWords * 4 + (size_t)Q::kLdsBytes + 4 * rest;
+    const bool two = tape || f.crew_packed != nullptr; // (both teams: the second network's biases stay resident behind the image)
+    const size_t sh = (size_t)kTableWords * 4 + (size_t)(two ? Q::kLdsBytesTwo : Q::kLdsBytes) + 4 * rest;
     if (sh > 160 * 1024) return fail(SUSNET_E_INVALID, "susnet_qnet_policy_step: observation too large for the LDS left beside the network image");
     QStepArgs ka{env->c, env->s, f.packed, f.q_out, f.n_out, a, o, (int)rest, n_ticks, ts, f.crew_packed, f.crew_q_out, f.crew_n_out, 0};
     if (tape) HIP_TRY((qnet_step_launch_k<ROW, S, TapeRng, true>(ka, sh, st))); // (TAPE: both networks, checked by the caller)

@@ -48,7 +48,10 @@ struct QNet {
     static constexpr int kGather = 2 * ROW::A + 1;
     static constexpr int kRows = kTail + (1 << kTailBits);
     static constexpr int kRowStride = H1 + 4; // floats: consecutive rows start 4 banks apart
-    static constexpr int kW1 = kRows * kRowStride;
+    // (padded to a multiple of 4 KiB: the both-teams tick swaps this part of the image by 1 KiB global -> LDS transfers, the same number for
+    // each of the four waves: qnet_swap_issue)
+    static constexpr int kW1 = (kRows * kRowStride + 1023) / 1024 * 1024;
+    static constexpr int kTailFloats = H2 + H3 + H4 + NO; // the biases of layers 2..5 behind it
     // packed image, in floats (susnet_qnet_pack writes it, the kernel reads it).  First the part every workgroup copies to LDS
     // (layer 1 transposed + the biases of layers 2..5), then ALL 32 x 32 weight blocks of layers 2..5 as one stream in the order the
     // kernel consumes them, then the four PReLU slopes.
@@ -56,6 +59,7 @@ struct QNet {
     static constexpr int oW2 = kLdsFloats, oW3 = oW2 + H1 * H2, oW4 = oW3 + H2 * H3, oW5 = oW4 + H3 * H4, oSlope = oW5 + H4 * NO, kPacked = oSlope + 4;
     static constexpr int kBlocks = (H1 * H2 + H2 * H3 + H3 * H4 + H4 * NO) / 1024; // of the stream
     static constexpr int kLdsBytes = kLdsFloats * 4;
+    static constexpr int kLdsBytesTwo = kLdsBytes + kTailFloats * 4; // both teams: the second network's biases stay resident behind the image
     static constexpr int kThreads = 256, kEnvsPerWave = 64, kEnvsPerBlock = 4 * kEnvsPerWave;
     static_assert(kTailBits >= 0 && kTailBits <= 4 && kLdsFloats % 4 == 0 && H2 / 32 == 4 && (H1 / 32) % 2 == 0, "16-byte copies; the pipelined stage is written for this shape");
 };
@@ -115,8 +119,12 @@ struct WeightStream {
     }
 };
 // a register-resident dense layer on stream blocks B0 .. B0 + KB NB - 1 ([kb][nb] order): in[KB][T] (activated) -> out[NB][T] (bias + sum)
-template <int B0, int KB, int NB, int T, int LAST>
-__device__ __forceinline__ void dense(const WeightStream &ws, f32x4 (&w)[4][4], const float *bias, const f32x16 (&in)[KB][T], f32x16 (&out)[NB][T]) {
+// mid(i): called in the middle of block i's matrix instructions (the both-teams tick issues its image transfers there, a few per block)
+struct NoMidBlock {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int B0, int KB, int NB, int T, int LAST, class MIDB = NoMidBlock>
+__device__ __forceinline__ void dense(const WeightStream &ws, f32x4 (&w)[4][4], const float *bias, const f32x16 (&in)[KB][T], f32x16 (&out)[NB][T], MIDB &&mid = MIDB()) {
     const int h = ws.lane >> 5;
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) bias_block<T>(bias, nb, h, out[nb]);
@@ -128,6 +136,9 @@ __device__ __forceinline__ void dense(const WeightStream &ws, f32x4 (&w)[4][4], 
             __builtin_amdgcn_sched_barrier(0);
         }
         mfma_half<0, T>(w[b % 4], in[kb], out[nb]);
+        __builtin_amdgcn_sched_barrier(0);
+        mid(i);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_half<1, T>(w[b % 4], in[kb], out[nb]);
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -137,9 +148,16 @@ __device__ __forceinline__ void dense(const WeightStream &ws, f32x4 (&w)[4][4], 
 // image of layer 1; wave w of block g owns environments (4 g + w) * 64 ..; lane = (column m = lane % 32, half h = lane / 32) of each
 // of its two 32-environment tiles.
 // Returns the greedy action of the environment lane `lane` of the wave owns (b0 + lane): argmax of its Q row, first maximum.
-template <class ROW, bool UNIT>
-__device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&aw)[2][ROW::A], const float *pk, const float *w1, float *q_out, int n_out,
-                                              int64_t b0, int lane) {
+// btail: the biases of layers 2..5 in LDS (b2 | b3 | b4 | b5); after: synchronise() is called once the layer-1 image has been read for
+// the last time, transfer(i, n) in the middle of block i of layer 3's n weight blocks (the both-teams tick fetches the other network's
+// image there, a share per block: the rest of the pass covers the transfer)
+struct NoAfter {
+    __device__ __forceinline__ void synchronise() const {}
+    __device__ __forceinline__ void transfer(int, int) const {}
+};
+template <class ROW, bool UNIT, class AFTER = NoAfter>
+__device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&aw)[2][ROW::A], const float *pk, const float *w1, const float *btail, float *q_out,
+                                              int n_out, int64_t b0, int lane, AFTER &&after = AFTER()) {
     using Q = QNet<ROW>;
     constexpr int T = 2, R = Q::kGather;
     const int h = lane >> 5;
@@ -184,7 +202,7 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
     // interleaving, and the k loop is unrolled so that every LDS offset is an immediate.
     f32x16 a2[Q::H2 / 32][T];
 #pragma unroll
-    for (int nb = 0; nb < Q::H2 / 32; nb++) bias_block<T>(w1 + Q::oB2, nb, h, a2[nb]);
+    for (int nb = 0; nb < Q::H2 / 32; nb++) bias_block<T>(btail, nb, h, a2[nb]);
     static_for<0, Q::H1 / 32>([&](auto kc) __attribute__((always_inline)) {
         constexpr int kb = decltype(kc)::value;
         ws.template request<2>(w, kb * 4 + 2, kLast);
@@ -215,6 +233,7 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
         mfma_half<1, T>(w[3], hb, a2[3]);
         __builtin_amdgcn_sched_barrier(0);
     });
+    after.synchronise();
 #pragma unroll
     for (int nb = 0; nb < Q::H2 / 32; nb++)
 #pragma unroll
@@ -222,19 +241,19 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
 
     constexpr int kB3 = Q::H1 / 32 * 4, kB4 = kB3 + (Q::H2 / 32) * (Q::H3 / 32), kB5 = kB4 + (Q::H3 / 32) * (Q::H4 / 32);
     f32x16 a3[Q::H3 / 32][T];
-    dense<kB3, Q::H2 / 32, Q::H3 / 32, T, kLast>(ws, w, w1 + Q::oB3, a2, a3);
+    dense<kB3, Q::H2 / 32, Q::H3 / 32, T, kLast>(ws, w, btail + Q::H2, a2, a3, [&](int i) __attribute__((always_inline)) { after.transfer(i, (Q::H2 / 32) * (Q::H3 / 32)); });
 #pragma unroll
     for (int nb = 0; nb < Q::H3 / 32; nb++)
 #pragma unroll
         for (int t = 0; t < T; t++) prelu16<UNIT>(a3[nb][t], slope3);
 
     f32x16 a4[Q::H4 / 32][T];
-    dense<kB4, Q::H3 / 32, Q::H4 / 32, T, kLast>(ws, w, w1 + Q::oB4, a3, a4);
+    dense<kB4, Q::H3 / 32, Q::H4 / 32, T, kLast>(ws, w, btail + Q::H2 + Q::H3, a3, a4);
 #pragma unroll
     for (int t = 0; t < T; t++) prelu16<UNIT>(a4[0][t], slope4);
 
     f32x16 a5[Q::NO / 32][T];
-    dense<kB5, Q::H4 / 32, Q::NO / 32, T, kLast>(ws, w, w1 + Q::oB5, a4, a5); // dqn.py:328: no activation after the last Linear
+    dense<kB5, Q::H4 / 32, Q::NO / 32, T, kLast>(ws, w, btail + Q::H2 + Q::H3 + Q::H4, a4, a5); // dqn.py:328: no activation after the last Linear
 
     // The Q rows go out through a raw buffer over this wave's rows: a row past the batch or an entry past n_out gets an offset the
     // hardware's range check drops -- NO divergent branch anywhere in this function.  (Every vector register is spoken for here and the
@@ -318,8 +337,8 @@ __global__ __launch_bounds__(256) void k_qnet(Consts c, State s, const float *pk
     bool unit = true; // wave-uniform: scalar loads and compares
 #pragma unroll
     for (int l = 0; l < 4; l++) unit = unit && pk[Q::oSlope + l] >= 0.0f && pk[Q::oSlope + l] <= 1.0f;
-    if (unit) qnet_wave<ROW, true>(c, aw, pk, w1, q_out, n_out, b0, lane);
-    else qnet_wave<ROW, false>(c, aw, pk, w1, q_out, n_out, b0, lane);
+    if (unit) qnet_wave<ROW, true>(c, aw, pk, w1, w1 + Q::oB2, q_out, n_out, b0, lane);
+    else qnet_wave<ROW, false>(c, aw, pk, w1, w1 + Q::oB2, q_out, n_out, b0, lane);
 }
 
 // The whole policy tick in ONE kernel (visualize.py:547-582 with a reference MLP as the imposters' network and a random crew): the
@@ -389,9 +408,42 @@ __device__ __forceinline__ void qnet_fill_image(const float *pk, float *w1, int 
     }
 }
 
-// BOTH TEAMS by their networks (pk_crew != NULL): per tick the workgroup runs the imposters' network, swaps the LDS image for the crew's
-// (two barriers: everybody has read the old image / the new one is complete), runs the crew's, and each wave steps its environments with
-// both argmaxes; the next tick swaps back.  Waves past the batch stay in the loop for the fills and barriers (they hold no environment:
+// The both-teams tick's image swap: the layer-1 part of another network's image (kW1 floats, whole KiB) global -> LDS without passing
+// through registers, 1 KiB per instruction and wave (global_load_lds_dwordx4: lane L's 16 bytes land at M0 + 16 L), piece p of the
+// image by wave p % 4, rounds [r0, r1) of the image's kW1 / 1024.  Inline assembly on purpose: with the compiler's builtin every
+// vector-memory wait behind a transfer becomes vmcnt(0) (two kinds of events pending on one counter: it assumes nothing about their order)
+// and the next weight block's wait takes the whole transfer; as assembly the compiler does not see them -- the hardware counter is
+// in order, so its waits for the weight stream stay correct but ALSO wait for every transfer issued before them: the caller issues a
+// few per weight block, right behind that block's wait, so that they are a block's matrix instructions old when the next wait comes
+// (all 26 at one point: 2 us gained of 6).  The caller waits (qnet_swap_wait) and synchronises the workgroup before anybody reads the image.
+template <class ROW>
+__device__ __forceinline__ void qnet_swap_issue(const float *pk_other, uint32_t w1_lds_addr, int wave, int lane, int r0, int r1) {
+    using Q = QNet<ROW>;
+    constexpr int kRounds = Q::kW1 * 4 / 4096;
+    static_assert(Q::kW1 % 1024 == 0 && Q::oW1 == 0, "whole rounds of four KiB, at the start of the packed image");
+    const uint32_t voff = (uint32_t)lane * 16u + (uint32_t)wave * 1024u;
+    const uint64_t gbase = reinterpret_cast<uint64_t>(pk_other);
+    const uint32_t lbase = w1_lds_addr + (uint32_t)wave * 1024u;
+#pragma unroll
+    for (int i = 0; i < kRounds; i++) {
+        if (i >= r0 && i < r1) { // (compile-time once inlined: no run-time condition around the assembly -- inside a branch the compiler takes
+                                 // for divergent it hands the scalar operands over in vector registers)
+            const uint32_t la = lbase + (uint32_t)i * 4096u;
+            const uint64_t gb = gbase + (uint64_t)i * 4096u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(la), "v"(voff), "s"(gb) : "memory");
+        }
+    }
+}
+template <class ROW>
+constexpr int qnet_swap_rounds() { return QNet<ROW>::kW1 * 4 / 4096; }
+__device__ __forceinline__ void qnet_swap_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// BOTH TEAMS by their networks (pk_crew != NULL): per tick the workgroup runs the imposters' network and the crew's on ONE LDS image
+// slot.  A pass reads the layer-1 part of its image in its first stage only (layers 1 + 2); right behind that stage the workgroup
+// synchronises (everybody is done with it) and starts the transfer of the OTHER network's layer-1 part into the slot (qnet_swap_issue),
+// which the rest of the pass -- 320 matrix instructions -- covers; before the next pass's first stage: wait + barrier.  The biases of
+// layers 2..5 are read throughout a pass, so both networks' stay resident (the second set behind the image).  Each wave steps its
+// environments with both argmaxes.  Waves past the batch stay in the loop for the fills and barriers (they hold no environment:
 // no network pass, no step).  With the crew's network and no exploration nothing is drawn from the action stream, so numpy-tape handles
 // are served too (RNG = TapeRng: the reference's collection loop with two networks, tests/golden/collect_*.npz).
 // TWO: both networks (a kernel of its own: the one-network tick keeps its register budget).
@@ -406,6 +458,11 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
     const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t b00 = ((int64_t)blockIdx.x * 4 + wave0) * Q::kEnvsPerWave;
     qnet_fill_image<ROW>(ka.pk, w1, (int)threadIdx.x);
+    if constexpr (TWO) { // the crew network's biases, resident behind the image
+        if (threadIdx.x < Q::kTailFloats / 4)
+            reinterpret_cast<f32x4 *>(w1 + Q::kLdsFloats)[threadIdx.x] = reinterpret_cast<const f32x4 *>(ka.pk_crew + Q::oB2)[threadIdx.x];
+    }
+    constexpr int kImageFloats = Q::kLdsFloats + (TWO ? Q::kTailFloats : 0);
     // the step's table image (launch-constant): written ONCE, by the first wave, and published to the other three by the barrier -- no
     // wave writes LDS words another one reads after this point (but for the image swaps of TWO, which have barriers of their own)
     if (wave0 == 0) {
@@ -448,10 +505,29 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
             }
         }
         float *qk = q_out ? reinterpret_cast<float *>(reinterpret_cast<char *>(q_out) + (int64_t)k * qstride) : nullptr;
-        const uint32_t am = unit ? qnet_wave<ROW, true>(c, aw, pk, w1, qk, n_out, b0, lane) : qnet_wave<ROW, false>(c, aw, pk, w1, qk, n_out, b0, lane);
+        const float *btail = TWO && pass ? w1 + Q::kLdsFloats : w1 + Q::oB2;
+        // both teams: behind the first stage the other network's layer-1 image starts to arrive, a share per weight block of layer 3 (see above)
+        struct After {
+            int pass;
+            int lane0, wave0;
+            __device__ __forceinline__ void synchronise() const {
+                if constexpr (TWO) __syncthreads();
+            }
+            __device__ __forceinline__ void transfer(int i, int n) const {
+                if constexpr (TWO) {
+                    KernargPtr kq = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                    int lane_a = lane0, wave_a = wave0;
+                    asm volatile("" : "+s"(kq), "+v"(lane_a), "+s"(wave_a));
+                    const float *other = pass ? SUSNET_KARG(kq, pk) : SUSNET_KARG(kq, pk_crew);
+                    const int per = (qnet_swap_rounds<ROW>() + n - 1) / n;
+                    qnet_swap_issue<ROW>(other, (uint32_t)kTableWords * 4u, wave_a, lane_a, i * per, (i + 1) * per);
+                }
+            }
+        } after{pass, lane0, wave0};
+        const uint32_t am = unit ? qnet_wave<ROW, true>(c, aw, pk, w1, btail, qk, n_out, b0, lane, after) : qnet_wave<ROW, false>(c, aw, pk, w1, btail, qk, n_out, b0, lane, after);
         int lane_s = lane0; // (a fresh copy: nothing lane-derived crosses the matrix section)
         asm volatile("" : "+v"(lane_s));
-        uint32_t *stash = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
+        uint32_t *stash = dyn + kTableWords + kImageFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
         stash[(pass ? 64 : 0) + lane_s] = am;
     };
 #pragma clang loop unroll(disable)
@@ -465,17 +541,19 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
         } else {
 #pragma clang loop unroll(disable)
             for (int pass = 0; pass < 2; pass++) {
-                if (pass > 0 || k > 0) { // the other team's image: every wave has read the one that is there; nobody reads before it is whole
-                    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-                    asm volatile("" : "+s"(kp));
-                    const float *pk = pass ? SUSNET_KARG(kp, pk_crew) : SUSNET_KARG(kp, pk);
-                    int tid_f = wave0 * 64 + lane0;
-                    asm volatile("" : "+v"(tid_f));
-                    __syncthreads();
-                    qnet_fill_image<ROW>(pk, w1, tid_f);
+                if (pass > 0 || k > 0) { // this pass's image was requested behind the previous pass's first stage: it is whole once every wave's transfers are
+                    qnet_swap_wait();
                     __syncthreads();
                 }
                 if (live) net_pass(pass, k);
+                else { // a wave without environments: its share of the barrier and of the transfer
+                    KernargPtr kq = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                    int lane_a = lane0, wave_a = wave0;
+                    asm volatile("" : "+s"(kq), "+v"(lane_a), "+s"(wave_a));
+                    const float *other = pass ? SUSNET_KARG(kq, pk) : SUSNET_KARG(kq, pk_crew);
+                    __syncthreads();
+                    qnet_swap_issue<ROW>(other, (uint32_t)kTableWords * 4u, wave_a, lane_a, 0, qnet_swap_rounds<ROW>());
+                }
             }
         }
         if (live) {
@@ -489,7 +567,7 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
             const ObsArgs &o = ka.o; // (a component list indexed at run time: read in place)
             const TickStrides ts = SUSNET_KARG(kp, ts);
             const int step_lds_bytes = SUSNET_KARG(kp, step_lds_bytes);
-            uint32_t *stash = dyn + kTableWords + Q::kLdsFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
+            uint32_t *stash = dyn + kTableWords + kImageFloats + (size_t)wave * (size_t)(step_lds_bytes / 4);
             wave_lds_publish();
             const int a_imp = (int)stash[lane], a_crew = TWO ? (int)stash[64 + lane] : -1;
             uint32_t *rest = stash + kStashWords;
@@ -504,6 +582,7 @@ __global__ __launch_bounds__(256) void k_qnet_step(QStepArgs ka) {
             step_wave<RNG, S, false>(c, s, ak, o, dyn, rest, lane, b0, a_imp, (int64_t)k, a_crew);
         }
     }
+    if constexpr (TWO) qnet_swap_wait(); // (the last pass's transfer: nothing reads it, but it targets this workgroup's LDS)
 }
 #undef SUSNET_KARG
 

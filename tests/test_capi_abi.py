@@ -200,7 +200,8 @@ def test_qnet_pack_layout(pkg):
     pad = [88, 256, 128, 64, 32, 32]
     RS = 256 + 4
     rows = 84 + 1 + 16  # position bits, the zero row, 2^4 combinations of the four bits behind the one-hots
-    lds = rows * RS + sum(pad[2:])  # what a workgroup copies to LDS: layer 1 transposed, then the biases of layers 2..5
+    w1_floats = -(-rows * RS // 1024) * 1024  # (zero-padded to whole rounds of 4 KiB: the both-teams tick swaps it by 1 KiB transfers, one per wave and round)
+    lds = w1_floats + sum(pad[2:])  # what a workgroup copies to LDS: layer 1 transposed, then the biases of layers 2..5
     assert n == lds + sum(pad[l] * pad[l + 1] for l in range(1, 5)) + 4
     rng = np.random.default_rng(0)
     W = [rng.standard_normal((dims[l + 1], dims[l])).astype(np.float32) for l in range(5)]
@@ -219,7 +220,8 @@ def test_qnet_pack_layout(pkg):
             if (v >> bit) & 1:
                 want = want + W[0][:, 84 + bit]  # float32, lowest bit first
         np.testing.assert_array_equal(w1[85 + v, :200], want)
-    off = rows * RS
+    assert not out[rows * RS:w1_floats].any()
+    off = w1_floats
     for l in range(1, 5):
         bias = np.zeros(pad[l + 1], dtype=np.float32)
         bias[:dims[l + 1]] = Bv[l]
