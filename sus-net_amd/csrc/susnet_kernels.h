@@ -824,17 +824,22 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
         }
     };
-    auto stage_b = [&]() __attribute__((always_inline)) {
+    // (the step's `mid` interface has two parts -- the two-lane kernel puts each inside one of the step's gates, susnet_swar.h NoMid; here
+    // part 0 is all of B and the step runs it between its kill and job sections: split and placed in the gates this kernel measured slower)
+    auto stage_b = [&](int part) __attribute__((always_inline)) {
         if constexpr (!RNG::kNumpy) {
-            TickWords<GW::W> tw = tw_n;
-            sample_actions_swar<S, 0>(c, w, rng, tw, 0ull, act_n);
-            if constexpr (RankLut<S>::kOk) raw_n = ranks_lut_issue<S, 0>(rng, tw, 0ull);
-            else if constexpr (S::kOrd > 0) ranks_from_stream<S, 0>(c, 0u, rng, tw, 0ull, true, R_n);
+            if (part == 0) {
+                TickWords<GW::W> tw = tw_n;
+                sample_actions_swar<S, 0>(c, w, rng, tw, 0ull, act_n);
+                if constexpr (RankLut<S>::kOk) raw_n = ranks_lut_issue<S, 0>(rng, tw, 0ull);
+                else if constexpr (S::kOrd > 0) ranks_from_stream<S, 0>(c, 0u, rng, tw, 0ull, true, R_n);
+            }
         }
     };
+    MidParts<decltype(stage_b)> mid_b{stage_b, tw_n.wd[0], tw_n.wd[0]};
     if (!RNG::kNumpy && active && a.n_ticks > 0) {
         stage_a(0, true);
-        stage_b();
+        stage_b(0);
     }
     // the next episode of my environment, drawn ahead (production stream; see draw_episode).  Not in OUT_ANY: the drawn-ahead episode is a
     // second copy of the whole byte-parallel state (47 registers with 8 agents and 2 imposters), and next to the general observation
@@ -884,9 +889,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
             bool done, trunc;
             // (the win rules run unconditionally at the launch's first tick only: the state may come from outside; see step_swar)
 #ifdef SUSNET_STAMPS
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2, stage_b, jm, tick == 0, tick != a.n_ticks - 1);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, wseg2, mid_b, jm, tick == 0, tick != a.n_ticks - 1);
 #else
-            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, nullptr, stage_b, jm, tick == 0, tick != a.n_ticks - 1);
+            step_swar<S>(c, T, w, e, rng, act, R, rr, done, trunc, nullptr, mid_b, jm, tick == 0, tick != a.n_ticks - 1);
 #endif
             KSTAMP(1);
             if (kTraj) {
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar(Consts c, State s, Roll
                     jm.set_jobs(st, S::J(c));
                     // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
                     // continue what the action draws (role-dependent ranges) left of their last word
-                    stage_b();
+                    stage_b(0);
                     // info counters of a terminal step stay readable until the next step: only the launch's last tick can be observed
                     if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
                     else zero_metrics(e);
@@ -1164,16 +1169,22 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             for (int k = 0; k < GW::W; k++) tw_n.wd[k] = gw.read(pos, k);
         }
     };
-    auto stage_b = [&]() __attribute__((always_inline)) {
+    TickWords<GW::W> tw_b = tw_n; // (B in two parts: see k_rollout_swar)
+    auto stage_b = [&](int part) __attribute__((always_inline)) {
         if constexpr (!RNG::kNumpy) {
-            TickWords<GW::W> tw = tw_n;
-            act_n = sample_actions_pair<S, 0>(w, rng, tw, 0ull);
-            if constexpr (RankLut<S>::kOk) raw_n = ranks_lut_issue<S, 0>(rng, tw, 0ull);
+            if (part == 0) {
+                tw_b = tw_n;
+                act_n = sample_actions_pair<S, 0>(w, rng, tw_b, 0ull);
+            } else {
+                if constexpr (RankLut<S>::kOk) raw_n = ranks_lut_issue<S, 0>(rng, tw_b, 0ull);
+            }
         }
     };
+    MidParts<decltype(stage_b)> mid_b{stage_b, tw_n.wd[0], tw_b.rem};
     if (!RNG::kNumpy && a.n_ticks > 0) {
         stage_a(0, true);
-        stage_b();
+        stage_b(0);
+        stage_b(1);
     }
     // the next episode of my environment, drawn ahead (production stream; see draw_episode): both lanes of a pair hold their own half
     W wn = w;
@@ -1210,7 +1221,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
         float rr[4];
         bool done, trunc;
         if constexpr (RNG::kNumpy) step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0, false);
-        else step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0, tick != a.n_ticks - 1, stage_b);
+        else step_swar2<S>(c, w, e, rng, act, R, rr, done, trunc, jm, tick == 0, tick != a.n_ticks - 1, mid_b);
         // (the rewards come out of LDS lookups issued at the very end of the step: they are stored LAST, behind everything else
         // the tick writes, so that nothing waits for them)
         if (kTraj) {
@@ -1261,7 +1272,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
                 jm.set_jobs(st, S::J(c));
                 // new roles: the next tick's action digits again, from the words already fetched -- and its turn ranks, whose digits
                 // continue what the action draws (role-dependent ranges) left of their last word
-                if constexpr (!RNG::kNumpy) stage_b();
+                if constexpr (!RNG::kNumpy) {
+                    stage_b(0);
+                    stage_b(1);
+                }
                 if (tick == a.n_ticks - 1) e.flags |= FLAG_FRESH;
                 else zero_metrics(e);
             }

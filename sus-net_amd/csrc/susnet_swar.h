@@ -482,11 +482,37 @@ __device__ __forceinline__ void ranks_from_lut(PhiloxRng &rng, AS &as, uint64_t 
 
 // One step.  act: role-relative action bytes (valid for their roles); R: turn ranks (byte = rank | 0x80).
 // Rewards go to rr[] (float32: the compiled-in kernels are only selected when every reward constant is float-exact).
+// mid: independent work the caller wants done inside the step -- the fused rollouts' sampling of the NEXT tick, in two parts: run(0) the
+// action digits, run(1) the turn ranks.  Where it goes: between the COMPARE of a ballot gate and its BRANCH.  At one wave per SIMD a gate
+// costs 35-41 cycles when the branch follows its compare directly -- the compare's way to the scalar side -- and ~20 with a dozen
+// independent instructions in between (profiles/r05_step_sections_cfg4.md); the compiler sinks a compare it knows down to the branch and
+// lifts independent work above one it does not, so the compare is written as assembly and the FIRST operand of the work passes through it
+// (tie(part): a register the part reads first).  In the two-lane step (susnet_swar2.h) part 0 sits in the first kill turn's candidate gate,
+// part 1 in the job section's gate: cfg4 +1.1 % for the first gate alone (gpurun_out/r05af), +2.6 % for both (r05ag).  The one-lane step
+// below runs both parts between its kill and job sections, as before: inside the gates it measured slower (see there).
 struct NoMid {
-    __device__ __forceinline__ void operator()() const {}
+    static constexpr bool kOn = false;
+    mutable uint32_t none = 0;
+    __device__ __forceinline__ void run(int) const {}
+    __device__ __forceinline__ uint32_t &tie(int) const { return none; } // (never reached: the callers test kOn)
 };
-// mid(): called between the kill section and the job section -- the fused rollouts put the next tick's sampling there (its
-// multiplies and table reads fill the waits of this tick's own lookups)
+template <class T> struct MidOf { typedef T type; };
+template <class T> struct MidOf<T &> { typedef T type; };
+template <class T> struct MidOf<T &&> { typedef T type; };
+template <class F>
+struct MidParts {
+    static constexpr bool kOn = true;
+    F &f;
+    uint32_t &t0, &t1;
+    __device__ __forceinline__ void run(int part) const { f(part); }
+    __device__ __forceinline__ uint32_t &tie(int part) const { return part ? t1 : t0; }
+};
+// ballot(v != 0) with the compare pinned HERE, above whatever reads `tie` next
+__device__ __forceinline__ uint64_t early_ballot_nz(uint32_t v, uint32_t &tie) {
+    uint64_t m;
+    asm volatile("v_cmp_ne_u32_e64 %0, 0, %2" : "=s"(m), "+v"(tie) : "v"(v));
+    return m;
+}
 // jm: the fused rollouts' cell -> job map (JobMap), or NoJobMap = match the job cells by compare chain (one-step kernels).
 // check_win = false: the caller guarantees that the state it hands over is not a won one (every tick of a fused rollout but its
 // first: the previous tick's check covered it, or a reset replaced it) -- the win rules then run only behind a ballot on "something
@@ -745,7 +771,10 @@ __device__ __forceinline__ void step_swar(const Consts &c, const Tables &T, Swar
     // final positions: a victim that had not acted yet stays where it was
 #pragma unroll
     for (int q = 0; q < NW; q++) w.xy[q] = sel_bytes(ff_from80(pend80[q]), w.xy[q], newt[q]);
-    mid();
+    // (both parts here, between the kill section and the job section: inside the gates, as in susnet_swar2.h, the one-lane kernels came out
+    // 1.6-1.8 % SLOWER -- cfg3 127.4 -> 125.5 G, tag5 51.0 -> 50.1 G, gpurun_out/r05ag -- where the two-lane kernel gained 2.6 %)
+    mid.run(0);
+    mid.run(1);
 
     WSTAMP(1);
     // ---- FIX (base.py:518-524) / SABOTAGE (527-533): first job on the agent's own cell (544-546; job cells are distinct) ------

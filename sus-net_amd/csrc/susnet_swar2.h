@@ -181,18 +181,30 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
         bool second_first = false; // two imposters: the one with the earlier turn kills first
         if (NI == 2) second_first = kb[1] != 0u && (kb[0] == 0u || rb[1] < rb[0]);
         uint32_t landed = 0; // kills this environment landed so far in this step
+        // the second turn's gate ("somebody attempts": the second turn only has work where BOTH imposters do) is known HERE: its compare is
+        // pinned above the whole first turn (the ranks pass through it: susnet_swar.h NoMid), its branch finds the mask long settled
+        uint32_t Rt = R;
+        uint64_t second_any = 0ull;
+        if (NI == 2) second_any = early_ballot_nz(second_first ? kb[0] : kb[1], Rt);
 #pragma unroll
         for (int it = 0; it < NI; it++) {
             const int s0 = it, s1 = NI - 1 - it;
             const uint32_t kbi = second_first ? kb[s1] : kb[s0], rbi = second_first ? rb[s1] : rb[s0], cbi = second_first ? cb[s1] : cb[s0];
-            // (no ballot on "somebody attempts" for the first kill turn: some environment of the wave nearly always does; the second
-            // turn only has work where BOTH imposters attempt)
-            if (it > 0 && __builtin_amdgcn_ballot_w64(kbi != 0u) == 0ull) continue;
-            const uint32_t ge80 = (R - (rbi & k7f)) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
+            // (no ballot on "somebody attempts" for the first kill turn: some environment of the wave nearly always does)
+            if (it > 0 && (NI == 2 ? second_any == 0ull : __builtin_amdgcn_ballot_w64(kbi != 0u) == 0ull)) continue;
+            const uint32_t ge80 = (Rt - (rbi & k7f)) & k80; // rank >= the killer's: has not acted yet (the killer itself included)
             const uint32_t pos = sel_bytes(ff_from80(ge80), w.xy, newt);
             const uint32_t cand = zero80(pos ^ cbi) & w.crew80 & kbi; // living crew NOW on the killer's cell (base.py:535-542), if it attempts
             // (a crew member on the killer's cell is rare: the rest -- the exchange between the two lanes included -- sits behind a ballot)
-            if (__builtin_amdgcn_ballot_w64(cand != 0u) == 0ull) continue;
+            bool none;
+            if constexpr (MidOf<MID>::type::kOn) { // (the next tick's action digits between the first gate's compare and its branch: susnet_swar.h NoMid)
+                if (it == 0) {
+                    const uint64_t any = early_ballot_nz(cand, mid.tie(0));
+                    mid.run(0);
+                    none = any == 0ull;
+                } else none = __builtin_amdgcn_ballot_w64(cand != 0u) == 0ull;
+            } else none = __builtin_amdgcn_ballot_w64(cand != 0u) == 0ull;
+            if (none) continue;
             const Pair pc = both_halves(cand);
             const uint32_t nc = (uint32_t)__popc(pc.lo) + (uint32_t)__popc(pc.hi);
             // base.py:497: uniform among the candidates (ascending agent index); with one candidate the lowest set flag
@@ -228,7 +240,15 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     }
 #endif
     w.xy = sel_bytes(ff_from80(pend80), w.xy, newt); // a victim that had not acted yet stays where it was
-    mid(); // (the fused rollout samples the next tick here: see step_swar)
+#ifdef SUSNET_EXP_SKIP_KILL
+    mid.run(0);
+#endif
+    constexpr bool kMidInJobGate = MidOf<MID>::type::kOn && W::kBase; // (part 1 sits in the job section's gate where there is one)
+#ifdef SUSNET_EXP_SKIP_JOBS
+    mid.run(1);
+#else
+    if constexpr (!kMidInJobGate) mid.run(1);
+#endif
 
     // ---- FIX (base.py:518-524) / SABOTAGE (527-533) through the cell -> job map (see susnet_swar.h) ------------------------------
     uint32_t fc80 = 0, sc80 = 0;
@@ -236,10 +256,15 @@ __device__ __forceinline__ void step_swar2(const Consts &c, Swar2<S> &w, Env &e,
     if (W::kBase) {
         static_assert(J <= 4, "one word of job status bytes");
         const uint32_t hj80 = jobat & (fix80 | sab80) & ~pend80; // (flag bits only) a living job actor, not killed before its turn, on a job
+        uint64_t actors;
+        if constexpr (kMidInJobGate) { // (the next tick's turn ranks between this gate's compare and its branch)
+            actors = early_ballot_nz(hj80, mid.tie(1));
+            mid.run(1);
+        } else actors = __builtin_amdgcn_ballot_w64(hj80 != 0u);
 #ifdef SUSNET_EXP_FREE_JOBS // experiment: the body without its gate (same results)
         {
 #else
-        if (__builtin_amdgcn_ballot_w64(hj80 != 0u) != 0ull) {
+        if (actors != 0ull) {
 #endif
             const uint32_t sel = jobat & 0x03030303u;                                  // the job's index
             const uint32_t dj80 = __builtin_amdgcn_perm(0u, w.jd, sel) << 7;          // completed? (0x80 / 0)
