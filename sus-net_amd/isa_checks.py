@@ -631,6 +631,18 @@ def parked_under_divergence(asm, kernels=None):
     return bad
 
 
+def m0_conflicts(asm):
+    """The both-teams Q-network tick issues its LDS transfers from inline assembly (`s_mov_b32 m0, sN` + `global_load_lds_dwordx4`:
+    susnet_qnet.h qnet_swap_issue) WITHOUT telling the compiler that M0 changes (it is a reserved register: not clobberable).  That is
+    only sound while nothing else in the library reads or writes M0: -> every line that mentions m0 and is not that move."""
+    bad = []
+    for ln in asm.splitlines():
+        code = ln.split("//")[0]
+        if re.search(r"\bm0\b", code) and not re.search(r"\bs_mov_b32\s+m0,\s*s\d+", code):
+            bad.append(code.strip())
+    return bad
+
+
 def scratch_instructions(asm):
     return [ln.strip() for ln in asm.splitlines() if re.search(r"\bscratch_", ln.split("//")[0])]
 
@@ -672,6 +684,9 @@ def _analyse(obj: str):
     if pk:
         problems.append(f"{os.path.basename(obj)}: {len(pk)} accumulator-register values read under a wider EXEC than they were written under, in "
                         f"{sorted(set(demangle([b[0] for b in pk]).values()))[:4]}, e.g. {[b[1:] for b in pk[:2]]}")
+    m0 = m0_conflicts(asm)
+    if m0:
+        problems.append(f"{os.path.basename(obj)}: {len(m0)} uses of M0 beside the LDS-transfer moves (qnet_swap_issue writes it unannounced), e.g. {m0[:2]}")
     sc = scratch_instructions(asm)
     if sc:
         problems.append(f"{os.path.basename(obj)}: {len(sc)} scratch instructions, e.g. {sc[:2]}")

@@ -378,6 +378,15 @@ def test_parking_move_checker_is_value_level(isa):
     assert isa.parked_under_divergence(_listing(K, region(["v_accvgpr_write_b32 a207, v11"], ["v_accvgpr_read_b32 v11, a207"])), kernels=("k_qnet",)) == []
 
 
+def test_m0_is_only_written_by_the_lds_transfer_moves(isa, shipped):
+    """The both-teams tick's image transfers set M0 from inline assembly without the compiler knowing (a reserved register cannot be
+    clobbered): sound only while nothing else in the library touches M0 -- checked on the shipped ISA by every build (`m0_conflicts`)."""
+    assert isa.m0_conflicts("\ts_mov_b32 m0, s13\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v0, s[10:11]\n") == []
+    assert isa.m0_conflicts("\ts_mov_b32 m0, s13\n\ts_movrels_b32 s1, s2\n\tds_gws_init v0 gds\n\ts_mov_b32 m0, 0x1000\n\tv_readlane_b32 s1, v2, m0\n") == [
+        "s_mov_b32 m0, 0x1000", "v_readlane_b32 s1, v2, m0"]
+    assert not [p for p in shipped[1] if "M0" in p]
+
+
 def test_no_accumulator_registers_outside_the_q_network_kernels(isa, shipped):
     """the value-level check passes on every kernel (test_shipped_library_passes_the_build_time_isa_checks), and the
     kernels that need no matrix core keep out of the accumulator registers altogether -- the environment kernels run under divergent
