@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
     BufDst drec = make_buf_dst(a.record, nt * (uint64_t)c.B * (uint64_t)a.record_bytes, 0u);
     const uint32_t rec_pb = (uint32_t)c.B * 16u, rec_b16 = (uint32_t)b * 16u;
     const uint32_t at_rew = h * rec_pb + rec_b16, at_act = 2u * rec_pb + rec_b16 + 4u * h, at_pos = (2u + h) * rec_pb + rec_b16 + (h ? 0u : 8u),
-                   at_al = 3u * rec_pb + rec_b16 + 8u + 4u * h, at_tail = 4u * rec_pb + rec_b16;
+                   at_al = 3u * rec_pb + rec_b16 + 8u + 4u * h, at_tail = h ? 0xffffff00u : 4u * rec_pb + rec_b16; // (0xffffff00: past any slab a 32-bit record count can describe)
     const uint32_t slab_a = (uint32_t)AB, slab_d = (uint32_t)c.B, slab_o = (uint32_t)o.tick_stride;
     const uint32_t slab_rec = (uint32_t)c.B * (uint32_t)a.record_bytes;
     if (a.n_ticks > 0) {
@@ -1294,8 +1294,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout_swar2(Consts c, State s, Rol
             const uint32_t x = w.xy & 0x0f0f0f0fu, y = (w.xy >> 4) & 0x0f0f0f0fu;
             drec.st64(at_pos, __builtin_amdgcn_perm(y, x, 0x05010400u), __builtin_amdgcn_perm(y, x, 0x07030602u));
             drec.st32(at_al, w.al & k01);
-            if (h == 0u)
-                drec.st128(at_tail, w.jobs_obs[0], w.jobs_obs[1], w.jd, (done ? 1u : 0u) | (trunc ? 0x100u : 0u));
+            // (the tail is the environment's: the lane of the high word stores it to an offset the tick slab's range check drops -- a divergent
+            // `if (h == 0)` is a branch per tick, ~20 cycles at one wave per SIMD)
+            drec.st128(at_tail, w.jobs_obs[0], w.jobs_obs[1], w.jd, (done ? 1u : 0u) | (trunc ? 0x100u : 0u));
             drec.st128(at_rew, __float_as_uint(rr[0]), __float_as_uint(rr[1]), __float_as_uint(rr[2]), __float_as_uint(rr[3]));
         }
         if (kTraj) store_row_f32<4>(dr, rr);
