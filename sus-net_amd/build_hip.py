@@ -21,12 +21,15 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-p
 # faster (same-box A/B, gpurun_out/r05v, r05w, r05x: cfg3 +3-7 %, cfg4 +3-5 %, tag5 +1-2 %; the family within +- 2 %) and every ISA check
 # below still passes.  Not for the Q-network units: their matrix sections are scheduled by hand (sched_barrier) and the network kernel
 # alone came out 11 % slower under it (49.3 -> 55.1 us; the one-kernel tick unchanged).  Nor for the 1v1 unit: no-walls within noise
-# (+0.7 %), the wall-map flavour 3 % slower (300.9 -> 292.1 G, gpurun_out/r05ad)
+# (+0.7 %), the wall-map flavour 3 % slower (300.9 -> 292.1 G, gpurun_out/r05ad).  Nor for susnet_capi.hip: its kernels (feature rows,
+# ring append, reset, observe) run many waves per SIMD and live on occupancy -- under max-ilp k_ring_append goes from 69 to 77 vector
+# registers (7 -> 6 waves), k_featurize / k_observe from 83 to 105 (5 -> 4)
 ILP_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def flags_for(src: str):
-    return FLAGS + ([] if os.path.basename(src).startswith(("inst_qnet", "inst_cfg2")) else ILP_FLAGS)
+    name = os.path.basename(src)
+    return FLAGS + (ILP_FLAGS if name.startswith("inst_") and not name.startswith(("inst_qnet", "inst_cfg2")) else [])
 
 
 def sources():

@@ -378,6 +378,22 @@ def test_parking_move_checker_is_value_level(isa):
     assert isa.parked_under_divergence(_listing(K, region(["v_accvgpr_write_b32 a207, v11"], ["v_accvgpr_read_b32 v11, a207"])), kernels=("k_qnet",)) == []
 
 
+def test_scheduling_strategy_per_translation_unit(pkg):
+    """`-amdgpu-sched-strategy=max-ilp` goes to the stepping units that run at one wave per SIMD and gain from it (cfg3 / cfg4 / tag5 / the
+    family / the generic kernels) and to nothing else: the Q-network units (hand-scheduled matrix sections: 11 % slower), the 1v1 unit (its
+    wall-map kernel: 3 % slower) and susnet_capi.hip (many-waves kernels that live on occupancy) keep the default -- build_hip.flags_for."""
+    import importlib
+
+    bh = importlib.import_module(pkg.__name__ + ".build_hip")
+    ilp = lambda name: "-amdgpu-sched-strategy=max-ilp" in bh.flags_for("/x/" + name)
+    assert all(ilp(n) for n in ("inst_cfg3.hip", "inst_cfg4.hip", "inst_tag5.hip", "inst_fam_a8_tag.hip", "inst_fam_a12_base_ni3.hip", "inst_generic.hip", "inst_a2.hip"))
+    assert not any(ilp(n) for n in ("susnet_capi.hip", "inst_cfg2.hip", "inst_qnet_onehot1.hip", "inst_qnet_onehot3.hip", "inst_qnet_coord1.hip"))
+    import os
+
+    have = {os.path.basename(f) for f in bh.sources()}
+    assert {"susnet_capi.hip", "inst_cfg2.hip", "inst_cfg3.hip", "inst_cfg4.hip", "inst_tag5.hip", "inst_qnet_onehot3.hip"} <= have
+
+
 def test_m0_is_only_written_by_the_lds_transfer_moves(isa, shipped):
     """The both-teams tick's image transfers set M0 from inline assembly without the compiler knowing (a reserved register cannot be
     clobbered): sound only while nothing else in the library touches M0 -- checked on the shipped ISA by every build (`m0_conflicts`)."""

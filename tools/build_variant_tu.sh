@@ -7,7 +7,7 @@ NAME="$1"; TU="$2"; shift 2
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OBJ=$(mktemp -d)
 mkdir -p "$ROOT/tools/_exp"
-case "$TU" in inst_qnet*|inst_cfg2*) ILP="" ;; *) ILP="-mllvm -amdgpu-sched-strategy=max-ilp" ;; esac  # (as sus-net_amd/build_hip.py flags_for)
+case "$TU" in inst_qnet*|inst_cfg2*|susnet_capi*) ILP="" ;; *) ILP="-mllvm -amdgpu-sched-strategy=max-ilp" ;; esac  # (as sus-net_amd/build_hip.py flags_for)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wno-pass-failed $ILP "$@" -c -o "$OBJ/$TU.o" "$ROOT/sus-net_amd/csrc/$TU.hip" || { echo "FAILED $TU"; exit 1; }
 OTHERS=$(ls "$ROOT"/sus-net_amd/_obj/*.o | grep -v "/$TU.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/_exp/$NAME.so" "$OBJ/$TU.o" $OTHERS && echo "built tools/_exp/$NAME.so"
