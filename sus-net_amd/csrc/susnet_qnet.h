@@ -71,10 +71,24 @@ __device__ __forceinline__ float prelu(float x, float slope) {
     if constexpr (UNIT) return __builtin_fmaxf(x, slope * x);
     else return x > 0.0f ? x : slope * x;
 }
+// four elements: the multiply as ONE vector expression (two v_pk_mul_f32 instead of four v_mul_f32; the same products)
+template <bool UNIT>
+__device__ __forceinline__ f32x4 prelu4(f32x4 x, float slope) {
+    const f32x4 m = x * slope;
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = UNIT ? __builtin_fmaxf(x[i], m[i]) : (x[i] > 0.0f ? x[i] : m[i]);
+    return r;
+}
 template <bool UNIT>
 __device__ __forceinline__ void prelu16(f32x16 &v, float slope) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = prelu<UNIT>(v[i], slope);
+    for (int q = 0; q < 4; q++) {
+        const f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        const f32x4 r = prelu4<UNIT>(x, slope);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[4 * q + i] = r[i];
+    }
 }
 
 // HALF of a 32 x 32 weight block (float4 2 HALF and 2 HALF + 1 of the lane's 16 k values, MFMA steps 8 HALF .. 8 HALF + 7) times
@@ -215,8 +229,9 @@ __device__ __forceinline__ uint32_t qnet_wave(const Consts &c, const uint32_t (&
                 f32x4 v = *reinterpret_cast<const f32x4 *>(rowp[t][0] + kb * 32 + 8 * j);
 #pragma unroll
                 for (int q = 1; q < R; q++) v += *reinterpret_cast<const f32x4 *>(rowp[t][q] + kb * 32 + 8 * j);
+                const f32x4 pv = prelu4<UNIT>(v, slope1);
 #pragma unroll
-                for (int r = 0; r < 4; r++) hb[t][4 * j + r] = prelu<UNIT>(v[r], slope1);
+                for (int r = 0; r < 4; r++) hb[t][4 * j + r] = pv[r];
             }
         __builtin_amdgcn_sched_barrier(0);
         mfma_half<0, T>(w[0], hb, a2[0]);
